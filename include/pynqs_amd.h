@@ -1,0 +1,95 @@
+/*
+ * pynqs_amd.h -- C ABI of libpynqs_amd.so, the MI355X (gfx950) determinant / local-energy engine.
+ *
+ * This is the drop-in boundary for PyNQS' `libs.C_extension` hot path.  The reference has no C ABI:
+ * its boundary is a pybind11/LibTorch module (cpp_src/tensor/bind.cpp:317-391) whose functions take
+ * at::Tensor.  Each entry point below names the reference interface it replaces (file:line relative
+ * to the PyNQS tree); the Python shim pynqs_amd/C_extension.py re-creates the reference's Python
+ * signatures on top of these calls (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (HIP, same device as `stream`) unless marked [host].
+ *  - ONVs are little-endian 64-bit words, `len = (sorb-1)/64 + 1` words per determinant; orbital j is
+ *    bit j%64 of word j/64, even j = alpha, odd j = beta (cpp_src/tensor/cpu_tensor.cpp:8-44).
+ *    The reference's uint8[n, 8*len] tensors are these words viewed as bytes.
+ *  - `dtype`: PYNQS_F32 or PYNQS_F64 = element type of h1e / h2e / hmat (the reference dispatches on
+ *    h1e's dtype, cpp_src/tensor/cpu_tensor.cpp:249,298).
+ *  - h1e: T[sorb*sorb] row-major; h2e: T[pair*(pair+1)/2], pair = sorb*(sorb-1)/2, antisymmetrised
+ *    packed triangle (cpp_src/tensor/integral.cpp:6-60).
+ *  - The caller owns all buffers.  Calls enqueue work on `stream` (a hipStream_t; NULL = default
+ *    stream) and return without synchronising, like the reference's CUDA path (cuda/kernel.cu:266-277).
+ *  - Return value: PYNQS_OK or a negative error code; pynqs_last_error() gives a thread-local message.
+ *    No exceptions cross the ABI.  n == 0 is a valid no-op.
+ *  - Thread-safe and re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef PYNQS_AMD_H
+#define PYNQS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYNQS_ABI_VERSION 1
+
+#define PYNQS_OK 0
+#define PYNQS_EINVAL (-1)  /* bad argument: sorb/nele out of range, null pointer, bad dtype        */
+#define PYNQS_ELAUNCH (-2) /* HIP launch failure (message carries hipGetErrorString)               */
+#define PYNQS_ELENGTH (-3) /* check_sorb: sorb needs more words than PYNQS_MAX_SORB_LEN            */
+#define PYNQS_EOVERFLOW (-4) /* check_sorb: too many electrons / virtual orbitals                 */
+
+#define PYNQS_F32 0
+#define PYNQS_F64 1
+
+/* Limits.  The reference fixes MAX_SORB_LEN at compile time (cpp_src/common/default.h:3-10); here the
+ * word count is a run-time dispatch over 1..3 and the limits are those of its MAX_SORB_LEN=3 build. */
+#define PYNQS_MAX_SORB_LEN 3
+#define PYNQS_MAX_SORB 192
+#define PYNQS_MAX_NELE 120
+#define PYNQS_MAX_NVIR 120
+
+int pynqs_abi_version(void);
+const char *pynqs_last_error(void);
+
+/* [host] cpp_src/cpu/excitation.cpp:8-16 (get_Num_SinglesDoubles): singles+doubles, identity excluded. */
+int64_t pynqs_num_sd(int sorb, int noA, int noB);
+
+/* [host] cpp_src/tensor/bind.cpp:282-301 (check_sorb): PYNQS_OK, PYNQS_ELENGTH or PYNQS_EOVERFLOW. */
+int pynqs_check_sorb(int sorb, int nele);
+
+/* cpp_src/tensor/bind.cpp:239-250 (get_comb_hij_fused) -> cpu_tensor.cpp:220-272 / cuda kernel.cu:224-277.
+ * comb [nbatch][ncomb][len] (row 0 = bra itself; may be NULL to skip the write), hmat T[nbatch][ncomb]
+ * (column 0 = <x|H|x>), ncomb = pynqs_num_sd()+1. */
+int pynqs_comb_hij_fused(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                         const void *h1e, const void *h2e, int dtype, uint64_t *comb, void *hmat,
+                         void *stream);
+
+/* cpp_src/tensor/bind.cpp:66-83 (get_comb_tensor) -> cpu_tensor.cpp:164-218.  comb as above;
+ * comb_pm1 (may be NULL) = double[nbatch][ncomb][sorb], the flag_bit=True +-1 expansion (the reference
+ * hard-codes double there, cpu_tensor.cpp:191-195). */
+int pynqs_comb(const uint64_t *bra, int64_t nbatch, int sorb, int noA, int noB, uint64_t *comb,
+               double *comb_pm1, void *stream);
+
+/* cpp_src/tensor/bind.cpp:39-64 (get_hij_torch) -> cpu_tensor.cpp:274-325.  ket_is_3d: ket[n][m][len]
+ * (local-energy mode) else ket[m][len] (full matrix).  hmat T[n][m]; excitation degree > 2 gives 0. */
+int pynqs_hij(const uint64_t *bra, int64_t n, const uint64_t *ket, int64_t m, int ket_is_3d,
+              const void *h1e, const void *h2e, int dtype, int sorb, int nele, void *hmat, void *stream);
+
+/* cpp_src/tensor/bind.cpp:24-37 (onv_to_tensor) -> cpu_tensor.cpp:46-88: out T[n][sorb] = +1 / -1. */
+int pynqs_onv_to_pm1(const uint64_t *bra, int64_t n, int sorb, int dtype, void *out, void *stream);
+
+/* cpp_src/tensor/bind.cpp:9-22 (tensor_to_onv) -> cpu_tensor.cpp:8-44: occ uint8[n][sorb] (1 = occupied,
+ * anything else = empty) -> out uint64[n][len]. */
+int pynqs_pm01_to_onv(const uint8_t *occ, int64_t n, int sorb, uint64_t *out, void *stream);
+
+/* cpp_src/tensor/bind.cpp:216-236 (wavefunction_lut, little_endian=True) -> cpu_tensor.cpp:589-688 /
+ * cuda kernel.cu:608-680.  keys uint64[nkeys][len] sorted ascending as multi-word integers (most
+ * significant word last); idx[i] = position of onv[i] or -1, mask[i] = found. */
+int pynqs_wavefunction_lut(const uint64_t *keys, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb,
+                           int64_t *idx, uint8_t *mask, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYNQS_AMD_H */

@@ -1,0 +1,261 @@
+"""Drop-in replacement for PyNQS' ``libs.C_extension`` hot-path functions on MI355X.
+
+Same names, positional/keyword arguments, shapes, dtypes and error behaviour as the reference's
+pybind11 module (cpp_src/tensor/bind.cpp:317-391, libs/C_extension.pyi), implemented on the C ABI of
+libpynqs_amd.so (include/pynqs_amd.h).  torch is used for device memory and streams only.
+
+Device rule.  The reference runs its CPU kernels when every input is a CPU tensor.  This package has
+no CPU kernels: CPU inputs are staged to the current HIP device, the HIP kernels run, and results are
+returned on the CPU, so callers that hold CPU tensors keep working.  Without a GPU (or without the
+built library) every compute function raises -- there is no fallback.
+
+Error rule.  The reference mixes TORCH_CHECK (-> RuntimeError) with C asserts that abort
+the process; here every such check raises RuntimeError.  check_sorb raises ValueError / OverflowError
+like bind.cpp:290-299.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _native as N
+
+MAX_SORB_LEN = 3  # run-time word-count dispatch; the reference compiles one build per length
+MAX_SORB = 64 * MAX_SORB_LEN
+MAX_NELE = 120
+
+__all__ = [
+    "tensor_to_onv", "onv_to_tensor", "get_comb_tensor", "get_hij_torch", "get_comb_hij_fused",
+    "wavefunction_lut", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
+    "MAX_SORB", "MAX_SORB_LEN", "MAX_NELE",
+]
+
+
+# ---- plumbing ----------------------------------------------------------------------------------------
+def _bra_len(sorb: int) -> int:
+    return (sorb - 1) // 64 + 1
+
+
+def _gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("pynqs_amd: no HIP device available (this package has no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stage(*ts: Tensor):
+    """Returns (device, tensors on that device, all_cpu)."""
+    all_cpu = all(t.device.type == "cpu" for t in ts)
+    dev = next((t.device for t in ts if t.device.type == "cuda"), None) or _gpu()
+    return dev, [t if t.device == dev else t.to(dev) for t in ts], all_cpu
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _contig(t: Tensor, name: str) -> None:
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")  # CHECK_CONTIGUOUS, common/default.h:17-18
+
+
+def _check_onv(t: Tensor, name: str, sorb: int, dims) -> None:
+    _contig(t, name)
+    if t.dtype != torch.uint8:
+        raise RuntimeError(f"{name} must be torch.uint8")  # assert in bind.cpp:13,29,51,74
+    if t.dim() not in dims:
+        raise RuntimeError(f"{name} must have dim in {dims}, got {t.dim()}")
+    if t.size(-1) != 8 * _bra_len(sorb):
+        raise RuntimeError(f"{name}: last dim {t.size(-1)} != 8 * bra_len = {8 * _bra_len(sorb)} for sorb = {sorb}")
+
+
+def _fdtype(h1e: Tensor, h2e: Tensor) -> int:
+    if h1e.dtype != h2e.dtype or h1e.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("h1e/h2e must both be float32 or both float64")  # AT_DISPATCH_FLOATING_TYPES
+    return N.PYNQS_F64 if h1e.dtype == torch.float64 else N.PYNQS_F32
+
+
+def _check_integrals(h1e: Tensor, h2e: Tensor, sorb: int) -> None:
+    _contig(h1e, "h1e_tensor"); _contig(h2e, "h2e_tensor")
+    pair = sorb * (sorb - 1) // 2
+    if h1e.numel() != sorb * sorb or h2e.numel() != pair * (pair + 1) // 2:
+        # the reference reads out of bounds here; an explicit error is the safe equivalent
+        raise RuntimeError(f"h1e/h2e sizes {h1e.numel()}/{h2e.numel()} do not match sorb = {sorb}")
+
+
+def get_Num_SinglesDoubles(sorb: int, noA: int, noB: int) -> int:
+    """utils/public_function.py:132 / cpp_src/cpu/excitation.cpp:8-16."""
+    return int(N.lib().pynqs_num_sd(sorb, noA, noB))
+
+
+# ---- API -------------------------------------------------------------------------------------------
+def check_sorb(sorb: int, nele: int) -> None:
+    """bind.cpp:282-301.  The word count is dispatched at run time, so only sorb > 192 is a length error."""
+    N.check(N.lib().pynqs_check_sorb(int(sorb), int(nele)), "check_sorb")
+
+
+def tensor_to_onv(bra: Tensor, sorb: int) -> Tensor:
+    """bind.cpp:9-22 -> cpu_tensor.cpp:8-44: 0/1 uint8 states (1-D or 2-D) -> packed onv uint8[n, 8*len]."""
+    _contig(bra, "bra_tensor")
+    if bra.dtype != torch.uint8 or bra.dim() not in (1, 2):
+        raise RuntimeError("bra_tensor must be a 1-D or 2-D torch.uint8 tensor")
+    L = _bra_len(sorb)
+    if bra.numel() == 0:
+        return torch.empty((0, 8 * L), dtype=torch.uint8, device=bra.device)
+    if bra.numel() % sorb != 0:
+        raise RuntimeError(f"shape {tuple(bra.shape)} is invalid for sorb = {sorb}")  # view(-1, sorb) fails
+    dev, (x,), cpu = _stage(bra)
+    x = x.view(-1, sorb)
+    out = torch.empty((x.size(0), 8 * L), dtype=torch.uint8, device=dev)
+    N.check(N.lib().pynqs_pm01_to_onv(x.data_ptr(), x.size(0), sorb, out.data_ptr(), _stream(dev)), "tensor_to_onv")
+    return out.cpu() if cpu else out
+
+
+def onv_to_tensor(bra: Tensor, sorb: int) -> Tensor:
+    """bind.cpp:24-37 -> cpu_tensor.cpp:46-88: onv -> +-1 in torch.get_default_dtype(), shape [n, sorb]."""
+    _check_onv(bra, "bra_tensor", sorb, (1, 2))
+    dtype = torch.get_default_dtype()
+    if dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("default dtype must be float32 or float64")
+    if bra.numel() == 0:
+        return torch.empty((0, sorb), dtype=dtype, device=bra.device)
+    dev, (x,), cpu = _stage(bra)
+    x = x.view(-1, x.size(-1))
+    out = torch.empty((x.size(0), sorb), dtype=dtype, device=dev)
+    code = N.PYNQS_F64 if dtype == torch.float64 else N.PYNQS_F32
+    N.check(N.lib().pynqs_onv_to_pm1(x.data_ptr(), x.size(0), sorb, code, out.data_ptr(), _stream(dev)), "onv_to_tensor")
+    return out.cpu() if cpu else out
+
+
+def get_comb_tensor(bra: Tensor, sorb: int, nele: int, noA: int, noB: int, flag_bit: bool = False) -> Tuple[Tensor, Tensor]:
+    """bind.cpp:66-83 -> cpu_tensor.cpp:164-218.  Returns (comb uint8[n, ncomb, 8*len], states);
+    states = +-1 double[n, ncomb, sorb] if flag_bit else torch.ones(1, float64) on the CPU (cpu_tensor.cpp:191)."""
+    _check_onv(bra, "bra_tensor", sorb, (1, 2))
+    L = _bra_len(sorb)
+    ncomb = get_Num_SinglesDoubles(sorb, noA, noB) + 1
+    x2 = bra.view(-1, 8 * L)
+    n = x2.size(0) if bra.numel() else 0
+    if n == 0:
+        return (torch.empty((0, ncomb, 8 * L), dtype=torch.uint8, device=bra.device),
+                torch.empty((0, ncomb, sorb), dtype=torch.float64, device=bra.device))
+    dev, (x,), cpu = _stage(x2)
+    comb = torch.empty((n, ncomb, 8 * L), dtype=torch.uint8, device=dev)
+    pm = torch.empty((n, ncomb, sorb), dtype=torch.float64, device=dev) if flag_bit else None
+    N.check(N.lib().pynqs_comb(x.data_ptr(), n, sorb, noA, noB, comb.data_ptr(), pm.data_ptr() if flag_bit else None,
+                               _stream(dev)), "get_comb_tensor")
+    if not flag_bit:
+        pm = torch.ones(1, dtype=torch.float64)
+    elif cpu:
+        pm = pm.cpu()
+    return (comb.cpu() if cpu else comb), pm
+
+
+def get_comb_hij_fused(bra: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noA: int, noB: int) -> Tuple[Tensor, Tensor]:
+    """bind.cpp:239-250 -> cpu_tensor.cpp:220-272.  Returns (comb uint8[n, ncomb, 8*len], Hmat T[n, ncomb]),
+    T = dtype of h1e; column 0 is x itself / <x|H|x>."""
+    _check_onv(bra, "bra_tensor", sorb, (2,))
+    code = _fdtype(h1e, h2e)
+    _check_integrals(h1e, h2e, sorb)
+    L = _bra_len(sorb)
+    ncomb = get_Num_SinglesDoubles(sorb, noA, noB) + 1
+    n = bra.size(0)
+    if bra.numel() == 0:
+        return (torch.empty((0, ncomb, 8 * L), dtype=torch.uint8, device=bra.device),
+                torch.empty((0, ncomb), dtype=h1e.dtype, device=h1e.device))
+    dev, (x, a, b), cpu = _stage(bra, h1e, h2e)
+    comb = torch.empty((n, ncomb, 8 * L), dtype=torch.uint8, device=dev)
+    hmat = torch.empty((n, ncomb), dtype=h1e.dtype, device=dev)
+    N.check(N.lib().pynqs_comb_hij_fused(x.data_ptr(), n, sorb, nele, noA, noB, a.data_ptr(), b.data_ptr(), code,
+                                         comb.data_ptr(), hmat.data_ptr(), _stream(dev)), "get_comb_hij_fused")
+    return (comb.cpu(), hmat.cpu()) if cpu else (comb, hmat)
+
+
+def get_hij_torch(bra: Tensor, ket: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int) -> Tensor:
+    """bind.cpp:39-64 -> cpu_tensor.cpp:274-325.  ket 3-D [n, m, .]: Hmat[i, j] = <bra_i|H|ket_ij>;
+    ket 2-D [m, .]: the full matrix <bra_i|H|ket_j>.  Degree > 2 -> 0."""
+    _check_onv(bra, "bra_tensor", sorb, (2,))
+    _check_onv(ket, "ket_tensor", sorb, (2, 3))
+    code = _fdtype(h1e, h2e)
+    _check_integrals(h1e, h2e, sorb)
+    n = bra.size(0)
+    is3d = ket.dim() == 3
+    m = ket.size(1) if is3d else ket.size(0)
+    if is3d and ket.size(0) != n:
+        raise RuntimeError(f"ket.size(0) = {ket.size(0)} != bra.size(0) = {n}")
+    if bra.numel() == 0 or ket.numel() == 0:
+        return torch.empty((n, m), dtype=h1e.dtype, device=h1e.device)
+    dev, (x, k, a, b), cpu = _stage(bra, ket, h1e, h2e)
+    hmat = torch.empty((n, m), dtype=h1e.dtype, device=dev)
+    N.check(N.lib().pynqs_hij(x.data_ptr(), n, k.data_ptr(), m, int(is3d), a.data_ptr(), b.data_ptr(), code, sorb, nele,
+                              hmat.data_ptr(), _stream(dev)), "get_hij_torch")
+    return hmat.cpu() if cpu else hmat
+
+
+def wavefunction_lut(bra_key: Tensor, onv: Tensor, sorb: int, little_endian: bool = True) -> Tuple[Tensor, Tensor]:
+    """bind.cpp:216-236 -> cpu_tensor.cpp:642-688: binary search of onv in the sorted bra_key.
+    Returns (idx int64[n] with -1 for misses, mask bool[n]).  If either input is on the CPU the result
+    is on the CPU, as in the reference."""
+    if not little_endian:
+        raise NotImplementedError("big-endian keys are not supported (the reference's branch is broken, cpu_tensor.cpp:613)")
+    _check_onv(bra_key, "bra_key", sorb, (2,))
+    _check_onv(onv, "onv", sorb, (2,))
+    n = onv.size(0)
+    any_cpu = bra_key.device.type == "cpu" or onv.device.type == "cpu"
+    if onv.numel() == 0:
+        d = torch.device("cpu") if any_cpu else onv.device
+        return torch.zeros(0, dtype=torch.int64, device=d), torch.zeros(0, dtype=torch.bool, device=d)
+    dev, (k, q), _ = _stage(bra_key, onv)
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    mask = torch.empty(n, dtype=torch.bool, device=dev)
+    N.check(N.lib().pynqs_wavefunction_lut(k.data_ptr(), k.size(0), q.data_ptr(), n, sorb, idx.data_ptr(), mask.data_ptr(),
+                                           _stream(dev)), "wavefunction_lut")
+    return (idx.cpu(), mask.cpu()) if any_cpu else (idx, mask)
+
+
+# ---- integral layout (host side, numpy in / numpy out like cpp_src/tensor/integral.cpp) -----------------
+def _pair_maps(sorb: int):
+    i, j = np.meshgrid(np.arange(sorb), np.arange(sorb), indexing="ij")
+    hi, lo = np.maximum(i, j), np.minimum(i, j)
+    pair = hi * (hi - 1) // 2 + lo  # meaningless on the diagonal (masked by the callers)
+    sgn = np.where(i > j, 1.0, -1.0)
+    return pair, sgn, i != j
+
+
+def compress_h1e_h2e(h1e: np.ndarray, h2e: np.ndarray, sorb: int):
+    """integral.cpp:6-60: h1e[s, s], antisymmetrised h2e[s, s, s, s] -> (h1e[s*s], h2e[pair(pair+1)/2]).
+    When several (i,j,k,l) share a packed slot the LAST one in lexicographic order wins, as in the
+    reference's loop (numpy fancy assignment keeps the last write)."""
+    h1e = np.asarray(h1e, dtype=np.float64)
+    h2e = np.asarray(h2e, dtype=np.float64)
+    if h1e.shape != (sorb, sorb) or h2e.shape != (sorb,) * 4:
+        raise ValueError(f"expected h1e {(sorb, sorb)} and h2e {(sorb,) * 4}, got {h1e.shape} and {h2e.shape}")
+    npair = sorb * (sorb - 1) // 2
+    pair, sgn, off = _pair_maps(sorb)
+    ij = pair[:, :, None, None]; kl = pair[None, None, :, :]
+    valid = off[:, :, None, None] & off[None, None, :, :]
+    P = np.maximum(ij, kl); Q = np.minimum(ij, kl)
+    slot = (P * (P + 1) // 2 + Q)[valid]
+    vals = (sgn[:, :, None, None] * sgn[None, None, :, :] * h2e)[valid]
+    out = np.zeros(npair * (npair + 1) // 2, dtype=np.float64)
+    out[slot] = vals  # C-order traversal == the reference's i,j,k,l loop order; last write wins
+    return h1e.reshape(-1).copy(), out
+
+
+def decompress_h1e_h2e(h1e: np.ndarray, h2e: np.ndarray, sorb: int):
+    """integral.cpp:62-125; raises ValueError on a size mismatch (std::invalid_argument)."""
+    h1e = np.asarray(h1e, dtype=np.float64).reshape(-1)
+    h2e = np.asarray(h2e, dtype=np.float64).reshape(-1)
+    npair = sorb * (sorb - 1) // 2
+    if h1e.size != sorb * sorb:
+        raise ValueError(f"h1e array size is incorrect: expected {sorb * sorb}, got {h1e.size}")
+    if h2e.size != npair * (npair + 1) // 2:
+        raise ValueError(f"h2e array size is incorrect: expected {npair * (npair + 1) // 2}, got {h2e.size}")
+    pair, sgn, off = _pair_maps(sorb)
+    ij = pair[:, :, None, None]; kl = pair[None, None, :, :]
+    valid = off[:, :, None, None] & off[None, None, :, :]
+    P = np.maximum(ij, kl); Q = np.minimum(ij, kl)
+    slot = np.where(valid, P * (P + 1) // 2 + Q, 0)
+    full = np.where(valid, h2e[slot] * sgn[:, :, None, None] * sgn[None, None, :, :], 0.0)
+    return h1e.reshape(sorb, sorb).copy(), full

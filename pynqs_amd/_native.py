@@ -1,0 +1,72 @@
+"""ctypes binding of libpynqs_amd.so (the C ABI declared in include/pynqs_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, every compute entry
+point raises.  Building: ``python -c "import __graft_entry__ as g; g.build()"`` or
+``pynqs_amd.build.build_native()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpynqs_amd.so")
+
+PYNQS_F32, PYNQS_F64 = 0, 1
+OK, EINVAL, ELAUNCH, ELENGTH, EOVERFLOW = 0, -1, -2, -3, -4
+
+_i64, _int, _vp, _dbl = C.c_int64, C.c_int, C.c_void_p, C.c_double
+
+# name -> (restype, argtypes); mirrors include/pynqs_amd.h one to one
+SIGNATURES = {
+    "pynqs_abi_version": (_int, []),
+    "pynqs_last_error": (C.c_char_p, []),
+    "pynqs_num_sd": (_i64, [_int, _int, _int]),
+    "pynqs_check_sorb": (_int, [_int, _int]),
+    "pynqs_comb_hij_fused": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp]),
+    "pynqs_comb": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
+    "pynqs_hij": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    "pynqs_onv_to_pm1": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
+    "pynqs_pm01_to_onv": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "pynqs_wavefunction_lut": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libpynqs_amd.so; raises NativeLibraryError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "pynqs_amd has no CPU fallback."
+            )
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(l, name)  # AttributeError -> header/library mismatch, loud
+            f.restype = res
+            f.argtypes = args
+        if l.pynqs_abi_version() != 1:
+            raise NativeLibraryError("libpynqs_amd.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == OK:
+        return
+    msg = lib().pynqs_last_error().decode(errors="replace")
+    if rc == ELENGTH:
+        raise ValueError(msg)  # std::length_error -> ValueError in the reference (bind.cpp:290)
+    if rc == EOVERFLOW:
+        raise OverflowError(msg)  # std::overflow_error -> OverflowError (bind.cpp:294-299)
+    raise RuntimeError(f"{what}: {msg} (code {rc})")

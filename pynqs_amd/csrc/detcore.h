@@ -1,0 +1,368 @@
+// detcore.h -- device-side building blocks shared by every kernel of libpynqs_amd (gfx950 only).
+//
+// Design (MI355X-first, not a translation of cpp_src/cuda):
+//  * one workgroup works on ONE walker, so the walker's occupation words and its prefix-parity
+//    masks are wave-uniform (SGPRs); fermionic signs are bit tests on those masks instead of the
+//    reference's popcount loops (cpp_src/cpu/onstate.cpp:22-32);
+//  * the walker's excitation tables (singles lists, hole-pair / particle-pair lists) are built once
+//    per workgroup in LDS; an excitation rank is then ONE magic-number division plus two LDS reads,
+//    instead of the div/mod/sqrt chain of cpp_src/cpu/excitation.cpp:18-110 per element;
+//  * consecutive lanes take consecutive excitation ranks, so Hmat/comb stores are fully coalesced;
+//  * all global indexing is 64-bit (the reference overflows int32 at cuda/kernel.cu:243-263).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pynqs {
+
+constexpr int kMaxSorb = 192;
+constexpr int kBlock = 256;
+
+// Exact n / d for n < 2^24 by multiply-shift: m = ceil(2^s / d), s = 24 + ceil(log2 d).
+struct MagicDiv {
+  uint32_t m;
+  uint32_t s;
+  uint32_t d;
+};
+
+static inline MagicDiv make_magic(uint32_t d) {
+  MagicDiv r;
+  if (d == 0) d = 1;  // never used for division in that case (empty block)
+  uint32_t l = 0;
+  while ((1u << l) < d) ++l;
+  r.s = 24 + l;
+  r.m = (uint32_t)(((1ull << r.s) + d - 1) / d);
+  r.d = d;
+  return r;
+}
+
+__device__ __forceinline__ uint32_t mdiv(uint32_t n, const MagicDiv &k) {
+  return (uint32_t)(((uint64_t)n * k.m) >> k.s);
+}
+
+// Everything the enumeration needs, computed once on the host (excitation.cpp:20-42).
+struct SDParams {
+  int sorb, nele, noA, noB, nvA, nvB;
+  int noAA, noBB, nvAA, nvBB;  // pair counts
+  int nSa, nSb;                // noA*nvA, noB*nvB
+  uint32_t d0, d1, d2, d3;     // cumulative block ends [Sa, Sb, Daa, Dbb)
+  uint32_t nsd;                // total singles+doubles
+  uint32_t rotA, rotB;         // d1 % noAA, d2 % noBB : the `idx % noAA` quirk as a cyclic rotation
+  MagicDiv divNoA, divNoB, divNoAA, divNoBB, divNSa;
+  // LDS table offsets (in uint32 entries)
+  int offSa, offSb, offHPa, offPPa, offHPb, offPPb, tabEntries;
+};
+
+static inline bool make_sd_params(int sorb, int nele, int noA, int noB, SDParams *p) {
+  if (sorb < 1 || sorb > kMaxSorb || noA < 0 || noB < 0) return false;
+  int k = sorb / 2;
+  int nvA = k - noA, nvB = k - noB;
+  if (nvA < 0 || nvB < 0) return false;
+  p->sorb = sorb; p->nele = nele; p->noA = noA; p->noB = noB; p->nvA = nvA; p->nvB = nvB;
+  p->noAA = noA * (noA - 1) / 2; p->noBB = noB * (noB - 1) / 2;
+  p->nvAA = nvA * (nvA - 1) / 2; p->nvBB = nvB * (nvB - 1) / 2;
+  p->nSa = noA * nvA; p->nSb = noB * nvB;
+  int64_t nDaa = (int64_t)p->noAA * p->nvAA, nDbb = (int64_t)p->noBB * p->nvBB;
+  int64_t nDab = (int64_t)p->nSa * p->nSb;
+  int64_t tot = p->nSa + p->nSb + nDaa + nDbb + nDab;
+  if (tot >= (1ll << 24)) return false;  // magic division range; sorb <= 192 never reaches it
+  p->d0 = p->nSa; p->d1 = p->d0 + p->nSb; p->d2 = p->d1 + (uint32_t)nDaa; p->d3 = p->d2 + (uint32_t)nDbb;
+  p->nsd = (uint32_t)tot;
+  p->rotA = p->noAA ? p->d1 % p->noAA : 0;
+  p->rotB = p->noBB ? p->d2 % p->noBB : 0;
+  p->divNoA = make_magic(noA); p->divNoB = make_magic(noB);
+  p->divNoAA = make_magic(p->noAA); p->divNoBB = make_magic(p->noBB); p->divNSa = make_magic(p->nSa);
+  int o = 0;
+  p->offSa = o; o += p->nSa;
+  p->offSb = o; o += p->nSb;
+  p->offHPa = o; o += p->noAA;
+  p->offPPa = o; o += p->nvAA;
+  p->offHPb = o; o += p->noBB;
+  p->offPPb = o; o += p->nvBB;
+  p->tabEntries = o;
+  return true;
+}
+
+// ---- bit helpers ---------------------------------------------------------------------------------
+
+// bit n of the result = parity of the bits of x strictly below n
+__device__ __forceinline__ uint64_t prefix_parity_excl(uint64_t x) {
+  uint64_t y = x << 1;
+  y ^= y << 1; y ^= y << 2; y ^= y << 4; y ^= y << 8; y ^= y << 16; y ^= y << 32;
+  return y;
+}
+
+template <int LEN>
+struct Walker {
+  uint64_t w[LEN];   // occupation words (wave-uniform)
+  uint64_t pm[LEN];  // prefix-parity masks: bit n of pm[n/64] = parity(#occupied below n)
+};
+
+template <int LEN>
+__device__ __forceinline__ void load_walker(const uint64_t *__restrict__ bra, Walker<LEN> &wk) {
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) {
+    uint64_t v = bra[i];
+    // the address is workgroup-uniform: keep the value in scalar registers
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    v = ((uint64_t)hi << 32) | lo;
+    wk.w[i] = v;
+    uint64_t p = prefix_parity_excl(v);
+    wk.pm[i] = carry ? ~p : p;
+    carry ^= (uint32_t)__popcll(v) & 1u;
+  }
+}
+
+template <int LEN>
+__device__ __forceinline__ uint64_t pick(const uint64_t (&a)[LEN], int word) {
+  if constexpr (LEN == 1) return a[0];
+  else if constexpr (LEN == 2) return word ? a[1] : a[0];
+  else return word == 0 ? a[0] : (word == 1 ? a[1] : a[2]);
+}
+
+template <int LEN>
+__device__ __forceinline__ uint32_t bit_of(const uint64_t (&a)[LEN], int n) {
+  return (uint32_t)(pick<LEN>(a, n >> 6) >> (n & 63)) & 1u;
+}
+
+template <int LEN>
+__device__ __forceinline__ void toggle(uint64_t (&a)[LEN], int n) {
+  uint64_t b = 1ull << (n & 63);
+  if constexpr (LEN == 1) a[0] ^= b;
+  else {
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) a[i] ^= ((n >> 6) == i) ? b : 0ull;
+  }
+}
+
+// ---- integrals ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t pair_index(uint32_t hi, uint32_t lo) { return hi * (hi - 1) / 2 + lo; }
+
+// packed-triangle offset of (ij, kl); fits 32 bits for sorb <= 192 (max 1.68e8)
+__device__ __forceinline__ uint32_t tri_index(uint32_t ij, uint32_t kl) {
+  uint32_t P = ij > kl ? ij : kl, Q = ij > kl ? kl : ij;
+  return P * (P + 1) / 2 + Q;
+}
+
+// <ij||kl> for arbitrary order, hamiltonian.cpp:14-31
+template <typename T>
+__device__ __forceinline__ T two_body(const T *__restrict__ h2e, int i, int j, int k, int l) {
+  if (i == j || k == l) return T(0);
+  uint32_t ij = i > j ? pair_index(i, j) : pair_index(j, i);
+  uint32_t kl = k > l ? pair_index(k, l) : pair_index(l, k);
+  T v = h2e[tri_index(ij, kl)];
+  bool neg = (i > j) != (k > l);
+  return neg ? -v : v;
+}
+
+// ---- sorted-key table (WavefunctionLUT) -----------------------------------------------------------
+// cpu_tensor.cpp:589-637, little-endian branch: keys compare as multi-word integers, most significant
+// word LAST.  Returns the position of q or -1.
+template <int LEN>
+__device__ __forceinline__ int64_t lut_find(const uint64_t *__restrict__ keys, int64_t nkeys, const uint64_t (&q)[LEN]) {
+  int64_t lo = 0, hi = nkeys - 1;
+  while (lo <= hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    int c = 0;
+#pragma unroll
+    for (int w = LEN - 1; w >= 0; --w) {
+      const uint64_t kv = keys[mid * LEN + w];
+      if (c == 0) c = kv < q[w] ? -1 : (kv > q[w] ? 1 : 0);
+    }
+    if (c == 0) return mid;
+    if (c < 0) lo = mid + 1;
+    else hi = mid - 1;
+  }
+  return -1;
+}
+
+// ---- per-walker LDS state ------------------------------------------------------------------------
+// merged[sorb]  : onstate.cpp:147-193 slot list (u8 orbitals)
+// occv[nele]    : occupied orbitals in the order singles visit them (word ascending, bit 63 -> 0)
+// tab[...]      : excitation tables, entry = orbX | orbY << 8 | parity << 16
+struct LdsLayout {
+  uint8_t *merged;
+  uint8_t *occv;
+  uint32_t *tab;
+};
+
+__host__ __device__ inline size_t lds_bytes(const SDParams &p) {
+  return (size_t)p.tabEntries * 4 + 2 * 192;
+}
+
+__device__ __forceinline__ LdsLayout carve_lds(unsigned char *base, const SDParams &p) {
+  LdsLayout L;
+  L.tab = reinterpret_cast<uint32_t *>(base);
+  L.merged = base + (size_t)p.tabEntries * 4;
+  L.occv = L.merged + 192;
+  return L;
+}
+
+// triangular pair rank -> (hi > lo).  The reference uses int(sqrt(2(q+1)) + 0.5) in double
+// (excitation.h:6-11); for q < 2^24 the float estimate corrected by one step gives the same integers.
+__device__ __forceinline__ void pair_unrank(int q, int &hi, int &lo) {
+  int i = (int)(sqrtf(2.0f * (float)(q + 1)) + 0.5f);
+  // exact: i is the unique integer with i(i-1)/2 <= q < i(i+1)/2
+  while (i * (i - 1) / 2 > q) --i;
+  while (i * (i + 1) / 2 <= q) ++i;
+  hi = i;
+  lo = q - i * (i - 1) / 2;
+}
+
+// Builds merged / occv / tables for the workgroup's walker.  All threads of the block must call it;
+// ends with a barrier.  Returns the walker's electron count (length of occv).
+template <int LEN>
+__device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const SDParams &p, const LdsLayout &L) {
+  const int tid = threadIdx.x;
+  const int sorb = p.sorb;
+  // actual alpha / beta electron counts of this walker (the reference's slot counters run on the
+  // determinant itself, not on noA/noB)
+  int occA = 0, occB = 0;
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) {
+    occA += __popcll(wk.w[i] & 0x5555555555555555ull);
+    occB += __popcll(wk.w[i] & 0xAAAAAAAAAAAAAAAAull);
+  }
+  for (int s = tid; s < sorb; s += blockDim.x) {
+    const int word = s >> 6, b = s & 63;
+    const uint64_t spin = (s & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+    const uint64_t below = (1ull << b) - 1ull;
+    int rank_occ = 0, rank_all = 0;  // same-spin occupied / all same-spin orbitals below s
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) {
+      uint64_t m = i < word ? ~0ull : (i == word ? below : 0ull);
+      rank_occ += __popcll(wk.w[i] & spin & m);
+      rank_all += __popcll(spin & m);
+    }
+    const bool occ = (pick<LEN>(wk.w, word) >> b) & 1ull;
+    const int nocc = (s & 1) ? occB : occA;
+    const int r = occ ? rank_occ : nocc + (rank_all - rank_occ);
+    L.merged[2 * r + (s & 1)] = (uint8_t)s;
+    if (occ) {
+      // visiting order of singles: words ascending, bits descending inside a word
+      int before = 0;
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) {
+        if (i < word) before += __popcll(wk.w[i]);
+        if (i == word) before += __popcll(wk.w[i] & ~below & ~(1ull << b));
+      }
+      L.occv[before] = (uint8_t)s;
+    }
+  }
+  __syncthreads();
+  // singles tables: entry ia = a_idx*no + i_idx  ->  hole | particle << 8 | sign parity << 16
+  for (int e = tid; e < p.nSa + p.nSb; e += blockDim.x) {
+    const bool beta = e >= p.nSa;
+    const int ia = beta ? e - p.nSa : e;
+    const int no = beta ? p.noB : p.noA;
+    const int a_idx = (int)mdiv((uint32_t)ia, beta ? p.divNoB : p.divNoA);
+    const int i_idx = ia - a_idx * no;
+    const int h = L.merged[2 * i_idx + beta];
+    const int q = L.merged[2 * (a_idx + no) + beta];
+    const uint32_t par = bit_of<LEN>(wk.pm, h) ^ bit_of<LEN>(wk.pm, q) ^ (uint32_t)(h < q);
+    L.tab[(beta ? p.offSb : p.offSa) + ia] = (uint32_t)h | ((uint32_t)q << 8) | (par << 16);
+  }
+  // pair tables: hole pairs (hi > lo among occupied slots) and particle pairs (virtual slots)
+  const int nPairs = p.noAA + p.nvAA + p.noBB + p.nvBB;
+  for (int e = tid; e < nPairs; e += blockDim.x) {
+    int q = e, off, base, beta, extra;
+    if (q < p.noAA) { off = p.offHPa; base = 0; beta = 0; extra = 0; }
+    else if ((q -= p.noAA) < p.nvAA) { off = p.offPPa; base = p.noA; beta = 0; extra = 1; }
+    else if ((q -= p.nvAA) < p.noBB) { off = p.offHPb; base = 0; beta = 1; extra = 0; }
+    else { q -= p.noBB; off = p.offPPb; base = p.noB; beta = 1; extra = 1; }
+    int hi, lo;
+    pair_unrank(q, hi, lo);
+    const int o1 = L.merged[2 * (hi + base) + beta];
+    const int o0 = L.merged[2 * (lo + base) + beta];
+    // holes: P(p0)^P(p1); particles: P(q0)^P(q1)^1 (q1 < q0 is one of the flipped bits below q0)
+    const uint32_t par = bit_of<LEN>(wk.pm, o1) ^ bit_of<LEN>(wk.pm, o0) ^ (uint32_t)extra;
+    L.tab[off + q] = (uint32_t)o1 | ((uint32_t)o0 << 8) | (par << 16);
+  }
+  __syncthreads();
+  return occA + occB;
+}
+
+// One decoded excitation.
+struct Excitation {
+  int h0, h1;     // holes   (h0 > h1 for doubles; h1 unused for singles)
+  int q0, q1;     // particles (q0 > q1 for doubles)
+  uint32_t par;   // 1 -> matrix element gets a minus sign
+  bool is_double;
+};
+
+// rank r in [0, nsd) -> excitation, using the LDS tables (excitation.cpp:43-109 incl. the quirk).
+__device__ __forceinline__ Excitation decode(uint32_t r, const SDParams &p, const LdsLayout &L) {
+  Excitation x;
+  if (r < p.d1) {
+    const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
+    x.h0 = e & 0xff; x.q0 = (e >> 8) & 0xff; x.h1 = x.q1 = 0;
+    x.par = (e >> 16) & 1u;
+    x.is_double = false;
+    return x;
+  }
+  x.is_double = true;
+  uint32_t eh, ep;
+  if (r < p.d3) {
+    const bool beta = r >= p.d2;
+    const uint32_t t = r - (beta ? p.d2 : p.d1);
+    const uint32_t npair = beta ? p.noBB : p.noAA;
+    const uint32_t ab = mdiv(t, beta ? p.divNoBB : p.divNoAA);
+    uint32_t ij = t - ab * npair + (beta ? p.rotB : p.rotA);  // == r % npair
+    ij = ij >= npair ? ij - npair : ij;
+    eh = L.tab[(beta ? p.offHPb : p.offHPa) + ij];
+    ep = L.tab[(beta ? p.offPPb : p.offPPa) + ab];
+    x.h0 = eh & 0xff; x.h1 = (eh >> 8) & 0xff;
+    x.q0 = ep & 0xff; x.q1 = (ep >> 8) & 0xff;
+    x.par = ((eh ^ ep) >> 16) & 1u;
+    x.par ^= (uint32_t)(x.h0 < x.q0) ^ (uint32_t)(x.h1 < x.q0) ^ (uint32_t)(x.h0 < x.q1) ^ (uint32_t)(x.h1 < x.q1);
+  } else {
+    const uint32_t t = r - p.d3;
+    const uint32_t jb = mdiv(t, p.divNSa);
+    const uint32_t ia = t - jb * (uint32_t)p.nSa;
+    eh = L.tab[p.offSa + ia];  // alpha hole/particle
+    ep = L.tab[p.offSb + jb];  // beta hole/particle
+    const int ha = eh & 0xff, qa = (eh >> 8) & 0xff, hb = ep & 0xff, qb = (ep >> 8) & 0xff;
+    // entries carry P(h)^P(q)^[h<q] per spin; add the cross terms and the constant 1
+    x.par = (((eh ^ ep) >> 16) & 1u) ^ (uint32_t)(ha < qb) ^ (uint32_t)(hb < qa) ^ 1u;
+    x.h0 = ha > hb ? ha : hb; x.h1 = ha > hb ? hb : ha;
+    x.q0 = qa > qb ? qa : qb; x.q1 = qa > qb ? qb : qa;
+  }
+  return x;
+}
+
+template <int LEN>
+__device__ __forceinline__ void make_ket(const Walker<LEN> &wk, const Excitation &x, uint64_t (&ket)[LEN]) {
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+  toggle<LEN>(ket, x.h0);
+  toggle<LEN>(ket, x.q0);
+  if (x.is_double) {
+    toggle<LEN>(ket, x.h1);
+    toggle<LEN>(ket, x.q1);
+  }
+}
+
+// <x|H|x'> for a decoded excitation, bit-identical to excitation.cpp:141-167 (same operation order).
+template <typename T>
+__device__ __forceinline__ T element(const Excitation &x, const SDParams &p, const LdsLayout &L, int nocc,
+                                     const T *__restrict__ h1e, const T *__restrict__ h2e) {
+  if (x.is_double) {
+    const T v = h2e[tri_index(pair_index(x.h0, x.h1), pair_index(x.q0, x.q1))];
+    return x.par ? -v : v;
+  }
+  const int hp = x.h0, q = x.q0;
+  T acc = T(0);
+  acc += h1e[(size_t)q * p.sorb + hp];
+#pragma unroll 4
+  for (int t = 0; t < nocc; ++t) {
+    const int k = L.occv[t];
+    acc += two_body<T>(h2e, hp, k, q, k);
+  }
+  return x.par ? -acc : acc;
+}
+
+}  // namespace pynqs

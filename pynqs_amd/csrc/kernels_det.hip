@@ -1,0 +1,384 @@
+// kernels_det.hip -- drop-in determinant kernels of libpynqs_amd (gfx950).
+//   comb_hij_kernel : enumerate S+D excitations (+ <x|H|x'>)      [get_comb_hij_fused / get_comb_tensor]
+//   hii_kernel      : diagonal <x|H|x>                             [column 0 of Hmat]
+//   hij_pairs_kernel: generic bra/ket pairs, 3-D and 2-D mode      [get_hij_torch]
+//   onv_to_pm1 / pm01_to_onv / lut_search                          [onv_to_tensor / tensor_to_onv / wavefunction_lut]
+// Reference behaviour: cpp_src/cpu/*.cpp, cpp_src/tensor/cpu_tensor.cpp (cited per kernel).
+#include "detcore.h"
+#include "launch.h"
+
+namespace pynqs {
+
+// -------------------------------------------------------------------------------------------------
+// Fused enumerate + matrix element.  cpu_tensor.cpp:220-272 / excitation.cpp:125-169.
+// grid = nbatch * nchunks workgroups of 256; workgroup (walker, chunk) covers columns
+// [chunk*chunk_len, (chunk+1)*chunk_len) of that walker's row.  Column 0 (x itself) only gets its comb
+// entry here; Hmat[:,0] comes from hii_kernel.
+template <int LEN, typename T, bool WRITE_COMB, bool WITH_H>
+__global__ __launch_bounds__(kBlock) void comb_hij_kernel(const uint64_t *__restrict__ bra, SDParams p,
+                                                          uint32_t nchunks, uint32_t chunk_len,
+                                                          const T *__restrict__ h1e, const T *__restrict__ h2e,
+                                                          uint64_t *__restrict__ comb, T *__restrict__ hmat) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint64_t wg = blockIdx.x;
+  const uint64_t walker = wg / nchunks;
+  const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
+  Walker<LEN> wk;
+  load_walker<LEN>(bra + walker * LEN, wk);
+  const LdsLayout L = carve_lds(smem, p);
+  const int nocc = build_walker_tables<LEN>(wk, p, L);
+
+  const uint32_t ncomb = p.nsd + 1;
+  const uint32_t lo = chunk * chunk_len;
+  const uint32_t hi = min(lo + chunk_len, ncomb);
+  const size_t row = (size_t)walker * ncomb;
+  for (uint32_t k = lo + threadIdx.x; k < hi; k += kBlock) {
+    uint64_t ket[LEN];
+    if (k == 0) {
+      if constexpr (WRITE_COMB) {
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) comb[row * LEN + i] = wk.w[i];
+      }
+      continue;
+    }
+    const Excitation x = decode(k - 1, p, L);
+    if constexpr (WRITE_COMB) {
+      make_ket<LEN>(wk, x, ket);
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) comb[(row + k) * LEN + i] = ket[i];
+    }
+    if constexpr (WITH_H) hmat[row + k] = element<T>(x, p, L, nocc, h1e, h2e);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Diagonal element, hamiltonian.cpp:34-50.  The reference adds nele(nele+1)/2 terms in a fixed order
+// (for p ascending: h(p,p), then <pq||pq> for q < p ascending); the gathers are done by the whole
+// workgroup into LDS, the additions by one lane in that order, so the result is bit-identical.
+constexpr int kDiagTile = 2048;
+
+template <int LEN, typename T>
+__global__ __launch_bounds__(kBlock) void hii_kernel(const uint64_t *__restrict__ bra, int sorb, int nele,
+                                                     const T *__restrict__ h1e, const T *__restrict__ h2e,
+                                                     T *__restrict__ out, size_t out_stride) {
+  __shared__ uint8_t occ[kMaxSorb];
+  __shared__ T terms[kDiagTile];
+  const uint64_t walker = blockIdx.x;
+  Walker<LEN> wk;
+  load_walker<LEN>(bra + walker * LEN, wk);
+  const int tid = threadIdx.x;
+  if (tid < kMaxSorb) occ[tid] = 0;  // the reference's olst is zero-initialised
+  __syncthreads();
+  if (tid < sorb && bit_of<LEN>(wk.w, tid)) {
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) {
+      const int word = tid >> 6;
+      uint64_t m = i < word ? ~0ull : (i == word ? ((1ull << (tid & 63)) - 1ull) : 0ull);
+      r += __popcll(wk.w[i] & m);
+    }
+    occ[r] = (uint8_t)tid;
+  }
+  __syncthreads();
+  const int nterms = nele * (nele + 1) / 2;
+  T acc = T(0);
+  for (int base = 0; base < nterms; base += kDiagTile) {
+    const int end = min(base + kDiagTile, nterms);
+    for (int t = base + tid; t < end; t += kBlock) {
+      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (a * (a + 1) / 2 > t) --a;
+      while ((a + 1) * (a + 2) / 2 <= t) ++a;
+      const int pos = t - a * (a + 1) / 2;
+      const int pa = occ[a];
+      T v;
+      if (pos == 0) v = h1e[(size_t)pa * sorb + pa];
+      else v = two_body<T>(h2e, pa, occ[pos - 1], pa, occ[pos - 1]);
+      terms[t - base] = v;
+    }
+    __syncthreads();
+    if (tid == 0)
+      for (int t = 0; t < end - base; ++t) acc += terms[t];
+    __syncthreads();
+  }
+  if (tid == 0) out[walker * out_stride] = acc;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Generic pairs, hamiltonian.cpp:53-103 + onstate.cpp:10-55.  One lane per (i, j); consecutive lanes
+// take consecutive j so ket reads and Hmat writes are coalesced.
+template <int LEN>
+__device__ __forceinline__ int sign_below(const uint64_t (&w)[LEN], int n) {
+  uint32_t par = 0;
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) {
+    const int word = n >> 6;
+    uint64_t m = i < word ? ~0ull : (i == word ? ((1ull << (n & 63)) - 1ull) : 0ull);
+    par ^= (uint32_t)__popcll(w[i] & m);
+  }
+  return par & 1u;
+}
+
+template <int LEN, typename T>
+__device__ T diag_serial(const uint64_t (&x)[LEN], const T *__restrict__ h1e, const T *__restrict__ h2e, int sorb,
+                         int nele) {
+  // p ascending; q < p ascending (hamiltonian.cpp:41-48).  List entries past the determinant's electron
+  // count read as orbital 0, like the reference's zero-initialised olst[MAX_NELE].
+  T acc = T(0);
+  int wa = 0;
+  uint64_t bits_a = x[0];
+  for (int a = 0; a < nele; ++a) {
+    while (bits_a == 0 && wa < LEN - 1) bits_a = pick<LEN>(x, ++wa);
+    int pa = 0;
+    if (bits_a) { pa = wa * 64 + __builtin_ctzll(bits_a); bits_a &= bits_a - 1; }
+    acc += h1e[(size_t)pa * sorb + pa];
+    int b = 0;
+    for (int wj = 0; wj < LEN && b < a; ++wj) {
+      uint64_t bj = pick<LEN>(x, wj);
+      while (bj && b < a) {
+        const int pb = wj * 64 + __builtin_ctzll(bj);
+        bj &= bj - 1;
+        acc += two_body<T>(h2e, pa, pb, pa, pb);
+        ++b;
+      }
+    }
+    for (; b < a; ++b) acc += two_body<T>(h2e, pa, 0, pa, 0);
+  }
+  return acc;
+}
+
+template <int LEN, typename T>
+__global__ __launch_bounds__(kBlock) void hij_pairs_kernel(const uint64_t *__restrict__ bra, uint64_t n,
+                                                           const uint64_t *__restrict__ ket, uint64_t m, int ket_is_3d,
+                                                           const T *__restrict__ h1e, const T *__restrict__ h2e, int sorb,
+                                                           int nele, T *__restrict__ hmat) {
+  const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n * m) return;
+  const uint64_t i = idx / m, j = idx - i * m;
+  uint64_t b[LEN], k[LEN];
+  const uint64_t *kp = ket + ((ket_is_3d ? i * m : 0) + j) * LEN;
+  int nc = 0, na = 0;
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) {
+    b[w] = bra[i * LEN + w];
+    k[w] = kp[w];
+    const uint64_t d = b[w] ^ k[w];
+    nc += __popcll(d & b[w]);
+    na += __popcll(d & k[w]);
+  }
+  T val = T(0);
+  if (nc == 0 && na == 0) {
+    val = diag_serial<LEN, T>(b, h1e, h2e, sorb, nele);
+  } else if ((nc == 1 && na == 1) || (nc == 2 && na == 2)) {
+    int cre[2] = {0, 0}, ann[2] = {0, 0};
+    int ic = 0, ia = 0;
+#pragma unroll
+    for (int w = LEN - 1; w >= 0; --w) {  // highest orbital first (onstate.cpp:34-55)
+      const uint64_t d = b[w] ^ k[w];
+      uint64_t c = d & b[w], a = d & k[w];
+      while (c) { const int bit = 63 - __builtin_clzll(c); if (ic == 0) cre[0] = w * 64 + bit; else cre[1] = w * 64 + bit; ++ic; c &= ~(1ull << bit); }
+      while (a) { const int bit = 63 - __builtin_clzll(a); if (ia == 0) ann[0] = w * 64 + bit; else ann[1] = w * 64 + bit; ++ia; a &= ~(1ull << bit); }
+    }
+    if (nc == 1) {
+      const int hp = cre[0], q = ann[0];
+      T acc = T(0);
+      acc += h1e[(size_t)q * sorb + hp];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) {
+        uint64_t bits = b[w];
+        while (bits) {
+          const int bit = 63 - __builtin_clzll(bits);
+          const int o = 64 * w + bit;
+          acc += two_body<T>(h2e, hp, o, q, o);
+          bits &= ~(1ull << bit);
+        }
+      }
+      const uint32_t par = sign_below<LEN>(b, hp) ^ sign_below<LEN>(k, q);
+      val = par ? -acc : acc;
+    } else {
+      const uint32_t par = sign_below<LEN>(b, cre[0]) ^ sign_below<LEN>(b, cre[1]) ^ sign_below<LEN>(k, ann[0]) ^
+                           sign_below<LEN>(k, ann[1]);
+      const T v = two_body<T>(h2e, cre[0], cre[1], ann[0], ann[1]);
+      val = par ? -v : v;
+    }
+  }
+  hmat[idx] = val;
+}
+
+// -------------------------------------------------------------------------------------------------
+// onstate.h:45-63 : one lane per output element, +1 occupied / -1 empty.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void onv_to_pm1_kernel(const uint64_t *__restrict__ bra, uint64_t n, int sorb, int len,
+                                                            T *__restrict__ out) {
+  const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n * (uint64_t)sorb) return;
+  const uint64_t w = idx / (uint32_t)sorb;
+  const int o = (int)(idx - w * (uint32_t)sorb);
+  const uint64_t word = bra[w * len + (o >> 6)];
+  out[idx] = ((word >> (o & 63)) & 1ull) ? T(1) : T(-1);
+}
+
+// cpu_tensor.cpp:8-44 : one wave per output word; lane l tests byte l, ballot packs the word.
+__global__ __launch_bounds__(kBlock) void pm01_to_onv_kernel(const uint8_t *__restrict__ occ, uint64_t n, int sorb, int len,
+                                                             uint64_t *__restrict__ out) {
+  const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n * (uint64_t)len) return;
+  const uint64_t w = wave / (uint32_t)len;
+  const int word = (int)(wave - w * (uint32_t)len);
+  const int o = word * 64 + lane;
+  const bool set = o < sorb && occ[w * (uint64_t)sorb + o] == 1;
+  const uint64_t bits = __ballot(set);
+  if (lane == 0) out[wave] = bits;
+}
+
+// cpu_tensor.cpp:589-688 : binary search of multi-word keys (most significant word last).
+template <int LEN>
+__global__ __launch_bounds__(kBlock) void lut_search_kernel(const uint64_t *__restrict__ keys, int64_t nkeys,
+                                                            const uint64_t *__restrict__ onv, uint64_t n,
+                                                            int64_t *__restrict__ idx, uint8_t *__restrict__ mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint64_t q[LEN];
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) q[w] = onv[i * LEN + w];
+  idx[i] = lut_find<LEN>(keys, nkeys, q);
+  mask[i] = idx[i] >= 0;
+}
+
+}  // namespace pynqs
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace pynqs;
+
+#define DISPATCH_LEN(len, ...)                                  \
+  switch (len) {                                                \
+    case 1: { constexpr int LEN = 1; __VA_ARGS__; } break;      \
+    case 2: { constexpr int LEN = 2; __VA_ARGS__; } break;      \
+    default: { constexpr int LEN = 3; __VA_ARGS__; } break;     \
+  }
+
+template <int LEN, typename T>
+static int launch_comb_hij(const uint64_t *bra, int64_t nbatch, const SDParams &p, const T *h1e, const T *h2e,
+                           uint64_t *comb, T *hmat, hipStream_t st) {
+  const uint32_t ncomb = p.nsd + 1;
+  uint32_t nchunks, chunk_len;
+  plan_chunks(nbatch, ncomb, &nchunks, &chunk_len);
+  const size_t lds = lds_bytes(p);
+  const uint64_t grid = (uint64_t)nbatch * nchunks;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large: nbatch*nchunks > 2^31-1");
+  const bool with_h = hmat != nullptr;
+  if (comb && with_h)
+    hipLaunchKernelGGL((comb_hij_kernel<LEN, T, true, true>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, nchunks,
+                       chunk_len, h1e, h2e, comb, hmat);
+  else if (comb)
+    hipLaunchKernelGGL((comb_hij_kernel<LEN, T, true, false>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, nchunks,
+                       chunk_len, h1e, h2e, comb, hmat);
+  else
+    hipLaunchKernelGGL((comb_hij_kernel<LEN, T, false, true>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, nchunks,
+                       chunk_len, h1e, h2e, comb, hmat);
+  if (with_h)
+    hipLaunchKernelGGL((hii_kernel<LEN, T>), dim3((uint32_t)nbatch), dim3(kBlock), 0, st, bra, p.sorb, p.nele, h1e, h2e, hmat,
+                       (size_t)ncomb);
+  return check_launch("comb_hij");
+}
+
+extern "C" int pynqs_comb_hij_fused(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                    const void *h1e, const void *h2e, int dtype, uint64_t *comb, void *hmat, void *stream) {
+  SDParams p;
+  if (!make_sd_params(sorb, nele, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
+  if (nbatch < 0 || (dtype != PYNQS_F32 && dtype != PYNQS_F64)) return set_error(PYNQS_EINVAL, "bad nbatch/dtype");
+  if (nbatch == 0) return PYNQS_OK;
+  if (!bra || !h1e || !h2e || !hmat) return set_error(PYNQS_EINVAL, "null pointer");
+  if (nbatch > 0x7fffffffll) return set_error(PYNQS_EINVAL, "nbatch too large");
+  const int len = (sorb - 1) / 64 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
+  DISPATCH_LEN(len, rc = dtype == PYNQS_F64
+                          ? launch_comb_hij<LEN, double>(bra, nbatch, p, (const double *)h1e, (const double *)h2e, comb, (double *)hmat, st)
+                          : launch_comb_hij<LEN, float>(bra, nbatch, p, (const float *)h1e, (const float *)h2e, comb, (float *)hmat, st));
+  return rc;
+}
+
+extern "C" int pynqs_comb(const uint64_t *bra, int64_t nbatch, int sorb, int noA, int noB, uint64_t *comb, double *comb_pm1,
+                          void *stream) {
+  SDParams p;
+  if (!make_sd_params(sorb, noA + noB, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
+  if (nbatch < 0) return set_error(PYNQS_EINVAL, "bad nbatch");
+  if (nbatch == 0) return PYNQS_OK;
+  if (!bra || !comb) return set_error(PYNQS_EINVAL, "null pointer");
+  if (nbatch > 0x7fffffffll) return set_error(PYNQS_EINVAL, "nbatch too large");
+  const int len = (sorb - 1) / 64 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
+  DISPATCH_LEN(len, rc = launch_comb_hij<LEN, double>(bra, nbatch, p, nullptr, nullptr, comb, nullptr, st));
+  if (rc != PYNQS_OK) return rc;
+  if (comb_pm1) return pynqs_onv_to_pm1(comb, nbatch * (int64_t)(p.nsd + 1), sorb, PYNQS_F64, comb_pm1, stream);
+  return PYNQS_OK;
+}
+
+extern "C" int pynqs_hij(const uint64_t *bra, int64_t n, const uint64_t *ket, int64_t m, int ket_is_3d, const void *h1e,
+                         const void *h2e, int dtype, int sorb, int nele, void *hmat, void *stream) {
+  if (sorb < 1 || sorb > kMaxSorb || n < 0 || m < 0 || nele < 0 || (dtype != PYNQS_F32 && dtype != PYNQS_F64))
+    return set_error(PYNQS_EINVAL, "bad sorb/n/m/dtype");
+  if (n == 0 || m == 0) return PYNQS_OK;
+  if (!bra || !ket || !h1e || !h2e || !hmat) return set_error(PYNQS_EINVAL, "null pointer");
+  const int len = (sorb - 1) / 64 + 1;
+  const uint64_t total = (uint64_t)n * (uint64_t)m;
+  const uint64_t grid = (total + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "n*m too large for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_LEN(len, {
+    if (dtype == PYNQS_F64)
+      hipLaunchKernelGGL((hij_pairs_kernel<LEN, double>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, (uint64_t)n, ket,
+                         (uint64_t)m, ket_is_3d, (const double *)h1e, (const double *)h2e, sorb, nele, (double *)hmat);
+    else
+      hipLaunchKernelGGL((hij_pairs_kernel<LEN, float>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, (uint64_t)n, ket,
+                         (uint64_t)m, ket_is_3d, (const float *)h1e, (const float *)h2e, sorb, nele, (float *)hmat);
+  });
+  return check_launch("hij_pairs");
+}
+
+extern "C" int pynqs_onv_to_pm1(const uint64_t *bra, int64_t n, int sorb, int dtype, void *out, void *stream) {
+  if (sorb < 1 || sorb > kMaxSorb || n < 0 || (dtype != PYNQS_F32 && dtype != PYNQS_F64))
+    return set_error(PYNQS_EINVAL, "bad sorb/n/dtype");
+  if (n == 0) return PYNQS_OK;
+  if (!bra || !out) return set_error(PYNQS_EINVAL, "null pointer");
+  const int len = (sorb - 1) / 64 + 1;
+  const uint64_t total = (uint64_t)n * (uint64_t)sorb;
+  const uint64_t grid = (total + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "n*sorb too large for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == PYNQS_F64)
+    hipLaunchKernelGGL((onv_to_pm1_kernel<double>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, (uint64_t)n, sorb, len, (double *)out);
+  else
+    hipLaunchKernelGGL((onv_to_pm1_kernel<float>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, (uint64_t)n, sorb, len, (float *)out);
+  return check_launch("onv_to_pm1");
+}
+
+extern "C" int pynqs_pm01_to_onv(const uint8_t *occ, int64_t n, int sorb, uint64_t *out, void *stream) {
+  if (sorb < 1 || sorb > kMaxSorb || n < 0) return set_error(PYNQS_EINVAL, "bad sorb/n");
+  if (n == 0) return PYNQS_OK;
+  if (!occ || !out) return set_error(PYNQS_EINVAL, "null pointer");
+  const int len = (sorb - 1) / 64 + 1;
+  const uint64_t waves = (uint64_t)n * len;
+  const uint64_t grid = (waves * 64 + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "n too large for one launch");
+  hipLaunchKernelGGL(pm01_to_onv_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, (hipStream_t)stream, occ, (uint64_t)n, sorb, len, out);
+  return check_launch("pm01_to_onv");
+}
+
+extern "C" int pynqs_wavefunction_lut(const uint64_t *keys, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb,
+                                      int64_t *idx, uint8_t *mask, void *stream) {
+  if (sorb < 1 || sorb > kMaxSorb || n < 0 || nkeys < 0) return set_error(PYNQS_EINVAL, "bad sorb/n/nkeys");
+  if (n == 0) return PYNQS_OK;
+  if (!onv || !idx || !mask || (nkeys > 0 && !keys)) return set_error(PYNQS_EINVAL, "null pointer");
+  const int len = (sorb - 1) / 64 + 1;
+  const uint64_t grid = ((uint64_t)n + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "n too large for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_LEN(len, hipLaunchKernelGGL((lut_search_kernel<LEN>), dim3((uint32_t)grid), dim3(kBlock), 0, st, keys, nkeys, onv,
+                                       (uint64_t)n, idx, mask));
+  return check_launch("lut_search");
+}

@@ -1,0 +1,44 @@
+// launch.h -- host-side helpers shared by the C-ABI translation units of libpynqs_amd.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pynqs_amd.h"
+
+namespace pynqs {
+
+char *error_buffer();  // thread-local, defined in capi_common.hip
+
+inline int set_error(int code, const char *msg) {
+  snprintf(error_buffer(), 256, "%s", msg);
+  return code;
+}
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(error_buffer(), 256, "%s: %s", what, hipGetErrorString(e));
+    return PYNQS_ELAUNCH;
+  }
+  return PYNQS_OK;
+}
+
+// How a walker's row of ncomb columns is split over workgroups.  One workgroup per walker when there
+// are enough walkers to fill the chip (256 CUs x 8 resident workgroups); otherwise rows are cut into
+// chunks (multiples of 256 columns, never shorter than 2048 so that the per-workgroup table build
+// stays amortised).
+inline void plan_chunks(int64_t nbatch, uint32_t ncomb, uint32_t *nchunks, uint32_t *chunk_len) {
+  const int64_t want = 4096;  // workgroups in flight target: 2 waves of 256 CUs x 8
+  int64_t c = nbatch >= want ? 1 : (want + nbatch - 1) / nbatch;
+  int64_t maxc = (ncomb + 2047) / 2048;
+  if (c > maxc) c = maxc;
+  if (c < 1) c = 1;
+  uint32_t len = (uint32_t)((ncomb + c - 1) / c);
+  len = (len + 255u) & ~255u;
+  *chunk_len = len;
+  *nchunks = (ncomb + len - 1) / len;
+}
+
+}  // namespace pynqs
