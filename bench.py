@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py -- local-energy throughput of the MI355X determinant engine (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of walkers (every rank works on its own shard of
+`--walkers` walkers: weak scaling).  W untimed warm-up steps, then exactly K steps bracketed by
+barrier + torch.cuda.synchronize(); the maximum over ranks is the step time.  Rank 0 prints ONE JSON
+line (the contract of the build prompt) with `roofline` (dominant kernel, live HIP-event timing) and
+`cpu_baseline` (reference/oracle timed on the host cores, rank 0, N = 1 only).
+
+Workloads (config.workload):
+  fe2s2_dropin   get_comb_hij_fused on the shipped Fe2S2 problem (sorb 40, 15a15b, ncomb 7876):
+                 comb + Hmat materialised exactly like the reference API (HBM-write bound).
+  syn<sorb>_dropin  same on synthetic dense integrals, sorb in {56, 120, 184}.
+Inputs are resident in HBM before the timed region.  Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+# ---------------------------------------------------------------------------------------------------
+def synth_integrals(sorb: int, seed: int = 1234):
+    g = torch.Generator().manual_seed(seed)
+    h1 = torch.rand(sorb, sorb, generator=g, dtype=torch.float64) - 0.5
+    h1 = (h1 + h1.T).reshape(-1).contiguous()
+    pair = sorb * (sorb - 1) // 2
+    h2 = torch.rand(pair * (pair + 1) // 2, generator=g, dtype=torch.float64) - 0.5
+    return h1, h2
+
+
+def synth_walkers(n: int, sorb: int, noA: int, noB: int, seed: int) -> torch.Tensor:
+    """noA distinct even + noB distinct odd orbitals per walker, packed on the host."""
+    g = np.random.default_rng(seed)
+    k = sorb // 2
+    ra = np.argsort(g.random((n, k)), axis=1)[:, :noA]
+    rb = np.argsort(g.random((n, k)), axis=1)[:, :noB]
+    L = (sorb - 1) // 64 + 1
+    words = np.zeros((n, L), dtype=np.uint64)
+    for orb in (2 * ra, 2 * rb + 1):
+        for c in range(orb.shape[1]):
+            o = orb[:, c]
+            np.bitwise_or.at(words, (np.arange(n), o // 64), np.uint64(1) << (o % 64).astype(np.uint64))
+    return torch.from_numpy(words.view(np.uint8).reshape(n, 8 * L))
+
+
+def load_fe2s2():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "fe2s2_inputs.npz"))
+    return d
+
+
+def algorithmic_bytes_dropin(sorb, nele, noA, noB, esize=8):
+    """SURVEY.md 8(d) / BASELINE.md 3: bytes per walker of the drop-in fused call."""
+    k = sorb // 2
+    nvA, nvB = k - noA, k - noB
+    nS = noA * nvA + noB * nvB
+    nD = noA * (noA - 1) // 2 * (nvA * (nvA - 1) // 2) + noB * (noB - 1) // 2 * (nvB * (nvB - 1) // 2) + noA * noB * nvA * nvB
+    ncomb = 1 + nS + nD
+    L = (sorb - 1) // 64 + 1
+    gathers = esize * (nD + nS * (1 + nele) + nele + nele * (nele - 1) // 2)
+    out = ncomb * (esize + 8 * L)
+    return gathers + out + 8 * L, ncomb
+
+
+# ---------------------------------------------------------------------------------------------------
+class Workload:
+    name = ""
+    unit_per_walker = 1
+
+    def step(self):  # enqueue one pass; returns (start_event, end_event) around the dominant kernel
+        raise NotImplementedError
+
+
+class DropinFused(Workload):
+    """get_comb_hij_fused: enumerate + <x|H|x'>, comb and Hmat written to HBM (reference API shape)."""
+
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev):
+        from pynqs_amd import _native as N
+
+        self.N = N
+        self.lib = N.lib()
+        self.name = f"{tag}_dropin"
+        self.sorb, self.nele, self.noA, self.noB = sorb, nele, noA, noB
+        self.h1, self.h2, self.x = h1.to(dev), h2.to(dev), walkers.to(dev).contiguous()
+        self.n = self.x.size(0)
+        self.bytes_per_walker, self.ncomb = algorithmic_bytes_dropin(sorb, nele, noA, noB)
+        L = (sorb - 1) // 64 + 1
+        self.comb = torch.empty((self.n, self.ncomb, 8 * L), dtype=torch.uint8, device=dev)
+        self.hmat = torch.empty((self.n, self.ncomb), dtype=torch.float64, device=dev)
+        self.dev = dev
+        self.kernel = "comb_hij_kernel"
+
+    def step(self):
+        st = torch.cuda.current_stream(self.dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        rc = self.lib.pynqs_comb_hij_fused(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
+                                           self.h1.data_ptr(), self.h2.data_ptr(), self.N.PYNQS_F64,
+                                           self.comb.data_ptr(), self.hmat.data_ptr(), st.cuda_stream)
+        e1.record(st)
+        self.N.check(rc, "pynqs_comb_hij_fused")
+        return e0, e1
+
+    def parity_gate(self):
+        """max |dH| against the CPU oracle on the first walkers (SURVEY.md 8d 'parity gate')."""
+        from oracle import oracle as O
+
+        m = min(self.n, 8)
+        co, ho = O.comb_hij_fused(self.x[:m].cpu().numpy(), self.h1.cpu().numpy(), self.h2.cpu().numpy(), self.sorb,
+                                  self.nele, self.noA, self.noB)
+        ok_c = np.array_equal(self.comb[:m].cpu().numpy(), co)
+        dh = float(np.abs(self.hmat[:m].cpu().numpy() - ho).max())
+        return ok_c, dh
+
+    def cpu_baseline(self, budget_s=15.0):
+        """The reference's own CPU extension (oracle/_ref, compiled from its sources) when present, else the
+        oracle port; all host cores; bounded sample of the same workload."""
+        x = self.x.cpu(); h1 = self.h1.cpu(); h2 = self.h2.cpu()
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")
+        kind, fn = "port", None
+        # the GPU box gives one GPU's share of the host: 16 cores (build prompt); use min(affinity, 16)
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        if self.sorb <= 64 and self.nele <= 40 and os.path.exists(os.path.join(ref_dir, "C_extension.so")):
+            try:
+                sys.path.insert(0, ref_dir)
+                import C_extension as ref  # noqa: the reference module, MAX_SORB_LEN = 1
+
+                torch.set_num_threads(cores)
+                fn = lambda xs: ref.get_comb_hij_fused(xs, h1, h2, self.sorb, self.nele, self.noA, self.noB)
+                kind = "reference"
+            except Exception as e:  # pragma: no cover
+                print(f"[bench] oracle/_ref not usable ({e}); falling back to the oracle port", file=sys.stderr)
+        if fn is None:
+            from oracle import oracle as O
+
+            h1n, h2n = h1.numpy(), h2.numpy()
+            fn = lambda xs: O.comb_hij_fused(xs.numpy(), h1n, h2n, self.sorb, self.nele, self.noA, self.noB, nthreads=cores)
+        # calibrate the sample so that the timed part is ~budget_s
+        m = max(1, min(self.n, 256))
+        t0 = time.perf_counter(); fn(x[:m].contiguous()); dt = time.perf_counter() - t0
+        rate = m / max(dt, 1e-6)
+        sample = int(max(m, min(self.n, rate * budget_s / 4)))
+        reps, done, t0 = 0, 0, time.perf_counter()
+        while True:
+            fn(x[:sample].contiguous()); reps += 1; done += sample
+            if time.perf_counter() - t0 > budget_s * 0.8 or reps >= 50:
+                break
+        el = time.perf_counter() - t0
+        return {"value": done / el, "unit": "local energies/s", "cores": cores, "kind": kind,
+                "sample": f"{reps} x get_comb_hij_fused on the first {sample} walkers of the same batch ({el:.1f} s)"}
+
+
+def make_workload(name: str, walkers: int, rank: int, dev) -> Workload:
+    if name == "fe2s2_dropin":
+        d = load_fe2s2()
+        ci = d["ci_space"]
+        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        return DropinFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
+                           torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev)
+    if name.startswith("syn") and name.endswith("_dropin"):
+        sorb = int(name[3:-7])
+        no = {56: 7, 120: 30, 184: 46}.get(sorb, sorb // 4)
+        h1, h2 = synth_integrals(sorb)
+        return DropinFused(f"syn{sorb}", sorb, 2 * no, no, no, h1, h2, synth_walkers(walkers, sorb, no, no, 4321 + rank), dev)
+    raise SystemExit(f"unknown workload {name}")
+
+
+# ---------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fe2s2_dropin")
+    ap.add_argument("--walkers", type=int, default=8192, help="walkers per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    wl = make_workload(args.workload, args.walkers, rank, dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    events = [wl.step() for _ in range(args.steps)]
+    barrier()
+    el = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+
+    if rank == 0:
+        ok_c, dh = wl.parity_gate()
+        total_walkers = wl.n * world * args.steps
+        value = total_walkers / el
+        ach = wl.bytes_per_walker * wl.n / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_{wl.name}.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "local energies/sec (whole node)",
+            "value": value,
+            "unit": "local energies/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "shipped Fe2S2 integrals + ci_space walkers (tests/golden fixture)" if args.workload.startswith("fe2s2")
+                    else "synthetic (seeded dense integrals, random walkers)",
+            "config": {"workload": wl.name, "sorb": wl.sorb, "nele": wl.nele, "ncomb": wl.ncomb,
+                       "walkers_per_gpu": wl.n, "parallelism": f"walker-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": wl.bytes_per_walker * wl.n},
+            "parity": {"comb_bit_exact": bool(ok_c), "max_abs_dH_vs_oracle": dh},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

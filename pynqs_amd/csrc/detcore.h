@@ -183,15 +183,26 @@ __device__ __forceinline__ int64_t lut_find(const uint64_t *__restrict__ keys, i
 // ---- per-walker LDS state ------------------------------------------------------------------------
 // merged[sorb]  : onstate.cpp:147-193 slot list (u8 orbitals)
 // occv[nele]    : occupied orbitals in the order singles visit them (word ascending, bit 63 -> 0)
+// occa[192]     : occupied orbitals ascending, zero-padded (the reference's olst, hamiltonian.cpp:38-39)
 // tab[...]      : excitation tables, entry = orbX | orbY << 8 | parity << 16
+// scratch       : kDiagTile elements of the integral dtype (diagonal-element terms), 8-byte aligned
 struct LdsLayout {
   uint8_t *merged;
   uint8_t *occv;
+  uint8_t *occa;
   uint32_t *tab;
+  unsigned char *scratch;
 };
 
-__host__ __device__ inline size_t lds_bytes(const SDParams &p) {
-  return (size_t)p.tabEntries * 4 + 2 * 192;
+constexpr int kDiagTile = 2048;
+
+__host__ __device__ inline size_t lds_fixed_bytes(const SDParams &p) {
+  return (((size_t)p.tabEntries * 4 + 3 * 192) + 7) & ~(size_t)7;
+}
+
+// with_diag_scratch: room for kDiagTile values of `elem` bytes after the fixed part
+__host__ __device__ inline size_t lds_bytes(const SDParams &p, size_t elem = 0) {
+  return lds_fixed_bytes(p) + elem * kDiagTile;
 }
 
 __device__ __forceinline__ LdsLayout carve_lds(unsigned char *base, const SDParams &p) {
@@ -199,6 +210,8 @@ __device__ __forceinline__ LdsLayout carve_lds(unsigned char *base, const SDPara
   L.tab = reinterpret_cast<uint32_t *>(base);
   L.merged = base + (size_t)p.tabEntries * 4;
   L.occv = L.merged + 192;
+  L.occa = L.occv + 192;
+  L.scratch = base + lds_fixed_bytes(p);
   return L;
 }
 
@@ -227,6 +240,8 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     occA += __popcll(wk.w[i] & 0x5555555555555555ull);
     occB += __popcll(wk.w[i] & 0xAAAAAAAAAAAAAAAAull);
   }
+  for (int s = tid; s < 192; s += blockDim.x) L.occa[s] = 0;
+  __syncthreads();
   for (int s = tid; s < sorb; s += blockDim.x) {
     const int word = s >> 6, b = s & 63;
     const uint64_t spin = (s & 1) ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
@@ -244,13 +259,14 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     L.merged[2 * r + (s & 1)] = (uint8_t)s;
     if (occ) {
       // visiting order of singles: words ascending, bits descending inside a word
-      int before = 0;
+      int before = 0, lower = 0;
 #pragma unroll
       for (int i = 0; i < LEN; ++i) {
-        if (i < word) before += __popcll(wk.w[i]);
-        if (i == word) before += __popcll(wk.w[i] & ~below & ~(1ull << b));
+        if (i < word) { before += __popcll(wk.w[i]); lower += __popcll(wk.w[i]); }
+        if (i == word) { before += __popcll(wk.w[i] & ~below & ~(1ull << b)); lower += __popcll(wk.w[i] & below); }
       }
       L.occv[before] = (uint8_t)s;
+      L.occa[lower] = (uint8_t)s;
     }
   }
   __syncthreads();
@@ -363,6 +379,40 @@ __device__ __forceinline__ T element(const Excitation &x, const SDParams &p, con
     acc += two_body<T>(h2e, hp, k, q, k);
   }
   return x.par ? -acc : acc;
+}
+
+// Diagonal element <x|H|x>, hamiltonian.cpp:34-50.  The reference adds nele(nele+1)/2 terms in a fixed
+// order (for p ascending: h(p,p), then <pq||pq> for q < p ascending).  The whole workgroup gathers the
+// terms into LDS (coalescing does not matter: they are L2 hits), then ONE lane (the last of the block)
+// adds them in the reference's order, so the value is bit-identical; the other waves go on.
+// Must be called by every thread of the block, after build_walker_tables.
+template <typename T>
+__device__ __forceinline__ void diag_phase(const SDParams &p, const LdsLayout &L, const T *__restrict__ h1e,
+                                           const T *__restrict__ h2e, T *__restrict__ out) {
+  T *tile = reinterpret_cast<T *>(L.scratch);
+  const int tid = threadIdx.x;
+  const int nele = p.nele;
+  const int nterms = nele * (nele + 1) / 2;
+  T acc = T(0);
+  for (int base = 0; base < nterms; base += kDiagTile) {
+    const int end = min(base + kDiagTile, nterms);
+    if (base) __syncthreads();  // previous tile fully consumed
+    for (int t = base + tid; t < end; t += blockDim.x) {
+      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (a * (a + 1) / 2 > t) --a;
+      while ((a + 1) * (a + 2) / 2 <= t) ++a;
+      const int pos = t - a * (a + 1) / 2;
+      const int pa = L.occa[a];
+      T v;
+      if (pos == 0) v = h1e[(size_t)pa * p.sorb + pa];
+      else v = two_body<T>(h2e, pa, L.occa[pos - 1], pa, L.occa[pos - 1]);
+      tile[t - base] = v;
+    }
+    __syncthreads();
+    if (tid == (int)blockDim.x - 1)
+      for (int t = 0; t < end - base; ++t) acc += tile[t];
+  }
+  if (tid == (int)blockDim.x - 1) *out = acc;
 }
 
 }  // namespace pynqs

@@ -1,6 +1,5 @@
 // kernels_det.hip -- drop-in determinant kernels of libpynqs_amd (gfx950).
 //   comb_hij_kernel : enumerate S+D excitations (+ <x|H|x'>)      [get_comb_hij_fused / get_comb_tensor]
-//   hii_kernel      : diagonal <x|H|x>                             [column 0 of Hmat]
 //   hij_pairs_kernel: generic bra/ket pairs, 3-D and 2-D mode      [get_hij_torch]
 //   onv_to_pm1 / pm01_to_onv / lut_search                          [onv_to_tensor / tensor_to_onv / wavefunction_lut]
 // Reference behaviour: cpp_src/cpu/*.cpp, cpp_src/tensor/cpu_tensor.cpp (cited per kernel).
@@ -13,7 +12,7 @@ namespace pynqs {
 // Fused enumerate + matrix element.  cpu_tensor.cpp:220-272 / excitation.cpp:125-169.
 // grid = nbatch * nchunks workgroups of 256; workgroup (walker, chunk) covers columns
 // [chunk*chunk_len, (chunk+1)*chunk_len) of that walker's row.  Column 0 (x itself) only gets its comb
-// entry here; Hmat[:,0] comes from hii_kernel.
+// entry from the loop; Hmat[:,0] is produced by diag_phase in the walker's first workgroup.
 template <int LEN, typename T, bool WRITE_COMB, bool WITH_H>
 __global__ __launch_bounds__(kBlock) void comb_hij_kernel(const uint64_t *__restrict__ bra, SDParams p,
                                                           uint32_t nchunks, uint32_t chunk_len,
@@ -32,6 +31,9 @@ __global__ __launch_bounds__(kBlock) void comb_hij_kernel(const uint64_t *__rest
   const uint32_t lo = chunk * chunk_len;
   const uint32_t hi = min(lo + chunk_len, ncomb);
   const size_t row = (size_t)walker * ncomb;
+  if constexpr (WITH_H) {
+    if (chunk == 0) diag_phase<T>(p, L, h1e, h2e, hmat + row);
+  }
   for (uint32_t k = lo + threadIdx.x; k < hi; k += kBlock) {
     uint64_t ket[LEN];
     if (k == 0) {
@@ -49,58 +51,6 @@ __global__ __launch_bounds__(kBlock) void comb_hij_kernel(const uint64_t *__rest
     }
     if constexpr (WITH_H) hmat[row + k] = element<T>(x, p, L, nocc, h1e, h2e);
   }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Diagonal element, hamiltonian.cpp:34-50.  The reference adds nele(nele+1)/2 terms in a fixed order
-// (for p ascending: h(p,p), then <pq||pq> for q < p ascending); the gathers are done by the whole
-// workgroup into LDS, the additions by one lane in that order, so the result is bit-identical.
-constexpr int kDiagTile = 2048;
-
-template <int LEN, typename T>
-__global__ __launch_bounds__(kBlock) void hii_kernel(const uint64_t *__restrict__ bra, int sorb, int nele,
-                                                     const T *__restrict__ h1e, const T *__restrict__ h2e,
-                                                     T *__restrict__ out, size_t out_stride) {
-  __shared__ uint8_t occ[kMaxSorb];
-  __shared__ T terms[kDiagTile];
-  const uint64_t walker = blockIdx.x;
-  Walker<LEN> wk;
-  load_walker<LEN>(bra + walker * LEN, wk);
-  const int tid = threadIdx.x;
-  if (tid < kMaxSorb) occ[tid] = 0;  // the reference's olst is zero-initialised
-  __syncthreads();
-  if (tid < sorb && bit_of<LEN>(wk.w, tid)) {
-    int r = 0;
-#pragma unroll
-    for (int i = 0; i < LEN; ++i) {
-      const int word = tid >> 6;
-      uint64_t m = i < word ? ~0ull : (i == word ? ((1ull << (tid & 63)) - 1ull) : 0ull);
-      r += __popcll(wk.w[i] & m);
-    }
-    occ[r] = (uint8_t)tid;
-  }
-  __syncthreads();
-  const int nterms = nele * (nele + 1) / 2;
-  T acc = T(0);
-  for (int base = 0; base < nterms; base += kDiagTile) {
-    const int end = min(base + kDiagTile, nterms);
-    for (int t = base + tid; t < end; t += kBlock) {
-      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > t) --a;
-      while ((a + 1) * (a + 2) / 2 <= t) ++a;
-      const int pos = t - a * (a + 1) / 2;
-      const int pa = occ[a];
-      T v;
-      if (pos == 0) v = h1e[(size_t)pa * sorb + pa];
-      else v = two_body<T>(h2e, pa, occ[pos - 1], pa, occ[pos - 1]);
-      terms[t - base] = v;
-    }
-    __syncthreads();
-    if (tid == 0)
-      for (int t = 0; t < end - base; ++t) acc += terms[t];
-    __syncthreads();
-  }
-  if (tid == 0) out[walker * out_stride] = acc;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -265,10 +215,10 @@ static int launch_comb_hij(const uint64_t *bra, int64_t nbatch, const SDParams &
   const uint32_t ncomb = p.nsd + 1;
   uint32_t nchunks, chunk_len;
   plan_chunks(nbatch, ncomb, &nchunks, &chunk_len);
-  const size_t lds = lds_bytes(p);
+  const bool with_h = hmat != nullptr;
+  const size_t lds = lds_bytes(p, with_h ? sizeof(T) : 0);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large: nbatch*nchunks > 2^31-1");
-  const bool with_h = hmat != nullptr;
   if (comb && with_h)
     hipLaunchKernelGGL((comb_hij_kernel<LEN, T, true, true>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, nchunks,
                        chunk_len, h1e, h2e, comb, hmat);
@@ -278,9 +228,6 @@ static int launch_comb_hij(const uint64_t *bra, int64_t nbatch, const SDParams &
   else
     hipLaunchKernelGGL((comb_hij_kernel<LEN, T, false, true>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, nchunks,
                        chunk_len, h1e, h2e, comb, hmat);
-  if (with_h)
-    hipLaunchKernelGGL((hii_kernel<LEN, T>), dim3((uint32_t)nbatch), dim3(kBlock), 0, st, bra, p.sorb, p.nele, h1e, h2e, hmat,
-                       (size_t)ncomb);
   return check_launch("comb_hij");
 }
 
