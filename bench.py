@@ -89,7 +89,7 @@ class Workload:
 class DropinFused(Workload):
     """get_comb_hij_fused: enumerate + <x|H|x'>, comb and Hmat written to HBM (reference API shape)."""
 
-    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev):
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev, path="plan"):
         from pynqs_amd import _native as N
 
         self.N = N
@@ -103,15 +103,35 @@ class DropinFused(Workload):
         self.comb = torch.empty((self.n, self.ncomb, 8 * L), dtype=torch.uint8, device=dev)
         self.hmat = torch.empty((self.n, self.ncomb), dtype=torch.float64, device=dev)
         self.dev = dev
-        self.kernel = "comb_hij_kernel"
+        self.comb_ptr = self.comb.data_ptr()
+        self.path = path if sorb % 2 == 0 else "direct"
+        self.kernel = "comb_hij_plan_kernel" if self.path == "plan" else "comb_hij_kernel"
+        self.plan, self.plan_build_ms = None, None
+        if self.path == "plan":
+            # one-time re-layout of the integrals (include/pynqs_amd.h 'integral plan'); built once per
+            # (h1e, h2e), outside the timed region like the integrals themselves
+            nb = self.lib.pynqs_plan_bytes(sorb, N.PYNQS_F64)
+            self.plan = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream(dev)
+            e0.record(st)
+            N.check(self.lib.pynqs_plan_build(self.h1.data_ptr(), self.h2.data_ptr(), sorb, N.PYNQS_F64, self.plan.data_ptr(),
+                                              st.cuda_stream), "plan_build")
+            e1.record(st); e1.synchronize()
+            self.plan_build_ms = e0.elapsed_time(e1)
 
     def step(self):
         st = torch.cuda.current_stream(self.dev)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        rc = self.lib.pynqs_comb_hij_fused(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
-                                           self.h1.data_ptr(), self.h2.data_ptr(), self.N.PYNQS_F64,
-                                           self.comb.data_ptr(), self.hmat.data_ptr(), st.cuda_stream)
+        if self.plan is not None:
+            rc = self.lib.pynqs_comb_hij_fused_plan(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
+                                                    self.plan.data_ptr(), self.N.PYNQS_F64, self.comb_ptr,
+                                                    self.hmat.data_ptr(), st.cuda_stream)
+        else:
+            rc = self.lib.pynqs_comb_hij_fused(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
+                                               self.h1.data_ptr(), self.h2.data_ptr(), self.N.PYNQS_F64,
+                                               self.comb_ptr, self.hmat.data_ptr(), st.cuda_stream)
         e1.record(st)
         self.N.check(rc, "pynqs_comb_hij_fused")
         return e0, e1
@@ -165,18 +185,18 @@ class DropinFused(Workload):
                 "sample": f"{reps} x get_comb_hij_fused on the first {sample} walkers of the same batch ({el:.1f} s)"}
 
 
-def make_workload(name: str, walkers: int, rank: int, dev) -> Workload:
+def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -> Workload:
     if name == "fe2s2_dropin":
         d = load_fe2s2()
         ci = d["ci_space"]
         idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
         return DropinFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
-                           torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev)
+                           torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev, path)
     if name.startswith("syn") and name.endswith("_dropin"):
         sorb = int(name[3:-7])
         no = {56: 7, 120: 30, 184: 46}.get(sorb, sorb // 4)
         h1, h2 = synth_integrals(sorb)
-        return DropinFused(f"syn{sorb}", sorb, 2 * no, no, no, h1, h2, synth_walkers(walkers, sorb, no, no, 4321 + rank), dev)
+        return DropinFused(f"syn{sorb}", sorb, 2 * no, no, no, h1, h2, synth_walkers(walkers, sorb, no, no, 4321 + rank), dev, path)
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -188,6 +208,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fe2s2_dropin")
     ap.add_argument("--walkers", type=int, default=8192, help="walkers per GPU")
+    ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
+    ap.add_argument("--no-comb", action="store_true", help="diagnostic: skip the comb output (Hmat only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -207,7 +229,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    wl = make_workload(args.workload, args.walkers, rank, dev)
+    wl = make_workload(args.workload, args.walkers, rank, dev, args.path)
+    if args.no_comb:
+        wl.comb_ptr = None
 
     def barrier():
         if dist is not None:
@@ -252,7 +276,7 @@ def main():
             "data": "shipped Fe2S2 integrals + ci_space walkers (tests/golden fixture)" if args.workload.startswith("fe2s2")
                     else "synthetic (seeded dense integrals, random walkers)",
             "config": {"workload": wl.name, "sorb": wl.sorb, "nele": wl.nele, "ncomb": wl.ncomb,
-                       "walkers_per_gpu": wl.n, "parallelism": f"walker-sharded x{world}, no data-path collective"},
+                       "walkers_per_gpu": wl.n, "integral_layout": wl.path, "plan_build_ms": wl.plan_build_ms, "parallelism": f"walker-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": wl.bytes_per_walker * wl.n},

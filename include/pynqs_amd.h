@@ -89,6 +89,20 @@ int pynqs_pm01_to_onv(const uint8_t *occ, int64_t n, int sorb, uint64_t *out, vo
 int pynqs_wavefunction_lut(const uint64_t *keys, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb,
                            int64_t *idx, uint8_t *mask, void *stream);
 
+/* ---- integral plan: the fast path ---------------------------------------------------------------
+ * The reference keeps h2e as one packed triangle over all spin-orbital pairs (integral.cpp:6-60); random
+ * gathers from it are bound by the CU's vector L1.  A plan is a spin-blocked dense re-layout of the SAME
+ * values (pynqs_amd/csrc/plan.h) in caller-owned device memory; it is built once per (h1e, h2e) and then
+ * replaces the two pointers.  Needs an even sorb.  Results are bit-identical to the direct entry points.
+ *   pynqs_plan_bytes : [host] size of the plan buffer in bytes, or -1 if unsupported
+ *   pynqs_plan_build : fill `plan` from the reference-layout h1e / h2e (one kernel, no sync)          */
+int64_t pynqs_plan_bytes(int sorb, int dtype);
+int pynqs_plan_build(const void *h1e, const void *h2e, int sorb, int dtype, void *plan, void *stream);
+
+/* get_comb_hij_fused (bind.cpp:239-250) on a plan.  Same outputs as pynqs_comb_hij_fused. */
+int pynqs_comb_hij_fused_plan(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                              const void *plan, int dtype, uint64_t *comb, void *hmat, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ from . import _native as N
 MAX_SORB_LEN = 3  # run-time word-count dispatch; the reference compiles one build per length
 MAX_SORB = 64 * MAX_SORB_LEN
 MAX_NELE = 120
+USE_PLAN = True  # route get_comb_hij_fused through the cached integral plan (False: direct packed-triangle kernels)
 
 __all__ = [
     "tensor_to_onv", "onv_to_tensor", "get_comb_tensor", "get_hij_torch", "get_comb_hij_fused",
@@ -83,6 +84,51 @@ def _check_integrals(h1e: Tensor, h2e: Tensor, sorb: int) -> None:
     if h1e.numel() != sorb * sorb or h2e.numel() != pair * (pair + 1) // 2:
         # the reference reads out of bounds here; an explicit error is the safe equivalent
         raise RuntimeError(f"h1e/h2e sizes {h1e.numel()}/{h2e.numel()} do not match sorb = {sorb}")
+
+
+class IntegralPlan:
+    """Device-resident spin-blocked re-layout of (h1e, h2e) (include/pynqs_amd.h, 'integral plan').
+    Built once per pair of integral tensors; values are copies of h1e/h2e elements, so every kernel that
+    reads the plan returns bit-identical numbers to the direct-layout kernels."""
+
+    def __init__(self, h1e: Tensor, h2e: Tensor, sorb: int):
+        code = _fdtype(h1e, h2e)
+        _check_integrals(h1e, h2e, sorb)
+        nbytes = N.lib().pynqs_plan_bytes(sorb, code)
+        if nbytes < 0:
+            raise RuntimeError(f"integral plan needs an even sorb in [2, {MAX_SORB}], got {sorb}")
+        dev, (a, b), _ = _stage(h1e, h2e)
+        self.sorb, self.code, self.dtype, self.device = sorb, code, h1e.dtype, dev
+        self.buf = torch.empty(nbytes // h1e.element_size(), dtype=h1e.dtype, device=dev)
+        N.check(N.lib().pynqs_plan_build(a.data_ptr(), b.data_ptr(), sorb, code, self.buf.data_ptr(), _stream(dev)), "plan_build")
+        # a, b may be staging copies: the build kernel must finish before they are released
+        if a is not h1e or b is not h2e:
+            torch.cuda.current_stream(dev).synchronize()
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+
+_PLANS: "list[tuple]" = []  # (weakref(h1e), weakref(h2e), versions, sorb, plan), most recent first
+_MAX_PLANS = 4
+
+
+def plan_for(h1e: Tensor, h2e: Tensor, sorb: int) -> "IntegralPlan | None":
+    """Cached IntegralPlan for these tensor objects (None when sorb is odd -> direct kernels)."""
+    import weakref
+
+    if sorb % 2 or sorb < 2:
+        return None
+    ver = (h1e._version, h2e._version, h1e.data_ptr(), h2e.data_ptr())
+    for i, (r1, r2, v, s, pl) in enumerate(_PLANS):
+        if r1() is h1e and r2() is h2e and v == ver and s == sorb:
+            if i:
+                _PLANS.insert(0, _PLANS.pop(i))
+            return pl
+    pl = IntegralPlan(h1e, h2e, sorb)
+    _PLANS.insert(0, (weakref.ref(h1e), weakref.ref(h2e), ver, sorb, pl))
+    del _PLANS[_MAX_PLANS:]
+    return pl
 
 
 def get_Num_SinglesDoubles(sorb: int, noA: int, noB: int) -> int:
@@ -164,6 +210,16 @@ def get_comb_hij_fused(bra: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: i
     if bra.numel() == 0:
         return (torch.empty((0, ncomb, 8 * L), dtype=torch.uint8, device=bra.device),
                 torch.empty((0, ncomb), dtype=h1e.dtype, device=h1e.device))
+    plan = plan_for(h1e, h2e, sorb) if USE_PLAN else None
+    if plan is not None:
+        dev = plan.device
+        x = bra if bra.device == dev else bra.to(dev)
+        cpu = bra.device.type == "cpu" and h1e.device.type == "cpu" and h2e.device.type == "cpu"
+        comb = torch.empty((n, ncomb, 8 * L), dtype=torch.uint8, device=dev)
+        hmat = torch.empty((n, ncomb), dtype=h1e.dtype, device=dev)
+        N.check(N.lib().pynqs_comb_hij_fused_plan(x.data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), code,
+                                                  comb.data_ptr(), hmat.data_ptr(), _stream(dev)), "get_comb_hij_fused")
+        return (comb.cpu(), hmat.cpu()) if cpu else (comb, hmat)
     dev, (x, a, b), cpu = _stage(bra, h1e, h2e)
     comb = torch.empty((n, ncomb, 8 * L), dtype=torch.uint8, device=dev)
     hmat = torch.empty((n, ncomb), dtype=h1e.dtype, device=dev)

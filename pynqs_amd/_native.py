@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpynqs_amd.so")
+# PYNQS_AMD_LIB selects another build of the same library (e.g. a profiling variant); never a fallback
+LIB_PATH = os.environ.get("PYNQS_AMD_LIB") or os.path.join(_HERE, "csrc", "libpynqs_amd.so")
 
 PYNQS_F32, PYNQS_F64 = 0, 1
 OK, EINVAL, ELAUNCH, ELENGTH, EOVERFLOW = 0, -1, -2, -3, -4
@@ -29,6 +30,9 @@ SIGNATURES = {
     "pynqs_onv_to_pm1": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "pynqs_pm01_to_onv": (_int, [_vp, _i64, _int, _vp, _vp]),
     "pynqs_wavefunction_lut": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
+    "pynqs_plan_bytes": (_i64, [_int, _int]),
+    "pynqs_plan_build": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
+    "pynqs_comb_hij_fused_plan": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -184,7 +184,7 @@ __device__ __forceinline__ int64_t lut_find(const uint64_t *__restrict__ keys, i
 // merged[sorb]  : onstate.cpp:147-193 slot list (u8 orbitals)
 // occv[nele]    : occupied orbitals in the order singles visit them (word ascending, bit 63 -> 0)
 // occa[192]     : occupied orbitals ascending, zero-padded (the reference's olst, hamiltonian.cpp:38-39)
-// tab[...]      : excitation tables, entry = orbX | orbY << 8 | parity << 16
+// tab[...]      : excitation tables, entry = orbX | orbY << 8 | parity << 16 | plan offset part << 17
 // scratch       : kDiagTile elements of the integral dtype (diagonal-element terms), 8-byte aligned
 struct LdsLayout {
   uint8_t *merged;
@@ -280,7 +280,9 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     const int h = L.merged[2 * i_idx + beta];
     const int q = L.merged[2 * (a_idx + no) + beta];
     const uint32_t par = bit_of<LEN>(wk.pm, h) ^ bit_of<LEN>(wk.pm, q) ^ (uint32_t)(h < q);
-    L.tab[(beta ? p.offSb : p.offSa) + ia] = (uint32_t)h | ((uint32_t)q << 8) | (par << 16);
+    // bits 17..30: (particle spatial index) * K + (hole spatial index): the plan kernels' Vab offset parts
+    const uint32_t sp = (uint32_t)(q >> 1) * (uint32_t)(p.sorb >> 1) + (uint32_t)(h >> 1);
+    L.tab[(beta ? p.offSb : p.offSa) + ia] = (uint32_t)h | ((uint32_t)q << 8) | (par << 16) | (sp << 17);
   }
   // pair tables: hole pairs (hi > lo among occupied slots) and particle pairs (virtual slots)
   const int nPairs = p.noAA + p.nvAA + p.noBB + p.nvBB;
@@ -296,7 +298,9 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     const int o0 = L.merged[2 * (lo + base) + beta];
     // holes: P(p0)^P(p1); particles: P(q0)^P(q1)^1 (q1 < q0 is one of the flipped bits below q0)
     const uint32_t par = bit_of<LEN>(wk.pm, o1) ^ bit_of<LEN>(wk.pm, o0) ^ (uint32_t)extra;
-    L.tab[off + q] = (uint32_t)o1 | ((uint32_t)o0 << 8) | (par << 16);
+    // bits 17..29: pair rank over the spatial orbitals of this spin (the plan kernels' Vss row / column)
+    const uint32_t m1 = (uint32_t)o1 >> 1, m0 = (uint32_t)o0 >> 1;
+    L.tab[off + q] = (uint32_t)o1 | ((uint32_t)o0 << 8) | (par << 16) | ((m1 * (m1 - 1) / 2 + m0) << 17);
   }
   __syncthreads();
   return occA + occB;

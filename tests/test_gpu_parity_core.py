@@ -16,14 +16,19 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.fixture(scope="module")
-def cx():
+@pytest.fixture(scope="module", params=["plan", "direct"])
+def cx(request):
+    """Both code paths of get_comb_hij_fused: the integral-plan kernels (default) and the direct
+    packed-triangle kernels."""
     from pynqs_amd import C_extension as m
     from pynqs_amd import _native
 
     _native.lib()  # fail loudly if the HIP library is missing
     assert torch.cuda.is_available()
-    return m
+    old = m.USE_PLAN
+    m.USE_PLAN = request.param == "plan"
+    yield m
+    m.USE_PLAN = old
 
 
 def G(a):
