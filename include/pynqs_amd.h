@@ -103,6 +103,28 @@ int pynqs_plan_build(const void *h1e, const void *h2e, int sorb, int dtype, void
 int pynqs_comb_hij_fused_plan(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
                               const void *plan, int dtype, uint64_t *comb, void *hmat, void *stream);
 
+/* ---- fused local energy (no comb / Hmat materialisation), on a plan, f64 ---------------------------
+ * SAMPLE_SPACE method: vmc/energy/eloc.py:326-401 (_only_sample_space) = get_comb_hij_fused +
+ * WavefunctionLUT.lookup (utils/public_function.py:817-838, cpu_tensor.cpp:589-688) + the contraction
+ * eloc.py:395-396, in one pass.  keys uint64[nkeys][len] sorted as for pynqs_wavefunction_lut; wf is
+ * double[nkeys] or interleaved complex double[nkeys][2]; eloc / psi0 have the same element type ([nbatch] or
+ * [nbatch][2]).  psi(x') = 0 for x' outside the table; psi0 = psi(x) (0 if x itself is not in the table,
+ * eloc is then inf/nan exactly like the reference's division).  The sum is taken as (sum_k H_k psi_k) / psi_0. */
+int pynqs_eloc_sample_space(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                            const void *plan, const uint64_t *keys, int64_t nkeys, const double *wf,
+                            int wf_is_complex, double *eloc, double *psi0, void *stream);
+
+/* REDUCE method front end: vmc/energy/eloc.py:205-324 with eps_sample == 0 keeps the columns with
+ * |<x|H|x'>| >= eps (eloc.py:297-298; column 0 is treated like any other).  Two passes, nothing materialised:
+ *   pynqs_reduce_count : counts[nbatch] = kept columns per walker
+ *   pynqs_reduce_emit  : offsets[nbatch] = exclusive prefix sum of counts (caller) -> kept_col int32[total],
+ *                        kept_onv uint64[total][len], kept_h T[total], ascending column order per walker. */
+int pynqs_reduce_count(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                       const void *plan, int dtype, double eps, int64_t *counts, void *stream);
+int pynqs_reduce_emit(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                      const void *plan, int dtype, double eps, const int64_t *offsets, int32_t *kept_col,
+                      uint64_t *kept_onv, void *kept_h, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

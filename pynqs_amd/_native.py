@@ -33,6 +33,9 @@ SIGNATURES = {
     "pynqs_plan_bytes": (_i64, [_int, _int]),
     "pynqs_plan_build": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_comb_hij_fused_plan": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
+    "pynqs_eloc_sample_space": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
+    "pynqs_reduce_count": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp]),
+    "pynqs_reduce_emit": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

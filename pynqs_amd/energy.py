@@ -1,0 +1,309 @@
+"""Local energy E_loc(x) = sum_x' <x|H|x'> psi(x') / psi(x)  -- mirror of PyNQS' vmc/energy/{eloc,flip,etot}.py.
+
+Same entry points and argument meaning as the reference:
+    local_energy(x, h1e, h2e, ansatz, ansatz_batch, sorb, nele, noa, nob, ...) -> (eloc, sloc, psi, times)
+    total_energy(x, nbatch, fp_batch, h1e, h2e, ansatz, sorb, nele, noa, nob, ...) -> (eloc, sloc, placeholder)
+    Func(func, x, WF_LUT, use_unique)
+with the three methods of the reference (SIMPLE / REDUCE / SAMPLE_SPACE, vmc/energy/eloc.py:75-114) and their
+spin-flip-projected and multi-psi variants (vmc/energy/flip.py).
+
+What differs is where the work happens (all on the MI355X, through pynqs_amd.C_extension / the C ABI):
+  * enumeration and <x|H|x'> always come from the fused kernel (the reference's SIMPLE/REDUCE call the
+    unfused pair get_comb_tensor + get_hij_torch, whose outputs are bit-identical to the fused call);
+  * SAMPLE_SPACE without spin-flip / multi-psi / spin-raising runs as ONE kernel
+    (pynqs_eloc_sample_space): enumerate, matrix element, table lookup and contraction, nothing materialised;
+  * REDUCE with eps_sample == 0 compacts the kept columns on chip (pynqs_reduce_count/emit) instead of
+    writing the whole (batch, ncomb) comb/Hmat and filtering afterwards.
+`FUSED = False` forces the generic tensor path everywhere (used by the tests to cross-check the fast paths).
+"""
+from __future__ import annotations
+
+import time
+from functools import partial
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import C_extension as CX
+from . import _native as N
+from .C_extension import get_comb_hij_fused, get_hij_torch
+from .distributed import get_rank
+from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, check_para, get_Num_SinglesDoubles,
+                              spin_flip_onv, spin_flip_sign, split_batch_idx)
+
+FUSED = True  # use the fused sample-space / reduce kernels when the configuration allows it
+
+
+def Func(func: Callable[..., Tensor], x: Tensor, WF_LUT: Optional[WavefunctionLUT] = None, use_unique: bool = False) -> Tensor:
+    """vmc/energy/flip.py:29-63: psi(x) through the lookup table for known determinants, the ansatz (on the
+    unique rows if use_unique) for the others."""
+    use_lut = WF_LUT is not None
+    batch = x.size(0)
+    if use_lut:
+        lut_idx, lut_not_idx, lut_value = WF_LUT.lookup(x)
+    _x = x[lut_not_idx] if use_lut else x
+    if use_unique:
+        unique_x, inverse = torch.unique(_x, dim=0, return_inverse=True)
+        psi0 = torch.index_select(func(unique_x), 0, inverse)
+    else:
+        psi0 = func(_x)
+    if not use_lut:
+        return psi0
+    psi = torch.empty(batch, dtype=psi0.dtype, device=psi0.device)
+    psi[lut_idx] = lut_value.to(psi0.dtype)
+    psi[lut_not_idx] = psi0
+    return psi
+
+
+def _real_dtype(dtype: torch.dtype) -> torch.dtype:
+    return dtype.to_real() if dtype.is_complex else dtype
+
+
+def _contract(f_psi: Tensor, psi_x1: Tensor, hij: Tensor) -> Tensor:
+    """eloc.py:185-186: ((f_psi.T / psi_0).T * H).sum(-1)."""
+    return ((f_psi.T / psi_x1[..., 0]).T * hij).sum(-1)
+
+
+def _amplitudes(comb_flat: Tensor, sel: Optional[Tensor], batch: int, n_comb: int, ansatz, ansatz_extra, WF_LUT, use_unique,
+                use_multi_psi, use_spin_flip, extra_norm, dtype, sorb, device):
+    """psi (and, for the projected / multi-psi forms, f*psi) on the selected columns, scattered into
+    (batch, n_comb) arrays that are zero elsewhere (eloc.py:300-311, flip.py:254-303)."""
+    x = comb_flat if sel is None else comb_flat[sel]
+
+    def scatter(v: Tensor, dt=None) -> Tensor:
+        if sel is None:
+            return v.reshape(batch, n_comb)
+        out = torch.zeros(batch * n_comb, dtype=dt or v.dtype, device=device)
+        out[sel] = v.to(out.dtype)
+        return out.reshape(batch, n_comb)
+
+    psi_x1 = scatter(Func(ansatz, x, WF_LUT, use_unique).to(dtype), dtype)
+    if not use_spin_flip:
+        if use_multi_psi:
+            f = scatter(Func(ansatz_extra, x, None, use_unique).to(dtype), dtype)
+            f_psi = psi_x1 * f * f[..., 0].reshape(-1, 1).conj() / extra_norm**2
+        else:
+            f_psi = psi_x1
+        return psi_x1, f_psi
+    eta = SpinProjection.eta
+    x_flip = spin_flip_onv(x, sorb)
+    eta_m = scatter(spin_flip_sign(x, sorb))
+    psi_flip = scatter(Func(ansatz, x_flip, WF_LUT, use_unique).to(dtype), dtype)
+    if use_multi_psi:
+        f = scatter(Func(ansatz_extra, x, None, use_unique).to(dtype), dtype)
+        f_flip = scatter(Func(ansatz_extra, x_flip, None, use_unique).to(dtype), dtype)
+        f_psi = (f * psi_x1 + eta * eta_m * f_flip * psi_flip) * f[..., 0].reshape(-1, 1).conj() / extra_norm**2
+    else:
+        f_psi = (psi_x1 + eta * eta_m * psi_flip) / extra_norm**2
+    return psi_x1, f_psi
+
+
+def _reduce_select(comb_hij: Tensor, eps: float, eps_sample: int) -> Tensor:
+    """Column selection of the REDUCE method (eloc.py:257-298).  With eps_sample > 0 the small elements are
+    importance-sampled (torch.multinomial, RNG dependent) and comb_hij is re-weighted in place."""
+    batch, n_comb = comb_hij.shape
+    device = comb_hij.device
+    if eps_sample <= 0:
+        return torch.where(comb_hij.reshape(-1).abs() >= eps)[0]
+    if eps > 0.0:
+        hij_abs = comb_hij.abs()
+        mask = hij_abs >= eps
+        index = torch.where(mask.flatten())[0]
+        hij = torch.where(mask, 0, hij_abs)
+    else:
+        index = None
+        hij = comb_hij.abs()
+    prob = hij / hij.sum(1, keepdim=True)
+    counts = torch.multinomial(prob, eps_sample, replacement=True)
+    counts += torch.arange(batch, device=device).reshape(-1, 1) * n_comb
+    index1, count = counts.unique(sorted=True, return_counts=True)
+    prob = prob.flatten()
+    comb_hij.view(-1)[index1] = (count / eps_sample) * comb_hij.flatten()[index1] / prob[index1]
+    return index1 if index is None else torch.cat([index, index1])
+
+
+def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip) -> bool:
+    return (FUSED and WF_LUT is not None and WF_LUT.sort and not (use_spin_raising or use_multi_psi or use_spin_flip)
+            and sorb % 2 == 0 and h1e.dtype == torch.float64 and WF_LUT.dtype in (torch.float64, torch.complex128)
+            and x.is_cuda and WF_LUT.bra_key.is_cuda)
+
+
+def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT) -> Tuple[Tensor, Tensor]:
+    plan = CX.plan_for(h1e, h2e, sorb)
+    dev = x.device
+    cplx = WF_LUT.dtype.is_complex
+    n = x.size(0)
+    wf = WF_LUT.wf_value.contiguous()
+    eloc = torch.empty(n, dtype=WF_LUT.dtype, device=dev)
+    psi0 = torch.empty(n, dtype=WF_LUT.dtype, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rc = N.lib().pynqs_eloc_sample_space(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
+                                         WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+    N.check(rc, "pynqs_eloc_sample_space")
+    return eloc, psi0
+
+
+def reduce_compact(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float):
+    """Kept columns of the REDUCE method, compacted on the GPU: (row int64[m], col int32[m], onv uint8[m, 8*len],
+    h[m], counts int64[n]) with |h| >= eps, rows ascending and columns ascending inside a row."""
+    plan = CX.plan_for(h1e, h2e, sorb)
+    dev = x.device
+    n = x.size(0)
+    L = (sorb - 1) // 64 + 1
+    code = N.PYNQS_F64 if h1e.dtype == torch.float64 else N.PYNQS_F32
+    st = torch.cuda.current_stream(dev).cuda_stream
+    counts = torch.empty(n, dtype=torch.int64, device=dev)
+    N.check(N.lib().pynqs_reduce_count(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, float(eps), counts.data_ptr(), st),
+            "pynqs_reduce_count")
+    ends = torch.cumsum(counts, 0)
+    offsets = (ends - counts).contiguous()
+    m = int(ends[-1].item()) if n else 0
+    col = torch.empty(m, dtype=torch.int32, device=dev)
+    onv = torch.empty((m, 8 * L), dtype=torch.uint8, device=dev)
+    h = torch.empty(m, dtype=h1e.dtype, device=dev)
+    if m:
+        N.check(N.lib().pynqs_reduce_emit(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, float(eps), offsets.data_ptr(),
+                                          col.data_ptr(), onv.data_ptr(), h.data_ptr(), st), "pynqs_reduce_emit")
+    row = torch.repeat_interleave(torch.arange(n, device=dev), counts)
+    return row, col, onv, h, counts
+
+
+def local_energy(
+    x: Tensor, h1e: Tensor, h2e: Tensor, ansatz, ansatz_batch: Callable[..., Tensor], sorb: int, nele: int, noa: int, nob: int,
+    dtype=torch.double, use_spin_raising: bool = False, h1e_spin: Optional[Tensor] = None, h2e_spin: Optional[Tensor] = None,
+    WF_LUT: Optional[WavefunctionLUT] = None, use_unique: bool = True, reduce_psi: bool = False, eps: float = 1e-12,
+    eps_sample: int = 0, use_sample_space: bool = False, index: Optional[Tuple[int, int]] = None, alpha: float = 2,
+    use_multi_psi: bool = False, use_spin_flip: bool = False, extra_norm: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Tensor, Tuple[float, float, float]]:
+    """vmc/energy/eloc.py:23-132.  Returns (eloc[n], sloc[n], psi(x)[n], (t_enumerate, t_hij, t_psi) in ms)."""
+    with torch.no_grad():
+        check_para(x)
+        assert x.dim() == 2
+        if use_sample_space:
+            assert WF_LUT is not None, "WF_ULT must be used if use_sample"
+        if reduce_psi and not use_sample_space:
+            assert eps >= 0.0 and eps_sample >= 0
+        if extra_norm is None:
+            extra_norm = 1.0
+        device = h1e.device
+        batch = x.size(0)
+        t0 = time.time_ns()
+
+        # ---- fast path: SAMPLE_SPACE in one kernel ----------------------------------------------------
+        if use_sample_space and _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip):
+            eloc, psi0 = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT)
+            t1 = time.time_ns()
+            return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
+
+        if use_multi_psi:
+            ansatz_extra = partial(ansatz_batch, func=ansatz.module.extra)
+            ansatz_f = partial(ansatz_batch, func=ansatz.module.sample)
+        else:
+            ansatz_extra = None
+            ansatz_f = partial(ansatz_batch, func=ansatz)
+
+        # ---- fast path: REDUCE (deterministic) with on-chip compaction -----------------------------------
+        if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and not (use_spin_raising or use_multi_psi or use_spin_flip)
+                and sorb % 2 == 0 and x.is_cuda):
+            row, col, onv, h, counts = reduce_compact(x, h1e, h2e, sorb, nele, noa, nob, eps)
+            t2 = time.time_ns()
+            psi = Func(ansatz_f, onv, WF_LUT, use_unique).to(dtype)
+            # psi(x) = amplitude of the kept column 0 of each row; 0 if it was filtered out (as in the reference)
+            psi_x = torch.zeros(batch, dtype=dtype, device=x.device)
+            first = col == 0
+            psi_x[row[first]] = psi[first]
+            w = (psi / psi_x[row]) * h.to(_real_dtype(dtype))
+            eloc = torch.zeros(batch, dtype=w.dtype, device=x.device).index_add_(0, row, w)
+            t3 = time.time_ns()
+            return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi_x, ((t2 - t0) / 1e6, 0.0, (t3 - t2) / 1e6)
+
+        # ---- generic path: same tensor algebra as the reference ---------------------------------------------
+        comb_x, comb_hij = get_comb_hij_fused(x, h1e, h2e, sorb, nele, noa, nob)
+        t1 = time.time_ns()
+        hij_spin = get_hij_torch(x, comb_x, h1e_spin, h2e_spin, sorb, nele) if use_spin_raising else None
+        t2 = time.time_ns()
+        n_comb, bra_len = comb_x.size(1), comb_x.size(2)
+        flat = comb_x.reshape(-1, bra_len)
+
+        if use_sample_space:
+            # psi only from the table (eloc.py:381-385, flip.py:375-383); misses stay 0
+            def lut_psi(xx: Tensor) -> Tensor:
+                out = torch.zeros(xx.size(0), device=xx.device, dtype=WF_LUT.dtype)
+                idx, _, value = WF_LUT.lookup(xx)
+                out[idx] = value
+                return out, idx
+
+            psi_flat, hit = lut_psi(flat)
+            psi_x1 = psi_flat.reshape(batch, n_comb)
+            if use_spin_flip:
+                eta = SpinProjection.eta
+                flip = spin_flip_onv(flat, sorb)
+                eta_m = spin_flip_sign(flat, sorb).reshape(batch, n_comb)
+                psi_flip_flat, hit_f = lut_psi(flip)
+                psi_flip = psi_flip_flat.reshape(batch, n_comb)
+                if use_multi_psi:
+                    fz = torch.zeros_like(psi_flat); fz[hit] = Func(ansatz_extra, flat[hit], None, True).to(fz.dtype)
+                    ff = torch.zeros_like(psi_flat); ff[hit_f] = Func(ansatz_extra, flip[hit_f], None, True).to(ff.dtype)
+                    f, f_flip = fz.reshape(batch, n_comb), ff.reshape(batch, n_comb)
+                    f_psi = (f * psi_x1 + eta * eta_m * f_flip * psi_flip) * f[..., 0].reshape(-1, 1).conj() / extra_norm**2
+                else:
+                    f_psi = (psi_x1 + eta * eta_m * psi_flip) / extra_norm**2
+            elif use_multi_psi:
+                fz = torch.zeros_like(psi_flat); fz[hit] = Func(ansatz_extra, flat[hit], None, True).to(fz.dtype)
+                f = fz.reshape(batch, n_comb)
+                f_psi = psi_x1 * f * f[..., 0].reshape(-1, 1).conj() / extra_norm**2
+            else:
+                f_psi = psi_x1
+        else:
+            sel = _reduce_select(comb_hij, eps, eps_sample) if reduce_psi else None
+            psi_x1, f_psi = _amplitudes(flat, sel, batch, n_comb, ansatz_f, ansatz_extra, WF_LUT, use_unique, use_multi_psi,
+                                        use_spin_flip, extra_norm, dtype, sorb, x.device)
+
+        rdt = _real_dtype(dtype)
+        eloc = _contract(f_psi, psi_x1, comb_hij.to(rdt))
+        sloc = _contract(f_psi, psi_x1, hij_spin.to(rdt)) if use_spin_raising else torch.zeros_like(eloc)
+        t3 = time.time_ns()
+        return eloc.to(dtype), sloc.to(dtype), psi_x1[..., 0].to(dtype), ((t1 - t0) / 1e6, (t2 - t1) / 1e6, (t3 - t2) / 1e6)
+
+
+def total_energy(
+    x: Tensor, nbatch: int, fp_batch: int, h1e: Tensor, h2e: Tensor, ansatz: Callable[..., Tensor], sorb: int, nele: int, noa: int,
+    nob: int, WF_LUT: Optional[WavefunctionLUT] = None, use_unique: bool = True, dtype=torch.double, use_spin_raising: bool = False,
+    h1e_spin: Optional[Tensor] = None, h2e_spin: Optional[Tensor] = None, reduce_psi: bool = False, eps: float = 1.0e-12,
+    eps_sample: int = 0, use_sample_space: bool = False, alpha: float = 2.0, use_multi_psi: bool = False,
+    use_spin_flip: bool = False, extra_norm: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Tensor]:
+    """vmc/energy/etot.py:24-169: local energies of this rank's walkers in chunks of `nbatch` walkers, ansatz
+    forwards in chunks of `fp_batch` rows; NaN guard; returns (eloc, sloc, placeholder)."""
+    dim = x.shape[0]
+    device = x.device
+    eloc = torch.zeros(dim, device=device).to(dtype)
+    sloc = torch.zeros_like(eloc)
+    assert fp_batch > 0 or fp_batch == -1
+    assert nbatch > 0 or nbatch == -1
+    if nbatch == -1:
+        nbatch = dim
+    ends = split_batch_idx(dim, min_batch=nbatch) if dim else []
+
+    def _ansatz_batch(x: Tensor, func: Callable[[Tensor], Tensor]) -> Tensor:
+        return ansatz_batch(func, x, fp_batch, sorb, device, dtype)
+
+    begin = 0
+    for end in ends:
+        _eloc, _sloc, _psi, _ = local_energy(
+            x[begin:end], h1e, h2e, ansatz, _ansatz_batch, sorb, nele, noa, nob, dtype=dtype, WF_LUT=WF_LUT,
+            use_spin_raising=False if reduce_psi else use_spin_raising, h1e_spin=h1e_spin, h2e_spin=h2e_spin, use_unique=use_unique,
+            reduce_psi=reduce_psi, eps=eps, eps_sample=eps_sample, use_sample_space=use_sample_space, index=(begin, end), alpha=alpha,
+            use_multi_psi=use_multi_psi, extra_norm=extra_norm, use_spin_flip=use_spin_flip)
+        if reduce_psi and use_spin_raising:
+            # <S-S+> is recomputed in the sample space (etot.py:119-142)
+            _sloc, _, _, _ = local_energy(x[begin:end], h1e_spin, h2e_spin, ansatz, _ansatz_batch, sorb, nele, noa, nob, dtype=dtype,
+                                          WF_LUT=WF_LUT, use_spin_raising=False, use_sample_space=True, index=(begin, end), alpha=alpha)
+        eloc[begin:end] = _eloc
+        sloc[begin:end] = _sloc
+        begin = end
+    if torch.any(torch.isnan(eloc)):
+        raise ValueError("The Local energy exists nan")
+    return eloc, sloc, torch.zeros(1, device=device, dtype=dtype)

@@ -1,0 +1,80 @@
+"""Weighted Monte-Carlo statistics with all-reduce (mirror of PyNQS' utils/stats/{dist_stats,mc_stats}.py).
+
+<O> = sum_rank sum_i O_i p_i / world_size with p pre-scaled by world_size (vmc/sample.py:772);
+var = sum |<O> - O_i|^2 p_i, sd = sqrt(var), se = sd / sqrt(counts)   (dist_stats.py:18-79).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .distributed import all_reduce_packed, get_world_size
+
+
+def _wdot(x: Tensor, p: Tensor) -> Tensor:
+    if torch.is_complex(x):
+        return torch.complex(torch.dot(x.real, p), torch.dot(x.imag, p))
+    return torch.dot(x, p)
+
+
+def dist_mean(x: Tensor, prob: Tensor, world_size: int = 1) -> Tensor:
+    assert x.dim() == 1 and prob.dim() == 1
+    return all_reduce_packed([_wdot(x, prob)], world_size)[0]
+
+
+def dist_var(x: Tensor, prob: Tensor, world_size: int = 1) -> Tuple[Tensor, Tensor]:
+    mean = dist_mean(x, prob, world_size)
+    corr = mean - x
+    var = all_reduce_packed([(corr * corr.conj() * prob).sum()], world_size)[0]
+    return mean, var
+
+
+def dist_stats(x: Tensor, prob: Tensor, counts: Optional[int] = None, world_size: int = 1):
+    """Two-pass form, identical in arithmetic to the reference (dist_stats.py:59-79)."""
+    mean, var = dist_var(x, prob, world_size)
+    sd = torch.sqrt(var)
+    if counts is None:
+        n = torch.tensor([float(x.size(0))], dtype=torch.float64, device=x.device)
+        counts = all_reduce_packed([n], 1)[0].item()  # total number of samples over ranks
+    se = sd / counts**0.5
+    return mean, var, sd, se
+
+
+def dist_stats_onepass(x: Tensor, prob: Tensor, counts: Optional[int] = None, world_size: int = 1):
+    """Same quantities from ONE packed all-reduce of (sum p O, sum p |O|^2, sum p[, n]):
+    var = E|O|^2 - |E O|^2 (valid when the global weights sum to world_size, i.e. normalised p).
+    One message instead of the reference's two all-reduce + barrier pairs; differs from the two-pass
+    value only by rounding."""
+    one = torch.ones((), dtype=prob.dtype, device=x.device)
+    vals = [_wdot(x, prob), torch.dot((x * x.conj()).real, prob), prob.sum() * one]
+    if counts is None:
+        vals.append(torch.tensor(float(x.size(0)), dtype=prob.dtype, device=x.device) * get_world_size())
+    red = all_reduce_packed([v.to(torch.complex128) if torch.is_complex(vals[0]) else v for v in vals], world_size)
+    mean, m2, psum = red[0], red[1].real if torch.is_complex(red[1]) else red[1], red[2]
+    var = (m2 - (mean * mean.conj()).real * (2.0 - (psum.real if torch.is_complex(psum) else psum))).to(vals[1].dtype)
+    if counts is None:
+        counts = float((red[3].real if torch.is_complex(red[3]) else red[3]).item())
+    sd = torch.sqrt(var.clamp_min(0))
+    return mean, var, sd, sd / counts**0.5
+
+
+class operator_statistics:
+    """utils/stats/mc_stats.py:19-54."""
+
+    def __init__(self, x: Tensor, prob: Tensor, counts: Optional[int] = None, operator: Optional[str] = None) -> None:
+        self.world_size = get_world_size()
+        self.operator = operator if operator is not None else "O"
+        mean, var, sd, se = dist_stats(x, prob, counts, self.world_size)
+        self.stats_dict = {"mean": mean, "var": var, "sd": sd, "se": se}
+
+    def __getitem__(self, key: str) -> Tensor:
+        return self.stats_dict[key]
+
+    def to_dict(self):
+        return self.stats_dict
+
+    def __repr__(self) -> str:
+        m, se, var = self["mean"], self["se"], self["var"]
+        return f"<{self.operator}> = {m.real:.9E} ± {se.real:.3E} [σ² = {var.real:.3E}]"

@@ -1,0 +1,148 @@
+"""pynqs_amd.energy (local_energy / total_energy / Func) on the GPU against outputs captured from the
+reference's own Python (vmc/energy/eloc.py run on its CPU extension; tests/golden/eloc_e2e_fe2s2.npz).
+Tolerance: 1e-8 Ha per determinant (the north-star bound); psi(x) to 1e-12 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def env(fe2s2):
+    from pynqs_amd import energy, public_function as pf
+    from pynqs_amd.rbm import RealRBM
+
+    assert torch.cuda.is_available()
+    d = golden("eloc_e2e_fe2s2.npz")
+    dev = torch.device("cuda")
+    f = fe2s2
+    e = {
+        "energy": energy, "pf": pf, "d": d, "dev": dev,
+        "h1e": torch.from_numpy(f["h1e"]).to(dev), "h2e": torch.from_numpy(f["h2e"]).to(dev),
+        "x": torch.from_numpy(d["x"]).to(dev),
+        "rbm": RealRBM(torch.from_numpy(d["W"]), torch.from_numpy(d["hb"]), torch.from_numpy(d["vb"])).to(dev).double(),
+    }
+    torch.set_default_dtype(torch.float64)
+    yield e
+    torch.set_default_dtype(torch.float32)
+
+
+def _ab(env, fp_batch=100000):
+    pf = env["pf"]
+    return lambda x, func: pf.ansatz_batch(func, x, fp_batch, 40, env["dev"], torch.double)
+
+
+def _le(env, **kw):
+    return env["energy"].local_energy(env["x"], env["h1e"], env["h2e"], env["rbm"], _ab(env), 40, 30, 15, 15, dtype=kw.pop("dtype", torch.double), **kw)
+
+
+def test_simple_matches_reference_python(env):
+    d = env["d"]
+    eloc, sloc, psi, times = _le(env, use_unique=True)
+    np.testing.assert_allclose(psi.cpu().numpy(), d["psi_simple"], rtol=1e-12)
+    np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_simple"], rtol=0, atol=TOL)
+    assert float(sloc.abs().max()) == 0.0 and len(times) == 3
+    e2, _, _, _ = _le(env, use_unique=False)
+    np.testing.assert_allclose(e2.cpu().numpy(), d["eloc_simple"], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_reduce_matches_reference_python(env, fused):
+    d, energy = env["d"], env["energy"]
+    old = energy.FUSED
+    energy.FUSED = fused
+    try:
+        eloc, _, psi, _ = _le(env, reduce_psi=True, eps=1e-2, eps_sample=0)
+        np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_reduce"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(psi.cpu().numpy(), d["psi_reduce"], rtol=1e-12)
+        # LUT-assisted (Func: hit/miss split + unique on the misses)
+        keys = torch.from_numpy(d["psi_lut_keys"][:512]).to(env["dev"])
+        lut = env["pf"].WavefunctionLUT(keys, torch.from_numpy(d["psi_lut"][:512]).to(env["dev"]), 40, device=env["dev"])
+        eloc, _, _, _ = _le(env, reduce_psi=True, eps=1e-2, eps_sample=0, WF_LUT=lut)
+        np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_reduce_lut"], rtol=0, atol=TOL)
+    finally:
+        energy.FUSED = old
+
+
+def test_reduce_compaction_is_exact(env):
+    """Kept columns from the on-chip compaction == |Hmat| >= eps of the materialised matrix, same order."""
+    from pynqs_amd import C_extension as cx
+
+    energy = env["energy"]
+    for eps in (1e-2, 0.0, 1e3):
+        row, col, onv, h, counts = energy.reduce_compact(env["x"], env["h1e"], env["h2e"], 40, 30, 15, 15, eps)
+        comb, hm = cx.get_comb_hij_fused(env["x"], env["h1e"], env["h2e"], 40, 30, 15, 15)
+        keep = hm.abs() >= eps
+        r2, c2 = torch.where(keep)
+        assert torch.equal(row, r2) and torch.equal(col.long(), c2)
+        assert torch.equal(h, hm[keep]) and torch.equal(onv, comb[keep])
+        assert torch.equal(counts, keep.sum(1))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_sample_space_matches_reference_python(env, fused, cplx):
+    d, energy = env["d"], env["energy"]
+    keys = torch.from_numpy(d["psi_lut_keys"]).to(env["dev"])
+    wf = torch.from_numpy(d["psi_lut_c" if cplx else "psi_lut"]).to(env["dev"])
+    lut = env["pf"].WavefunctionLUT(keys, wf, 40, device=env["dev"])
+    old = energy.FUSED
+    energy.FUSED = fused
+    try:
+        eloc, _, psi, _ = _le(env, WF_LUT=lut, use_sample_space=True, index=(0, 32), dtype=torch.complex128 if cplx else torch.double)
+    finally:
+        energy.FUSED = old
+    sfx = "_c" if cplx else ""
+    np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_sample_space" + sfx], rtol=0, atol=TOL)
+    np.testing.assert_allclose(psi.cpu().numpy(), d["psi_sample_space" + sfx], rtol=1e-14)
+
+
+def test_total_energy_chunks_and_statistics(env):
+    from pynqs_amd.stats import operator_statistics, dist_stats_onepass
+
+    d, energy = env["d"], env["energy"]
+    eloc, sloc, _ = energy.total_energy(env["x"], 5, 30000, env["h1e"], env["h2e"], env["rbm"], 40, 30, 15, 15, use_unique=True)
+    np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_simple"], rtol=0, atol=TOL)
+    prob = torch.from_numpy(d["prob"]).to(env["dev"])
+    ref = torch.from_numpy(d["eloc_simple"]).to(env["dev"])
+    st = operator_statistics(ref, prob, int(d["stat_counts"]), "E")
+    for k in ("mean", "var", "sd", "se"):
+        np.testing.assert_allclose(st[k].cpu().numpy(), d["stat_" + k], rtol=1e-13)
+    m, v, sd, se = dist_stats_onepass(ref, prob, int(d["stat_counts"]), 1)
+    np.testing.assert_allclose(m.cpu().numpy(), d["stat_mean"], rtol=1e-13)
+    np.testing.assert_allclose(v.cpu().numpy(), d["stat_var"], rtol=1e-8)
+    assert "<E> = " in repr(st)
+
+
+def test_spin_flip_and_multi_psi_paths_agree_with_plain_tensor_algebra(env):
+    """No reference capture exists for the projected forms; check them against a direct evaluation of
+    flip.py:120-139 built from the materialised comb/Hmat."""
+    from pynqs_amd import C_extension as cx
+
+    pf, energy = env["pf"], env["energy"]
+    pf.SpinProjection.init(30, 0)
+    x = env["x"][:6].contiguous()
+    ab = _ab(env)
+    en = torch.tensor(1.3, dtype=torch.float64, device=env["dev"])
+    eloc, _, psi, _ = energy.local_energy(x, env["h1e"], env["h2e"], env["rbm"], ab, 40, 30, 15, 15, use_spin_flip=True, extra_norm=en)
+    comb, hm = cx.get_comb_hij_fused(x, env["h1e"], env["h2e"], 40, 30, 15, 15)
+    flat = comb.reshape(-1, 8)
+    with torch.no_grad():
+        p = ab(flat, env["rbm"]).reshape(6, -1)
+        pfl = ab(pf.spin_flip_onv(flat, 40), env["rbm"]).reshape(6, -1)
+    eta_m = pf.spin_flip_sign(flat, 40).reshape(6, -1)
+    f_psi = (p + pf.SpinProjection.eta * eta_m * pfl) / en**2
+    want = ((f_psi.T / p[:, 0]).T * hm).sum(-1)
+    np.testing.assert_allclose(eloc.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-10)
+    # uint8 and +-1 forms of the spin-flip helpers agree
+    pm = cx.onv_to_tensor(flat[:500].contiguous(), 40)
+    assert torch.equal(pf.spin_flip_sign(flat[:500], 40), pf.spin_flip_sign(((pm + 1) / 2).to(torch.int64), 40))
+    assert torch.equal(cx.onv_to_tensor(pf.spin_flip_onv(flat[:500], 40).contiguous(), 40), pf.spin_flip_onv(pm, 40))
+    # REDUCE + spin flip == SIMPLE + spin flip when nothing is filtered (eps = 0)
+    e2, _, _, _ = energy.local_energy(x, env["h1e"], env["h2e"], env["rbm"], ab, 40, 30, 15, 15, use_spin_flip=True, extra_norm=en,
+                                      reduce_psi=True, eps=0.0)
+    np.testing.assert_allclose(e2.cpu().numpy(), eloc.cpu().numpy(), rtol=0, atol=1e-10)
