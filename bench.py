@@ -185,7 +185,94 @@ class DropinFused(Workload):
                 "sample": f"{reps} x get_comb_hij_fused on the first {sample} walkers of the same batch ({el:.1f} s)"}
 
 
+class SampleSpaceFused(Workload):
+    """Complete local energies, SAMPLE_SPACE method (vmc/energy/eloc.py:326-401), in ONE kernel: enumerate,
+    <x|H|x'>, psi(x') from the sorted sample table, contraction.  Nothing is materialised.  psi is complex128
+    like the Fe2S2 example's BDG-RNN amplitudes (synthetic, seeded)."""
+
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev):
+        from pynqs_amd import _native as N
+        from pynqs_amd import public_function as pf
+
+        self.N, self.lib = N, N.lib()
+        self.name = f"{tag}_eloc_sample_space"
+        self.sorb, self.nele, self.noA, self.noB = sorb, nele, noA, noB
+        self.h1, self.h2, self.x = h1.to(dev), h2.to(dev), walkers.to(dev).contiguous()
+        self.n = self.x.size(0)
+        dropin, self.ncomb = algorithmic_bytes_dropin(sorb, nele, noA, noB)
+        L = (sorb - 1) // 64 + 1
+        # SURVEY.md 8(d) B_fused: integral gathers + walker in + E_loc out (complex128)
+        self.bytes_per_walker = dropin - self.ncomb * (8 + 8 * L) + 16
+        g = torch.Generator().manual_seed(7)
+        nk = keys.size(0)
+        amp = torch.exp(-3.0 * torch.rand(nk, generator=g, dtype=torch.float64))
+        ph = 2 * np.pi * torch.rand(nk, generator=g, dtype=torch.float64)
+        wf = torch.polar(amp, ph)
+        self.lut = pf.WavefunctionLUT(keys.to(dev), wf.to(dev), sorb, device=dev)
+        nb = self.lib.pynqs_plan_bytes(sorb, N.PYNQS_F64)
+        self.plan = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream(dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        N.check(self.lib.pynqs_plan_build(self.h1.data_ptr(), self.h2.data_ptr(), sorb, N.PYNQS_F64, self.plan.data_ptr(), st.cuda_stream),
+                "plan_build")
+        e1.record(st); e1.synchronize()
+        self.plan_build_ms = e0.elapsed_time(e1)
+        self.eloc = torch.empty(self.n, dtype=torch.complex128, device=dev)
+        self.psi0 = torch.empty(self.n, dtype=torch.complex128, device=dev)
+        self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
+        self.dev, self.path, self.kernel = dev, "plan", "eloc_sample_space_kernel"
+        self.stats = None
+
+    def step(self):
+        st = torch.cuda.current_stream(self.dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        rc = self.lib.pynqs_eloc_sample_space(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB, self.plan.data_ptr(),
+                                              self.lut.bra_key.data_ptr(), self.lut.bra_key.size(0), self.lut.wf_value.data_ptr(), 1,
+                                              self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
+        e1.record(st)
+        self.N.check(rc, "pynqs_eloc_sample_space")
+        # <E_loc>, variance: one packed all-reduce over the ranks (RCCL), no barrier
+        from pynqs_amd.stats import dist_stats_onepass
+        from pynqs_amd.distributed import get_world_size
+
+        self.stats = dist_stats_onepass(self.eloc, self.prob, None, get_world_size())
+        return e0, e1
+
+    def parity_gate(self):
+        from oracle import oracle as O
+
+        m = min(self.n, 8)
+        e, p0 = O.eloc_sample_space(self.x[:m].cpu().numpy(), self.h1.cpu().numpy(), self.h2.cpu().numpy(), self.sorb, self.nele,
+                                    self.noA, self.noB, self.lut.bra_key.cpu().numpy(), self.lut.wf_value.cpu().numpy())
+        de = float(np.abs(self.eloc[:m].cpu().numpy() - e).max())
+        return bool(np.array_equal(self.psi0[:m].cpu().numpy(), p0)), de
+
+    def cpu_baseline(self, budget_s=15.0):
+        from oracle import oracle as O
+
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        x = self.x.cpu().numpy(); h1 = self.h1.cpu().numpy(); h2 = self.h2.cpu().numpy()
+        keys = self.lut.bra_key.cpu().numpy(); wf = self.lut.wf_value.cpu().numpy()
+        fn = lambda m: O.eloc_sample_space(x[:m], h1, h2, self.sorb, self.nele, self.noA, self.noB, keys, wf, nthreads=cores)
+        fn(min(self.n, 64))  # warm the thread pool
+        sample = min(self.n, 4096)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s * 0.8 and reps < 200:
+            fn(sample); reps += 1
+        el = time.perf_counter() - t0
+        return {"value": sample * reps / el, "unit": "local energies/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x oracle eloc_sample_space (C restatement, OpenMP) on the first {sample} walkers of the same batch ({el:.1f} s)"}
+
+
 def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -> Workload:
+    if name == "fe2s2_eloc_sample_space":
+        d = load_fe2s2()
+        ci = d["ci_space"]
+        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        return SampleSpaceFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
+                                torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), torch.from_numpy(ci.copy()), dev)
     if name == "fe2s2_dropin":
         d = load_fe2s2()
         ci = d["ci_space"]
@@ -211,6 +298,7 @@ def main():
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
     ap.add_argument("--no-comb", action="store_true", help="diagnostic: skip the comb output (Hmat only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'extra'")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -238,32 +326,37 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        wl.step()
-    barrier()
-    t0 = time.perf_counter()
-    events = [wl.step() for _ in range(args.steps)]
-    barrier()
-    el = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+    def timed(w, warmup, steps):
+        for _ in range(warmup):
+            w.step()
+        barrier()
+        t0 = time.perf_counter()
+        events = [w.step() for _ in range(steps)]
+        barrier()
+        el = time.perf_counter() - t0
+        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, len(events))
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), kern_ms
 
-    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    el = float(tmax.item())
+    def roofline(w, kern_ms):
+        ach = w.bytes_per_walker * w.n / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_{w.name}.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        return {"bound": "hbm", "kernel": w.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": w.bytes_per_walker * w.n}
+
+    el, kern_ms = timed(wl, args.warmup, args.steps)
 
     if rank == 0:
         ok_c, dh = wl.parity_gate()
         total_walkers = wl.n * world * args.steps
-        value = total_walkers / el
-        ach = wl.bytes_per_walker * wl.n / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"pmc_{wl.name}.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         out = {
             "metric": "local energies/sec (whole node)",
-            "value": value,
+            "value": total_walkers / el,
             "unit": "local energies/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -276,14 +369,32 @@ def main():
             "data": "shipped Fe2S2 integrals + ci_space walkers (tests/golden fixture)" if args.workload.startswith("fe2s2")
                     else "synthetic (seeded dense integrals, random walkers)",
             "config": {"workload": wl.name, "sorb": wl.sorb, "nele": wl.nele, "ncomb": wl.ncomb,
-                       "walkers_per_gpu": wl.n, "integral_layout": wl.path, "plan_build_ms": wl.plan_build_ms, "parallelism": f"walker-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": wl.bytes_per_walker * wl.n},
-            "parity": {"comb_bit_exact": bool(ok_c), "max_abs_dH_vs_oracle": dh},
+                       "walkers_per_gpu": wl.n, "integral_layout": wl.path, "plan_build_ms": wl.plan_build_ms,
+                       "parallelism": f"walker-sharded x{world}" + (", packed RCCL all-reduce of <E_loc>, <|E_loc|^2>" if hasattr(wl, "stats") else ", no data-path collective")},
+            "roofline": roofline(wl, kern_ms),
+            "parity": {"exact_part_bit_exact": bool(ok_c), "max_abs_diff_vs_oracle": dh},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
+    # secondary measurements (same run, N = 1 only): the complete fused local energy and the larger word counts
+    if world == 1 and not args.no_extra and args.workload == "fe2s2_dropin":
+        extra = {}
+        for name, nw, steps in (("fe2s2_eloc_sample_space", args.walkers, 20), ("syn120_dropin", 64, 10), ("syn184_dropin", 16, 5)):
+            try:
+                w2 = make_workload(name, nw, rank, dev, args.path)
+                el2, k2 = timed(w2, 2, steps)
+                ok2, d2 = w2.parity_gate()
+                extra[w2.name] = {"value": w2.n * steps / el2, "unit": "local energies/s", "walkers": w2.n, "ncomb": w2.ncomb,
+                                  "ms_per_step": el2 / steps * 1e3, "roofline": roofline(w2, k2),
+                                  "parity": {"exact_part_bit_exact": bool(ok2), "max_abs_diff_vs_oracle": d2}}
+                if name == "fe2s2_eloc_sample_space" and not args.no_cpu_baseline:
+                    extra[w2.name]["cpu_baseline"] = w2.cpu_baseline(budget_s=8.0)
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as e:  # pragma: no cover  (keeps the primary line intact)
+                extra[name] = {"error": repr(e)}
+        out["extra"] = extra
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier(device_ids=[local_rank])

@@ -30,7 +30,7 @@ USE_PLAN = True  # route get_comb_hij_fused through the cached integral plan (Fa
 
 __all__ = [
     "tensor_to_onv", "onv_to_tensor", "get_comb_tensor", "get_hij_torch", "get_comb_hij_fused",
-    "wavefunction_lut", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
+    "wavefunction_lut", "merge_rank_sample", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
     "MAX_SORB", "MAX_SORB_LEN", "MAX_NELE",
 ]
 
@@ -268,6 +268,15 @@ def wavefunction_lut(bra_key: Tensor, onv: Tensor, sorb: int, little_endian: boo
     N.check(N.lib().pynqs_wavefunction_lut(k.data_ptr(), k.size(0), q.data_ptr(), n, sorb, idx.data_ptr(), mask.data_ptr(),
                                            _stream(dev)), "wavefunction_lut")
     return (idx.cpu(), mask.cpu()) if any_cpu else (idx, mask)
+
+
+def merge_rank_sample(idx: Tensor, counts: Tensor, split_idx: Tensor, length: int) -> Tensor:
+    """bind.cpp:190-201 -> cpu_tensor.cpp:537-556: merge_counts[idx[i]] += counts[i] (int64[length]); used
+    after the cross-rank torch.unique in vmc/sample.py:675-685.  `split_idx` only steers the reference's
+    race-avoiding launch schedule (cuda_tensor.cpp:403-411) and is ignored: index_add_ is atomic."""
+    _contig(idx, "idx"); _contig(counts, "counts")
+    out = torch.zeros(int(length), dtype=torch.int64, device=idx.device)
+    return out.index_add_(0, idx.to(torch.int64), counts.to(torch.int64))
 
 
 # ---- integral layout (host side, numpy in / numpy out like cpp_src/tensor/integral.cpp) -----------------

@@ -67,7 +67,7 @@ def all_reduce_packed(values: Sequence[Tensor], world_size: int = 1) -> List[Ten
     for v, p, c in zip(values, parts, is_c):
         seg = buf[o:o + p.numel()]
         o += p.numel()
-        seg = torch.view_as_complex(seg.reshape(-1, 2)) if c else seg
+        seg = torch.complex(seg[0::2], seg[1::2]) if c else seg
         out.append(seg.reshape(v.shape).to(v.dtype))
     return out
 

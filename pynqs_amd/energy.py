@@ -124,8 +124,18 @@ def _reduce_select(comb_hij: Tensor, eps: float, eps_sample: int) -> Tensor:
     return index1 if index is None else torch.cat([index, index1])
 
 
-def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip) -> bool:
-    return (FUSED and WF_LUT is not None and WF_LUT.sort and not (use_spin_raising or use_multi_psi or use_spin_flip)
+def _fused_lds_ok(sorb: int, noa: int, nob: int, elem: int = 8) -> bool:
+    """The fused E_loc kernels stage all singles' matrix elements in LDS (<= 64 KiB static limit)."""
+    k = sorb // 2
+    nva, nvb = k - noa, k - nob
+    d1 = noa * nva + nob * nvb
+    tab = d1 + noa * (noa - 1) // 2 + nva * (nva - 1) // 2 + nob * (nob - 1) // 2 + nvb * (nvb - 1) // 2
+    fixed = (tab * 4 + 3 * 192 + 7) // 8 * 8
+    return fixed + 2048 * elem + (d1 + 2) * elem <= 64 * 1024
+
+
+def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa=0, nob=0) -> bool:
+    return (FUSED and _fused_lds_ok(sorb, noa, nob) and WF_LUT is not None and WF_LUT.sort and not (use_spin_raising or use_multi_psi or use_spin_flip)
             and sorb % 2 == 0 and h1e.dtype == torch.float64 and WF_LUT.dtype in (torch.float64, torch.complex128)
             and x.is_cuda and WF_LUT.bra_key.is_cuda)
 
@@ -192,7 +202,7 @@ def local_energy(
         t0 = time.time_ns()
 
         # ---- fast path: SAMPLE_SPACE in one kernel ----------------------------------------------------
-        if use_sample_space and _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip):
+        if use_sample_space and _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa, nob):
             eloc, psi0 = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT)
             t1 = time.time_ns()
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
@@ -206,7 +216,7 @@ def local_energy(
 
         # ---- fast path: REDUCE (deterministic) with on-chip compaction -----------------------------------
         if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and not (use_spin_raising or use_multi_psi or use_spin_flip)
-                and sorb % 2 == 0 and x.is_cuda):
+                and sorb % 2 == 0 and x.is_cuda and _fused_lds_ok(sorb, noa, nob, h1e.element_size())):
             row, col, onv, h, counts = reduce_compact(x, h1e, h2e, sorb, nele, noa, nob, eps)
             t2 = time.time_ns()
             psi = Func(ansatz_f, onv, WF_LUT, use_unique).to(dtype)

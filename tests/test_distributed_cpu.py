@@ -1,0 +1,103 @@
+"""world_size-2 gloo tests (CPU): walker sharding, packed all-reduce statistics and the DDP gradient
+estimator give the same numbers as the single-process evaluation."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pynqs_amd import distributed as D, grad as G, stats as S
+        from pynqs_amd.rbm import RealRBM
+
+        d = golden("eloc_e2e_fe2s2.npz")
+        eloc = torch.from_numpy(d["eloc_simple"])
+        prob = torch.from_numpy(d["prob"])
+        b, e = D.shard_bounds(eloc.numel(), world, rank)
+        # probabilities pre-scaled by world_size, as vmc/sample.py:772
+        x, p = eloc[b:e], prob[b:e] * world
+        st = S.operator_statistics(x, p, int(d["stat_counts"]), "E")
+        one = S.dist_stats_onepass(x, p, int(d["stat_counts"]), world)
+        packed = D.all_reduce_packed([x.sum(), torch.complex(x[:2], x[:2] * 2)], world)
+        # gradient estimator under DDP: micro-batches, last one synchronises
+        torch.manual_seed(0)
+        g = torch.Generator().manual_seed(3)
+        model = RealRBM(0.05 * torch.rand(6, 8, generator=g, dtype=torch.float64), 0.05 * torch.rand(6, generator=g, dtype=torch.float64),
+                        0.05 * torch.rand(8, generator=g, dtype=torch.float64))
+        ddp = torch.nn.parallel.DistributedDataParallel(model)
+        states = (torch.rand(10, 8, generator=torch.Generator().manual_seed(11), dtype=torch.float64) > 0.5).double() * 2 - 1
+        el = torch.rand(10, generator=torch.Generator().manual_seed(12), dtype=torch.float64)
+        pr = torch.full((10,), 0.1, dtype=torch.float64)
+        sb, se = D.shard_bounds(10, world, rank)
+        loss = G.grad(ddp, states[sb:se], pr[sb:se] * world, el[sb:se], float((el * pr).sum()), 1.0, torch.double, AD_MAX_DIM=2)
+        grads = [p_.grad.clone() for p_ in model.parameters()]
+        q.put((rank, {k: st[k].item() for k in ("mean", "var", "sd", "se")}, [t.item() for t in one], packed[0].item(),
+               packed[1].tolist(), [g_.numpy() for g_ in grads], loss.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_two_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _q
+
+    out = []
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=5))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: see its traceback above"
+    out.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    d = golden("eloc_e2e_fe2s2.npz")
+    for rank, st, one, s, c, grads, loss in out:
+        for k in ("mean", "var", "sd", "se"):
+            np.testing.assert_allclose(st[k], d["stat_" + k], rtol=1e-12)
+        np.testing.assert_allclose(one[0], d["stat_mean"], rtol=1e-12)
+        np.testing.assert_allclose(one[1], d["stat_var"], rtol=1e-7)
+        np.testing.assert_allclose(s, d["eloc_simple"].sum() / world, rtol=1e-12)  # SUM then / world_size
+    # both ranks hold the same (all-reduced) gradient == single-process gradient
+    from pynqs_amd import grad as G
+    from pynqs_amd.rbm import RealRBM
+
+    g = torch.Generator().manual_seed(3)
+    model = RealRBM(0.05 * torch.rand(6, 8, generator=g, dtype=torch.float64), 0.05 * torch.rand(6, generator=g, dtype=torch.float64),
+                    0.05 * torch.rand(8, generator=g, dtype=torch.float64))
+    states = (torch.rand(10, 8, generator=torch.Generator().manual_seed(11), dtype=torch.float64) > 0.5).double() * 2 - 1
+    el = torch.rand(10, generator=torch.Generator().manual_seed(12), dtype=torch.float64)
+    pr = torch.full((10,), 0.1, dtype=torch.float64)
+    G.grad(model, states, pr, el, float((el * pr).sum()), 1.0, torch.double, AD_MAX_DIM=3)
+    ref = [p_.grad.numpy() for p_ in model.parameters()]
+    for a, b in zip(out[0][5], out[1][5]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-15)
+    for a, r in zip(out[0][5], ref):
+        np.testing.assert_allclose(a, r, rtol=1e-10, atol=1e-14)
+
+
+def test_shard_bounds():
+    from pynqs_amd.distributed import shard_bounds
+
+    parts = [shard_bounds(11, 3, r) for r in range(3)]
+    assert parts == [(0, 4), (4, 8), (8, 11)]  # first n % ws ranks get one more (comm.py:108-111)
+    assert [shard_bounds(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]

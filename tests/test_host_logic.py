@@ -1,0 +1,110 @@
+"""CPU-only checks: the C ABI library loads and exports every symbol include/pynqs_amd.h declares, host-side
+entry points (no GPU needed) behave like the reference, and the product refuses to compute without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden, synth_integrals
+from oracle import oracle as O
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pynqs_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pynqs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from pynqs_amd import _native
+
+    syms = _declared_symbols()
+    assert len(syms) >= 16
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/pynqs_amd.h but not exported"
+    assert sorted(_native.SIGNATURES) == syms, "pynqs_amd/_native.py must bind exactly the declared ABI"
+    assert _native.lib().pynqs_abi_version() == 1
+
+
+def test_host_entry_points():
+    from pynqs_amd import C_extension as cx
+    from pynqs_amd import _native as N
+
+    # get_Num_SinglesDoubles: SURVEY.md 8 table
+    for (sorb, a, b, want) in [(8, 2, 2, 26), (56, 7, 7, 30723), (40, 15, 15, 7875), (120, 30, 30, 1190250), (184, 46, 46, 6624138)]:
+        assert cx.get_Num_SinglesDoubles(sorb, a, b) == want == O.num_sd(sorb, a, b)
+    cx.check_sorb(40, 30); cx.check_sorb(192, 120); cx.check_sorb(56, 14)
+    with pytest.raises(ValueError):
+        cx.check_sorb(193, 4)
+    with pytest.raises(OverflowError):
+        cx.check_sorb(130, 121)
+    with pytest.raises(OverflowError):
+        cx.check_sorb(190, 60)  # 130 virtual orbitals
+    assert (cx.MAX_SORB, cx.MAX_SORB_LEN, cx.MAX_NELE) == (192, 3, 120)
+    assert N.lib().pynqs_plan_bytes(40, N.PYNQS_F64) == 8 * (20**4 + 2 * 190**2 + 2 * 400 * 40 + 800 + 1600 + 40)
+    assert N.lib().pynqs_plan_bytes(41, N.PYNQS_F64) == -1
+
+
+def test_integral_layout_matches_oracle():
+    from pynqs_amd import C_extension as cx
+
+    sorb = 8
+    h1, h2 = synth_integrals(sorb)
+    a, b = cx.decompress_h1e_h2e(h1, h2, sorb)
+    ao, bo = O.decompress_h1e_h2e(h1, h2, sorb)
+    assert np.array_equal(a, ao) and np.array_equal(b, bo)
+    c, e = cx.compress_h1e_h2e(a, b, sorb)
+    assert np.array_equal(c, h1) and np.array_equal(e, h2)
+    # non-antisymmetric input: the last writer of a slot wins, as in integral.cpp:45-53
+    g = np.random.default_rng(5).standard_normal((sorb,) * 4)
+    c1, e1 = cx.compress_h1e_h2e(a, g, sorb)
+    c2, e2 = O.compress_h1e_h2e(a, g, sorb)
+    assert np.array_equal(e1, e2)
+    with pytest.raises(ValueError):
+        cx.decompress_h1e_h2e(h1[:-1], h2, sorb)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device every compute entry point raises instead of silently computing on the host."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pynqs_amd import C_extension as cx
+
+    x = torch.zeros((2, 8), dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        cx.onv_to_tensor(x, 40)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        cx.get_comb_tensor(x, 40, 30, 15, 15)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pynqs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle's", "").replace("the oracle", "").lower() or f == "build.py", f
+
+
+def test_split_helpers_and_sorting():
+    from pynqs_amd import public_function as pf
+
+    assert pf.split_batch_idx(11, 3) == [3, 6, 9, 11]      # utils/public_function.py docstring
+    assert pf.split_length_idx(11, 3) == [4, 8, 11]
+    d = golden("wavefunction_lut.npz")
+    for sorb in (40, 100, 184):
+        keys = torch.from_numpy(d[f"s{sorb}_keys"])
+        perm = torch.randperm(keys.size(0), generator=torch.Generator().manual_seed(1))
+        idx = pf.torch_sort_onv(keys[perm])
+        assert torch.equal(keys[perm][idx], keys)
+    bra = torch.tensor([[3, 0, 0, 0, 0, 0, 0, 0], [12, 0, 0, 0, 0, 0, 0, 0], [9, 0, 0, 0, 0, 0, 0, 0], [6, 0, 0, 0, 0, 0, 0, 0]],
+                       dtype=torch.uint8)
+    assert pf.torch_sort_onv(bra).tolist() == [0, 3, 2, 1]
+    # spin-flip helpers, uint8 form vs occupation form
+    occ = torch.tensor([[1, 1, 0, 1, 1, 0, 1, 1], [1, 0, 0, 1, 1, 1, 0, 0]], dtype=torch.int64)
+    byte = torch.tensor([[0b11011011, 0, 0, 0, 0, 0, 0, 0], [0b00111001, 0, 0, 0, 0, 0, 0, 0]], dtype=torch.uint8)
+    assert pf.spin_flip_sign(byte, 8).tolist() == pf.spin_flip_sign(occ, 8).tolist() == [1, -1]
+    assert pf.spin_flip_onv(byte, 8)[:, 0].tolist() == [0b11100111, 0b00110110]
