@@ -202,13 +202,6 @@ __global__ __launch_bounds__(kBlock) void lut_search_kernel(const uint64_t *__re
 // =================================================================================================
 using namespace pynqs;
 
-#define DISPATCH_LEN(len, ...)                                  \
-  switch (len) {                                                \
-    case 1: { constexpr int LEN = 1; __VA_ARGS__; } break;      \
-    case 2: { constexpr int LEN = 2; __VA_ARGS__; } break;      \
-    default: { constexpr int LEN = 3; __VA_ARGS__; } break;     \
-  }
-
 template <int LEN, typename T>
 static int launch_comb_hij(const uint64_t *bra, int64_t nbatch, const SDParams &p, const T *h1e, const T *h2e,
                            uint64_t *comb, T *hmat, hipStream_t st) {

@@ -8,113 +8,17 @@
 #include "detcore.h"
 #include "launch.h"
 #include "plan.h"
+#include "plan_dev.h"
 
 namespace pynqs {
 
-// One excitation of the walker: column k = rank + 1, value, ket.
-template <int LEN, typename T>
-struct Item {
-  uint64_t ket[LEN];
-  T h;
-};
-
-// Visits every column of the block's range in a fixed schedule: `rounds` of kBlock consecutive columns,
-// lane `tid` of round i handles column lo + i*kBlock + tid.  f(col, valid, h, ket) is called by ALL lanes
-// every round (valid == false past the end) so that f may use barriers and wave-wide operations.
-// Singles and the diagonal need the workgroup-cooperative phases of kernels_plan.hip; here they are computed
-// first into LDS (`hs` = one T per column < first_double) and replayed from there.
-template <int LEN, typename T>
-__device__ __forceinline__ T double_element(uint32_t r, const SDParams &p, const PlanLayout &pl, const LdsLayout &L,
-                                            const T *__restrict__ plan, const Walker<LEN> &wk, uint64_t (&ket)[LEN]) {
-  const uint32_t K = (uint32_t)pl.K, NP = (uint32_t)pl.NP;
-  int a, b, c, d;
-  T v;
-  uint32_t par;
-  if (r < p.d3) {
-    const bool beta = r >= p.d2;
-    const uint32_t t = r - (beta ? p.d2 : p.d1);
-    const uint32_t npair = beta ? p.noBB : p.noAA;
-    const uint32_t ab = mdiv(t, beta ? p.divNoBB : p.divNoAA);
-    uint32_t ij = t - ab * npair + (beta ? p.rotB : p.rotA);
-    ij = ij >= npair ? ij - npair : ij;
-    const uint32_t eh = L.tab[(beta ? p.offHPb : p.offHPa) + ij];
-    const uint32_t ep = L.tab[(beta ? p.offPPb : p.offPPa) + ab];
-    v = plan[pl.offVss + (size_t)(beta ? 1 : 0) * NP * NP + __umul24((ep >> 17) & 0x1fffu, NP) + ((eh >> 17) & 0x1fffu)];
-    a = eh & 0xff; b = (eh >> 8) & 0xff; c = ep & 0xff; d = (ep >> 8) & 0xff;
-    par = (((eh ^ ep) >> 16) & 1u) ^ (uint32_t)(a < c) ^ (uint32_t)(b < c) ^ (uint32_t)(a < d) ^ (uint32_t)(b < d);
-  } else {
-    const uint32_t t = r - p.d3;
-    const uint32_t jb = mdiv(t, p.divNSa);
-    const uint32_t ia = t - jb * (uint32_t)p.nSa;
-    const uint32_t ea = L.tab[p.offSa + ia], eb = L.tab[p.offSb + jb];
-    v = plan[pl.offVab + (size_t)__umul24(eb >> 17, K * K) + (ea >> 17)];
-    a = ea & 0xff; c = (ea >> 8) & 0xff; b = eb & 0xff; d = (eb >> 8) & 0xff;
-    par = (((ea ^ eb) >> 16) & 1u) ^ (uint32_t)(a < d) ^ (uint32_t)(b < c) ^ 1u;
-  }
-#pragma unroll
-  for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
-  toggle<LEN>(ket, a); toggle<LEN>(ket, b); toggle<LEN>(ket, c); toggle<LEN>(ket, d);
-  return par ? -v : v;
-}
-
-// Computes <x|H|x'> of the singles [0, d1) and of the diagonal into LDS: hs[0] = <x|H|x>, hs[1 + r] = single r.
-// Same arithmetic as comb_hij_plan_kernel.  `hs` must hold 1 + d1 values; uses L.scratch as staging.
+// <x|H|x'> of the singles [0, d1) and of the diagonal into LDS: hs[0] = <x|H|x>, hs[1 + r] = single r
+// (same arithmetic as comb_hij_plan_kernel: plan_dev.h).  `hs` holds 1 + d1 values.
 template <int LEN, typename T>
 __device__ __forceinline__ void singles_and_diag_to_lds(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                                         const T *__restrict__ plan, T *__restrict__ hs) {
-  const int tid = threadIdx.x;
-  const uint32_t K = (uint32_t)pl.K;
-  T *tile = reinterpret_cast<T *>(L.scratch);
-  const int stride = nocc | 1;
-  const int per_tile = max(1, min(kBlock, kDiagTile / stride));
-  const int wave = tid >> 6, lane = tid & 63;
-  const T *__restrict__ S2 = plan + pl.offS2;
-  const T *__restrict__ S1 = plan + pl.offS1;
-  for (uint32_t t0 = 0; t0 < p.d1; t0 += per_tile) {
-    const int cnt = (int)min((uint32_t)per_tile, p.d1 - t0);
-    __syncthreads();
-    for (int sl = wave; sl < cnt; sl += kBlock / 64) {
-      const uint32_t r = t0 + sl;
-      const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-      const uint32_t spin = r >= p.d0;
-      const uint32_t hm = (e & 0xff) >> 1, qm = ((e >> 8) & 0xff) >> 1;
-      const T *__restrict__ rowp = S2 + ((size_t)(spin * K + hm) * K + qm) * p.sorb;
-      for (int j = lane; j < nocc; j += 64) tile[sl * stride + j] = rowp[L.occv[j]];
-    }
-    __syncthreads();
-    if (tid < cnt) {
-      const uint32_t r = t0 + tid;
-      const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-      const uint32_t spin = r >= p.d0;
-      const int h = e & 0xff, q = (e >> 8) & 0xff;
-      T acc = T(0);
-      acc += S1[(size_t)(spin * K + (h >> 1)) * K + (q >> 1)];
-      const T *__restrict__ mine = tile + tid * stride;
-      for (int j = 0; j < nocc; ++j) acc += mine[j];
-      hs[1 + r] = ((e >> 16) & 1u) ? -acc : acc;
-    }
-  }
-  // diagonal (hamiltonian.cpp:41-48 order)
-  const T *__restrict__ D1 = plan + pl.offD1;
-  const T *__restrict__ D2 = plan + pl.offD2;
-  const int nele = p.nele, nterms = nele * (nele + 1) / 2;
-  T acc = T(0);
-  for (int base = 0; base < nterms; base += kDiagTile) {
-    const int end = min(base + kDiagTile, nterms);
-    __syncthreads();
-    for (int t = base + tid; t < end; t += kBlock) {
-      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > t) --a;
-      while ((a + 1) * (a + 2) / 2 <= t) ++a;
-      const int pos = t - a * (a + 1) / 2;
-      const int pa = L.occa[a];
-      tile[t - base] = pos == 0 ? D1[pa] : D2[pa * p.sorb + L.occa[pos - 1]];
-    }
-    __syncthreads();
-    if (tid == kBlock - 1)
-      for (int t = 0; t < end - base; ++t) acc += tile[t];
-  }
-  if (tid == kBlock - 1) hs[0] = acc;
+  singles_phase<T>(p, pl, L, nocc, plan, 0u, p.d1, [&](uint32_t r, T v, int, int) { hs[1 + r] = v; });
+  diag_phase_plan<T>(p, pl, L, plan, [&](T v) { hs[0] = v; });
   __syncthreads();
 }
 
@@ -285,13 +189,6 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const uint64_t *__restri
 
 // =================================================================================================
 using namespace pynqs;
-
-#define DISPATCH_LEN(len, ...)                                  \
-  switch (len) {                                                \
-    case 1: { constexpr int LEN = 1; __VA_ARGS__; } break;      \
-    case 2: { constexpr int LEN = 2; __VA_ARGS__; } break;      \
-    default: { constexpr int LEN = 3; __VA_ARGS__; } break;     \
-  }
 
 static int eloc_common_checks(int sorb, int nele, int noA, int noB, int64_t nbatch, SDParams *p, PlanLayout *pl) {
   if (!make_sd_params(sorb, nele, noA, noB, p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");

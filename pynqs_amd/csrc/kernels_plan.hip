@@ -3,11 +3,15 @@
 // (cpp_src/cpu/excitation.cpp:125-169, hamiltonian.cpp:34-50); what changes is where the bytes live:
 //   * doubles read one element of the dense spin-blocked tables whose fast index follows the lanes;
 //   * singles gather their nele+1 terms with lanes over the occupied orbitals (one contiguous table row
-//     per single), stage them in LDS and add them in the reference's order;
-//   * each excitation class has its own loop, so class parameters are scalar and no lane diverges.
+//     per single), stage them in LDS and add them in the reference's order (plan_dev.h);
+//   * each excitation class has its own loop, so class parameters are scalar and no lane diverges;
+//   * a lane produces TWO consecutive columns and writes them with 16-byte stores: the vector-memory
+//     pipeline (TA/TD busy 67-83 % in profiles/r01_fe2s2_dropin_v3_plan_pmc_deep.txt) is paid per
+//     instruction, so half as many store instructions move the same bytes.
 #include "detcore.h"
 #include "launch.h"
 #include "plan.h"
+#include "plan_dev.h"
 
 namespace pynqs {
 
@@ -63,23 +67,19 @@ __global__ __launch_bounds__(kBlock) void plan_build_kernel(const T *__restrict_
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int LEN>
-__device__ __forceinline__ void ket_from(const Walker<LEN> &wk, int a, int b, int c, int d, bool four, uint64_t (&ket)[LEN]) {
-#pragma unroll
-  for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
-  toggle<LEN>(ket, a);
-  toggle<LEN>(ket, b);
-  if (four) {
-    toggle<LEN>(ket, c);
-    toggle<LEN>(ket, d);
-  }
-}
+// Output stores relative to the walker's (wave-uniform) row pointers, with a 32-bit lane offset:
+// a row is < 2^32 bytes (ncomb < 2^24, <= 24 B per ket).
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
-// Output stores with a 32-bit lane offset on top of the walker's (wave-uniform) row pointer: one shift
-// instead of 64-bit address arithmetic per lane.  A row is < 2^32 bytes (ncomb < 2^24, <= 24 B per ket).
 template <typename T>
 __device__ __forceinline__ void store_h(T *__restrict__ hrow, uint32_t col, T v) {
   *reinterpret_cast<T *>(reinterpret_cast<char *>(hrow) + (size_t)(col * (uint32_t)sizeof(T))) = v;
+}
+template <typename T>
+__device__ __forceinline__ void store_h2(T *__restrict__ hrow, uint32_t col, T v0, T v1) {
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  T2 v = {v0, v1};
+  *reinterpret_cast<T2 *>(reinterpret_cast<char *>(hrow) + (size_t)(col * (uint32_t)sizeof(T))) = v;
 }
 template <int LEN>
 __device__ __forceinline__ void store_ket(uint64_t *__restrict__ crow, uint32_t col, const uint64_t (&ket)[LEN]) {
@@ -87,32 +87,73 @@ __device__ __forceinline__ void store_ket(uint64_t *__restrict__ crow, uint32_t 
 #pragma unroll
   for (int i = 0; i < LEN; ++i) dst[i] = ket[i];
 }
+// two consecutive kets = 2*LEN words = LEN 16-byte stores; (row base + col) is even, so the address is
+// 16-byte aligned for every LEN
+template <int LEN>
+__device__ __forceinline__ void store_ket2(uint64_t *__restrict__ crow, uint32_t col, const uint64_t (&k0)[LEN],
+                                           const uint64_t (&k1)[LEN]) {
+  u64x2 *dst = reinterpret_cast<u64x2 *>(reinterpret_cast<char *>(crow) + (size_t)(col * (uint32_t)(8 * LEN)));
+  uint64_t w[2 * LEN];
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) { w[i] = k0[i]; w[LEN + i] = k1[i]; }
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) { u64x2 v = {w[2 * i], w[2 * i + 1]}; dst[i] = v; }
+}
 
-// Diagonal element from the plan's D1/D2 (same order of additions as hamiltonian.cpp:41-48).
-template <typename T>
-__device__ __forceinline__ void diag_phase_plan(const SDParams &p, const LdsLayout &L, const T *__restrict__ D1,
-                                                const T *__restrict__ D2, T *__restrict__ out) {
-  T *tile = reinterpret_cast<T *>(L.scratch);
+#ifndef PYNQS_U
+#define PYNQS_U 2
+#endif
+
+// Columns [a0+1, a1+1) of one excitation class, two consecutive ranks per lane.  `odd_base` = parity of the
+// walker's first element index (walker * ncomb): pairs start where (walker*ncomb + col) is even so that the
+// 16-byte stores are aligned; the possible leading element and a trailing one use 8-byte stores.
+template <int LEN, typename T, bool WRITE_COMB, typename Fetch, typename Finish>
+__device__ __forceinline__ void paired_class_loop(uint32_t a0, uint32_t a1, uint32_t odd_base, T *__restrict__ hrow,
+                                                  uint64_t *__restrict__ crow, Fetch fetch, Finish finish) {
+  if (a0 >= a1) return;
+  constexpr int U = PYNQS_U;  // pair slots in flight per lane (2*U gathers outstanding)
   const int tid = threadIdx.x;
-  const int nele = p.nele;
-  const int nterms = nele * (nele + 1) / 2;
-  T acc = T(0);
-  for (int base = 0; base < nterms; base += kDiagTile) {
-    const int end = min(base + kDiagTile, nterms);
-    if (base) __syncthreads();
-    for (int t = base + tid; t < end; t += kBlock) {
-      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > t) --a;
-      while ((a + 1) * (a + 2) / 2 <= t) ++a;
-      const int pos = t - a * (a + 1) / 2;
-      const int pa = L.occa[a];
-      tile[t - base] = pos == 0 ? D1[pa] : D2[pa * p.sorb + L.occa[pos - 1]];
-    }
-    __syncthreads();
-    if (tid == kBlock - 1)
-      for (int t = 0; t < end - base; ++t) acc += tile[t];
+  const uint32_t r_e = a0 + ((odd_base + a0 + 1) & 1u);  // first rank whose column has an even element index
+  if (r_e > a0 && tid == 0) {
+    uint64_t ket[LEN];
+    const auto d = fetch(a0);
+    const T h = finish(d, ket);
+    store_h<T>(hrow, a0 + 1, h);
+    if constexpr (WRITE_COMB) store_ket<LEN>(crow, a0 + 1, ket);
   }
-  if (tid == kBlock - 1) *out = acc;
+  const uint32_t nslots = a1 > r_e ? (a1 - r_e + 1) / 2 : 0;
+  for (uint32_t m0 = tid; m0 < nslots; m0 += kBlock * U) {
+    decltype(fetch(0u)) d[U][2];
+    bool second[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t m = m0 + u * kBlock;
+      second[u] = false;
+      if (m < nslots) {
+        const uint32_t r = r_e + 2 * m;
+        d[u][0] = fetch(r);
+        second[u] = r + 1 < a1;
+        if (second[u]) d[u][1] = fetch(r + 1);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t m = m0 + u * kBlock;
+      if (m < nslots) {
+        const uint32_t col = r_e + 2 * m + 1;
+        uint64_t k0[LEN], k1[LEN];
+        const T h0 = finish(d[u][0], k0);
+        if (second[u]) {
+          const T h1 = finish(d[u][1], k1);
+          store_h2<T>(hrow, col, h0, h1);
+          if constexpr (WRITE_COMB) store_ket2<LEN>(crow, col, k0, k1);
+        } else {
+          store_h<T>(hrow, col, h0);
+          if constexpr (WRITE_COMB) store_ket<LEN>(crow, col, k0);
+        }
+      }
+    }
+  }
 }
 
 template <int LEN, typename T, bool WRITE_COMB>
@@ -137,177 +178,46 @@ __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *_
   const uint32_t rlo = lo == 0 ? 0 : lo - 1, rhi = hi - 1;
   T *__restrict__ hrow = hmat + (size_t)walker * ncomb;
   uint64_t *__restrict__ crow = comb + (size_t)walker * ncomb * LEN;
-  const uint32_t K = (uint32_t)pl.K, NP = (uint32_t)pl.NP;
+  const uint32_t odd_base = (uint32_t)((walker * (uint64_t)ncomb) & 1u);
 
-  // ---- singles: ranks [0, d1) --------------------------------------------------------------------------
-  {
-    const uint32_t s_lo = rlo, s_hi = min(rhi, p.d1);
-    if (s_lo < s_hi) {
-      T *tile = reinterpret_cast<T *>(L.scratch);
-      const int stride = nocc | 1;  // odd: conflict-free column reads in the summation
-      const int per_tile = max(1, min(kBlock, kDiagTile / stride));  // one summing lane per staged single
-      const int wave = tid >> 6, lane = tid & 63;
-      const T *__restrict__ S2 = plan + pl.offS2;
-      const T *__restrict__ S1 = plan + pl.offS1;
-      for (uint32_t t0 = s_lo; t0 < s_hi; t0 += per_tile) {
-        const int cnt = (int)min((uint32_t)per_tile, s_hi - t0);
-        __syncthreads();  // scratch free (diag sum / previous tile consumed)
-        for (int sl = wave; sl < cnt; sl += kBlock / 64) {
-          const uint32_t r = t0 + sl;
-          const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-          const uint32_t spin = r >= p.d0;
-          const uint32_t hm = (e & 0xff) >> 1, qm = ((e >> 8) & 0xff) >> 1;
-          const T *__restrict__ rowp = S2 + ((size_t)(spin * K + hm) * K + qm) * p.sorb;
-          for (int j = lane; j < nocc; j += 64) tile[sl * stride + j] = rowp[L.occv[j]];
-        }
-        __syncthreads();
-        if (tid < cnt) {
-          const uint32_t r = t0 + tid;
-          const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-          const uint32_t spin = r >= p.d0;
-          const int h = e & 0xff, q = (e >> 8) & 0xff;
-          T acc = T(0);
-          acc += S1[(size_t)(spin * K + (h >> 1)) * K + (q >> 1)];
-          const T *__restrict__ mine = tile + tid * stride;
-          for (int j = 0; j < nocc; ++j) acc += mine[j];
-          hrow[r + 1] = ((e >> 16) & 1u) ? -acc : acc;
-          if constexpr (WRITE_COMB) {
-            uint64_t ket[LEN];
-            ket_from<LEN>(wk, h, q, 0, 0, false, ket);
+  // ---- singles: ranks [0, d1) ---------------------------------------------------------------------------
+  singles_phase<T>(p, pl, L, nocc, plan, rlo, min(rhi, p.d1), [&](uint32_t r, T v, int h, int q) {
+    store_h<T>(hrow, r + 1, v);
+    if constexpr (WRITE_COMB) {
+      uint64_t ket[LEN];
 #pragma unroll
-            for (int i = 0; i < LEN; ++i) crow[(size_t)(r + 1) * LEN + i] = ket[i];
-          }
-        }
-      }
+      for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+      toggle<LEN>(ket, h);
+      toggle<LEN>(ket, q);
+      store_ket<LEN>(crow, r + 1, ket);
     }
-  }
+  });
 
-  // ---- column 0: x itself and <x|H|x>.  Placed after the singles so that the single lane doing the
-  // ordered summation overlaps with the doubles loops of the other waves.
+  // ---- column 0: x itself and <x|H|x>.  After the singles: the single lane doing the ordered summation
+  // overlaps with the doubles loops of the other waves.
   if (lo == 0) {
     if constexpr (WRITE_COMB) {
       if (tid < LEN) crow[tid] = pick<LEN>(wk.w, tid);
     }
-    __syncthreads();  // scratch free (last singles tile consumed)
-    diag_phase_plan<T>(p, L, plan + pl.offD1, plan + pl.offD2, hrow);
+    diag_phase_plan<T>(p, pl, L, plan, [&](T v) { hrow[0] = v; });
   }
 
-  // ---- doubles ------------------------------------------------------------------------------------------
-  // Software-pipelined: the table element of the NEXT excitations is requested before the stores of the
-  // current ones are issued.  gfx950 retires vector-memory operations in order for s_waitcnt purposes
-  // (stores included), so a load issued behind stores cannot be consumed until those stores have been
-  // acknowledged by HBM; issued ahead of them it only waits for itself.
-#ifndef PYNQS_U
-#define PYNQS_U 4
-#endif
-  constexpr int U = PYNQS_U;  // excitations in flight per lane
-
-  // same-spin: [d1, d2) alpha, [d2, d3) beta
+  // ---- doubles -----------------------------------------------------------------------------------------
 #pragma unroll
   for (int spin = 0; spin < 2; ++spin) {
-    const uint32_t b0 = spin ? p.d2 : p.d1, b1 = spin ? p.d3 : p.d2;
-    const uint32_t a0 = max(rlo, b0), a1 = min(rhi, b1);
-    if (a0 >= a1) continue;
-    const uint32_t npair = spin ? p.noBB : p.noAA;
-    const uint32_t rot = spin ? p.rotB : p.rotA;
-    const MagicDiv dv = spin ? p.divNoBB : p.divNoAA;
-    const uint32_t *__restrict__ HP = L.tab + (spin ? p.offHPb : p.offHPa);
-    const uint32_t *__restrict__ PP = L.tab + (spin ? p.offPPb : p.offPPa);
-    const T *__restrict__ V = plan + pl.offVss + (size_t)spin * NP * NP;
-    auto fetch = [&](uint32_t r, uint32_t &eh, uint32_t &ep, T &v) {
-      const uint32_t t = r - b0;
-      const uint32_t ab = mdiv(t, dv);
-      uint32_t ij = t - ab * npair + rot;  // == r % npair (excitation.cpp:63,79)
-      ij = ij >= npair ? ij - npair : ij;
-      eh = HP[ij]; ep = PP[ab];
-      v = V[__umul24((ep >> 17) & 0x1fffu, NP) + ((eh >> 17) & 0x1fffu)];
-    };
-    uint32_t eh[U], ep[U];
-    T v[U];
-    uint32_t r = a0 + tid;
-#pragma unroll
-    for (int u = 0; u < U; ++u) { eh[u] = ep[u] = 0; v[u] = T(0); if (r + u * kBlock < a1) fetch(r + u * kBlock, eh[u], ep[u], v[u]); }
-    while (r < a1) {
-      uint32_t neh[U], nep[U];
-      T nv[U];
-      const uint32_t rn = r + U * kBlock;
-#pragma unroll
-      for (int u = 0; u < U; ++u) { neh[u] = nep[u] = 0; nv[u] = T(0); if (rn + u * kBlock < a1) fetch(rn + u * kBlock, neh[u], nep[u], nv[u]); }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t rr = r + u * kBlock;
-        if (rr < a1) {
-          const int h0 = eh[u] & 0xff, h1 = (eh[u] >> 8) & 0xff, q0 = ep[u] & 0xff, q1 = (ep[u] >> 8) & 0xff;
-          const uint32_t par = (((eh[u] ^ ep[u]) >> 16) & 1u) ^ (uint32_t)(h0 < q0) ^ (uint32_t)(h1 < q0) ^
-                               (uint32_t)(h0 < q1) ^ (uint32_t)(h1 < q1);
-          store_h<T>(hrow, rr + 1, par ? -v[u] : v[u]);
-          if constexpr (WRITE_COMB) {
-            uint64_t ket[LEN];
-            ket_from<LEN>(wk, h0, h1, q0, q1, true, ket);
-            store_ket<LEN>(crow, rr + 1, ket);
-          }
-        }
-      }
-      r = rn;
-#pragma unroll
-      for (int u = 0; u < U; ++u) { eh[u] = neh[u]; ep[u] = nep[u]; v[u] = nv[u]; }
-    }
+    const SameSpinClass c = make_same_spin(p, pl, L, spin);
+    const uint32_t b1 = spin ? p.d3 : p.d2;
+    const T *__restrict__ V = plan + pl.offVss + (size_t)spin * pl.NP * pl.NP;
+    paired_class_loop<LEN, T, WRITE_COMB>(
+        max(rlo, c.b0), min(rhi, b1), odd_base, hrow, crow, [&](uint32_t r) { return fetch_same_spin<T>(r, c, V); },
+        [&](const PendingDouble<T> &d, uint64_t (&ket)[LEN]) { return finish_same_spin<LEN, T>(d, wk, ket); });
   }
-
-  // opposite-spin: [d3, nsd)
   {
-    const uint32_t a0 = max(rlo, p.d3), a1 = min(rhi, p.nsd);
-    const uint32_t *__restrict__ SA = L.tab + p.offSa;
-    const uint32_t *__restrict__ SB = L.tab + p.offSb;
+    const OppSpinClass c = make_opp_spin(p, pl, L);
     const T *__restrict__ V = plan + pl.offVab;
-    const uint32_t K2 = K * K;
-    auto fetch = [&](uint32_t r, uint32_t &ea, uint32_t &eb, T &v) {
-      const uint32_t t = r - p.d3;
-      const uint32_t jb = mdiv(t, p.divNSa);
-      const uint32_t ia = t - jb * (uint32_t)p.nSa;
-      ea = SA[ia]; eb = SB[jb];
-#ifdef PYNQS_ABL_NOGATHER
-      v = T(1) + T((eb >> 17) + (ea >> 17));
-#else
-      v = V[__umul24(eb >> 17, K2) + (ea >> 17)];
-#endif
-    };
-    uint32_t ea[U], eb[U];
-    T v[U];
-    uint32_t r = a0 + tid;
-#pragma unroll
-    for (int u = 0; u < U; ++u) { ea[u] = eb[u] = 0; v[u] = T(0); if (r + u * kBlock < a1) fetch(r + u * kBlock, ea[u], eb[u], v[u]); }
-    while (r < a1) {
-      uint32_t nea[U], neb[U];
-      T nv[U];
-      const uint32_t rn = r + U * kBlock;
-#pragma unroll
-      for (int u = 0; u < U; ++u) { nea[u] = neb[u] = 0; nv[u] = T(0); if (rn + u * kBlock < a1) fetch(rn + u * kBlock, nea[u], neb[u], nv[u]); }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t rr = r + u * kBlock;
-        if (rr < a1) {
-          const int ha = ea[u] & 0xff, qa = (ea[u] >> 8) & 0xff, hb = eb[u] & 0xff, qb = (eb[u] >> 8) & 0xff;
-          const uint32_t par = (((ea[u] ^ eb[u]) >> 16) & 1u) ^ (uint32_t)(ha < qb) ^ (uint32_t)(hb < qa) ^ 1u;
-#ifdef PYNQS_ABL_NOSTORE
-          const T vv = par ? -v[u] : v[u];
-          uint64_t ket[LEN];
-          ket_from<LEN>(wk, ha, qa, hb, qb, true, ket);
-          asm volatile("" ::"v"(vv), "v"(ket[0]));
-#else
-          store_h<T>(hrow, rr + 1, par ? -v[u] : v[u]);
-          if constexpr (WRITE_COMB) {
-            uint64_t ket[LEN];
-            ket_from<LEN>(wk, ha, qa, hb, qb, true, ket);
-            store_ket<LEN>(crow, rr + 1, ket);
-          }
-#endif
-        }
-      }
-      r = rn;
-#pragma unroll
-      for (int u = 0; u < U; ++u) { ea[u] = nea[u]; eb[u] = neb[u]; v[u] = nv[u]; }
-    }
+    paired_class_loop<LEN, T, WRITE_COMB>(
+        max(rlo, p.d3), min(rhi, p.nsd), odd_base, hrow, crow, [&](uint32_t r) { return fetch_opp_spin<T>(r, c, V); },
+        [&](const PendingDouble<T> &d, uint64_t (&ket)[LEN]) { return finish_opp_spin<LEN, T>(d, wk, ket); });
   }
 }
 
@@ -338,13 +248,6 @@ extern "C" int pynqs_plan_build(const void *h1e, const void *h2e, int sorb, int 
   return check_launch("plan_build");
 }
 
-#define DISPATCH_LEN(len, ...)                                  \
-  switch (len) {                                                \
-    case 1: { constexpr int LEN = 1; __VA_ARGS__; } break;      \
-    case 2: { constexpr int LEN = 2; __VA_ARGS__; } break;      \
-    default: { constexpr int LEN = 3; __VA_ARGS__; } break;     \
-  }
-
 template <int LEN, typename T>
 static int launch_plan(const uint64_t *bra, int64_t nbatch, const SDParams &p, const PlanLayout &pl, const T *plan,
                        uint64_t *comb, T *hmat, hipStream_t st) {
@@ -373,6 +276,8 @@ extern "C" int pynqs_comb_hij_fused_plan(const uint64_t *bra, int64_t nbatch, in
   if (nbatch == 0) return PYNQS_OK;
   if (!bra || !plan || !hmat) return set_error(PYNQS_EINVAL, "null pointer");
   if (nbatch > 0x7fffffffll) return set_error(PYNQS_EINVAL, "nbatch too large");
+  // the paired 16-byte stores need 16-byte aligned output buffers (any allocator gives that)
+  if (((uintptr_t)hmat & 15u) || ((uintptr_t)comb & 15u)) return set_error(PYNQS_EINVAL, "comb/hmat must be 16-byte aligned");
   const int len = (sorb - 1) / 64 + 1;
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;

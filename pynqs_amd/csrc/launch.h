@@ -42,3 +42,11 @@ inline void plan_chunks(int64_t nbatch, uint32_t ncomb, uint32_t *nchunks, uint3
 }
 
 }  // namespace pynqs
+
+// run-time dispatch of the ONV word count (the reference compiles one build per MAX_SORB_LEN)
+#define DISPATCH_LEN(len, ...)                                  \
+  switch (len) {                                                \
+    case 1: { constexpr int LEN = 1; __VA_ARGS__; } break;      \
+    case 2: { constexpr int LEN = 2; __VA_ARGS__; } break;      \
+    default: { constexpr int LEN = 3; __VA_ARGS__; } break;     \
+  }
