@@ -186,18 +186,28 @@ __device__ __forceinline__ int64_t lut_find(const uint64_t *__restrict__ keys, i
 // occa[192]     : occupied orbitals ascending, zero-padded (the reference's olst, hamiltonian.cpp:38-39)
 // tab[...]      : excitation tables, entry = orbX | orbY << 8 | parity << 16 | plan offset part << 17
 // scratch       : kDiagTile elements of the integral dtype (diagonal-element terms), 8-byte aligned
+// msk[...]      : (sorb <= 64 only) one 64-bit word per table entry: the entry's two orbital bits, XORed with
+//                 the walker for the alpha-singles and hole-pair tables, so that a ket is msk[x] ^ msk[y]
 struct LdsLayout {
   uint8_t *merged;
   uint8_t *occv;
   uint8_t *occa;
   uint32_t *tab;
+  uint64_t *msk;
   unsigned char *scratch;
 };
 
-constexpr int kDiagTile = 2048;
+#ifndef PYNQS_DIAG_TILE
+#define PYNQS_DIAG_TILE 2048
+#endif
+constexpr int kDiagTile = PYNQS_DIAG_TILE;
+
+__host__ __device__ inline size_t lds_tab_bytes(const SDParams &p) {
+  return (((size_t)p.tabEntries * 4 + 3 * 192) + 7) & ~(size_t)7;
+}
 
 __host__ __device__ inline size_t lds_fixed_bytes(const SDParams &p) {
-  return (((size_t)p.tabEntries * 4 + 3 * 192) + 7) & ~(size_t)7;
+  return lds_tab_bytes(p) + (p.sorb <= 64 ? (size_t)p.tabEntries * 8 : 0);
 }
 
 // with_diag_scratch: room for kDiagTile values of `elem` bytes after the fixed part
@@ -211,6 +221,7 @@ __device__ __forceinline__ LdsLayout carve_lds(unsigned char *base, const SDPara
   L.merged = base + (size_t)p.tabEntries * 4;
   L.occv = L.merged + 192;
   L.occa = L.occv + 192;
+  L.msk = reinterpret_cast<uint64_t *>(base + lds_tab_bytes(p));
   L.scratch = base + lds_fixed_bytes(p);
   return L;
 }
@@ -283,6 +294,10 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     // bits 17..30: (particle spatial index) * K + (hole spatial index): the plan kernels' Vab offset parts
     const uint32_t sp = (uint32_t)(q >> 1) * (uint32_t)(p.sorb >> 1) + (uint32_t)(h >> 1);
     L.tab[(beta ? p.offSb : p.offSa) + ia] = (uint32_t)h | ((uint32_t)q << 8) | (par << 16) | (sp << 17);
+    if constexpr (LEN == 1) {
+      const uint64_t bits = (1ull << h) ^ (1ull << q);
+      L.msk[(beta ? p.offSb : p.offSa) + ia] = beta ? bits : (bits ^ wk.w[0]);
+    }
   }
   // pair tables: hole pairs (hi > lo among occupied slots) and particle pairs (virtual slots)
   const int nPairs = p.noAA + p.nvAA + p.noBB + p.nvBB;
@@ -301,6 +316,10 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     // bits 17..29: pair rank over the spatial orbitals of this spin (the plan kernels' Vss row / column)
     const uint32_t m1 = (uint32_t)o1 >> 1, m0 = (uint32_t)o0 >> 1;
     L.tab[off + q] = (uint32_t)o1 | ((uint32_t)o0 << 8) | (par << 16) | ((m1 * (m1 - 1) / 2 + m0) << 17);
+    if constexpr (LEN == 1) {
+      const uint64_t bits = (1ull << o1) ^ (1ull << o0);
+      L.msk[off + q] = extra ? bits : (bits ^ wk.w[0]);
+    }
   }
   __syncthreads();
   return occA + occB;
