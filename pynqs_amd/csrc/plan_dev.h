@@ -216,7 +216,7 @@ __device__ __forceinline__ void diag_wave(const SDParams &p, const PlanLayout &p
       // ordered sum; the next 16 LDS values are requested while the current 16 are being added, so the
       // ~100-cycle LDS latency is paid once, not per group (it was 80 % of this loop's time)
       const int n = end - base;
-      constexpr int Gp = 16;
+      constexpr int Gp = 8;
       T cur[Gp], nxt[Gp];
       int t = 0;
       if (n >= Gp) {
