@@ -182,9 +182,10 @@ __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *_
   const ClassRange gB = class_range(p.d2, p.d3, rlo, rhi, odd_base);
   const ClassRange gO = class_range(p.d3, p.nsd, rlo, rhi, odd_base);
   const uint32_t tA = (gA.npairs + kTile - 1) / kTile, tB = (gB.npairs + kTile - 1) / kTile, tO = (gO.npairs + kTile - 1) / kTile;
-  // singles of this range: tiles of kSinglesPerTile, staged through the wave-private quarter of L.scratch
-  const uint32_t s_lo = rlo, s_hi = max(rlo, min(rhi, p.d1));
-  const uint32_t tS = (s_hi - s_lo + kSinglesPerTile - 1) / kSinglesPerTile;
+  // The singles tiles of the walker are dealt round-robin to its workgroups (they cost far more per column
+  // than doubles; left to the first chunk they would make it the straggler when rows are cut into many chunks).
+  const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+  const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
   // tile 0 = the odd jobs (unpaired columns, column 0 with the ordered diagonal sum), then singles, then doubles
   const uint32_t ntiles = 1 + tS + tA + tB + tO;
   const T *__restrict__ Vss = plan + pl.offVss;
@@ -217,8 +218,8 @@ __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *_
       continue;
     }
     if (tile <= tS) {
-      const uint32_t r0 = s_lo + (tile - 1) * kSinglesPerTile;
-      singles_tile<T>(r0, min(r0 + kSinglesPerTile, s_hi), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
+      const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSinglesPerTile;
+      singles_tile<T>(r0, min(r0 + kSinglesPerTile, p.d1), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
         store_h<T>(hrow, r + 1, v);
         if constexpr (WRITE_COMB) {
           uint64_t ket[LEN];
