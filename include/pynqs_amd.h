@@ -89,6 +89,13 @@ int pynqs_pm01_to_onv(const uint8_t *occ, int64_t n, int sorb, uint64_t *out, vo
 int pynqs_wavefunction_lut(const uint64_t *keys, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb,
                            int64_t *idx, uint8_t *mask, void *stream);
 
+/* cpp_src/tensor/bind.cpp:303-314 (spin_flip_rand) -> cpu_tensor.cpp:90-137 / cuda kernel.cu:691-716: one random
+ * single/double move per walker: r0 uniform on [0, nsd] (both ends), r0 == 0 keeps the walker, else excitation
+ * rank r0-1 is applied.  out may alias bra (in place).  The stream is a counter-based hash of
+ * (seed, offset + walker index): pass a different `offset` (e.g. a running sample count) on every call. */
+int pynqs_spin_flip_rand(const uint64_t *bra, int64_t n, int sorb, int noA, int noB, uint64_t seed,
+                         uint64_t offset, uint64_t *out, void *stream);
+
 /* ---- integral plan: the fast path ---------------------------------------------------------------
  * The reference keeps h2e as one packed triangle over all spin-orbital pairs (integral.cpp:6-60); random
  * gathers from it are bound by the CU's vector L1.  A plan is a spin-blocked dense re-layout of the SAME

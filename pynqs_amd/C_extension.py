@@ -30,7 +30,7 @@ USE_PLAN = True  # route get_comb_hij_fused through the cached integral plan (Fa
 
 __all__ = [
     "tensor_to_onv", "onv_to_tensor", "get_comb_tensor", "get_hij_torch", "get_comb_hij_fused",
-    "wavefunction_lut", "merge_rank_sample", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
+    "wavefunction_lut", "merge_rank_sample", "spin_flip_rand", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
     "MAX_SORB", "MAX_SORB_LEN", "MAX_NELE",
 ]
 
@@ -268,6 +268,32 @@ def wavefunction_lut(bra_key: Tensor, onv: Tensor, sorb: int, little_endian: boo
     N.check(N.lib().pynqs_wavefunction_lut(k.data_ptr(), k.size(0), q.data_ptr(), n, sorb, idx.data_ptr(), mask.data_ptr(),
                                            _stream(dev)), "wavefunction_lut")
     return (idx.cpu(), mask.cpu()) if any_cpu else (idx, mask)
+
+
+_SPIN_FLIP_CALLS = 0
+
+
+def spin_flip_rand(bra: Tensor, sorb: int, nele: int, noA: int, noB: int, seed: int, in_place: bool = False) -> Tuple[Tensor, Tensor]:
+    """bind.cpp:303-314 -> cpu_tensor.cpp:90-137: one random single/double move (or none) per walker.
+    Returns (onv_to_tensor(new walkers), new walkers uint8[n, 8*len]).  The reference's generators are
+    function-local statics seeded once, so its `seed` only matters on the first call; here
+    every call uses (seed, a per-process call counter) so that successive calls give fresh, reproducible moves."""
+    global _SPIN_FLIP_CALLS
+    _check_onv(bra, "bra_tensor", sorb, (1, 2))
+    x2 = bra.view(-1, bra.size(-1))
+    n = x2.size(0)
+    dev, (x,), cpu = _stage(x2)
+    out = x if (in_place and not cpu) else torch.empty_like(x)
+    if n:
+        N.check(N.lib().pynqs_spin_flip_rand(x.data_ptr(), n, sorb, noA, noB, int(seed) & (2**64 - 1), _SPIN_FLIP_CALLS << 32,
+                                             out.data_ptr(), _stream(dev)), "spin_flip_rand")
+    _SPIN_FLIP_CALLS += 1
+    if cpu:
+        out = out.cpu()
+        if in_place:
+            x2.copy_(out)
+            out = x2
+    return onv_to_tensor(out, sorb), out
 
 
 def merge_rank_sample(idx: Tensor, counts: Tensor, split_idx: Tensor, length: int) -> Tensor:

@@ -30,6 +30,7 @@ SIGNATURES = {
     "pynqs_onv_to_pm1": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
     "pynqs_pm01_to_onv": (_int, [_vp, _i64, _int, _vp, _vp]),
     "pynqs_wavefunction_lut": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
+    "pynqs_spin_flip_rand": (_int, [_vp, _i64, _int, _int, _int, C.c_uint64, C.c_uint64, _vp, _vp]),
     "pynqs_plan_bytes": (_i64, [_int, _int]),
     "pynqs_plan_build": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_comb_hij_fused_plan": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),

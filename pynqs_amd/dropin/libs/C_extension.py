@@ -5,7 +5,7 @@ local-energy path are present so that `vmc/sample.py:19-26` and 
 import cleanly; the ones not implemented raise NotImplementedError when CALLED, never at import."""
 from pynqs_amd.C_extension import (MAX_NELE, MAX_SORB, MAX_SORB_LEN, check_sorb, compress_h1e_h2e,  # noqa: F401
                                    decompress_h1e_h2e, get_comb_hij_fused, get_comb_tensor, get_hij_torch,
-                                   merge_rank_sample, onv_to_tensor, tensor_to_onv, wavefunction_lut)
+                                   merge_rank_sample, onv_to_tensor, spin_flip_rand, tensor_to_onv, wavefunction_lut)
 
 
 def _out_of_scope(name: str, where: str):
@@ -15,7 +15,6 @@ def _out_of_scope(name: str, where: str):
     return f
 
 
-spin_flip_rand = _out_of_scope("spin_flip_rand", "MCMC move, cpp_src/tensor/cpu_tensor.cpp:90")
 MCMC_sample = _out_of_scope("MCMC_sample", "dead code in the reference, vmc/sample.py:504")
 permute_sgn = _out_of_scope("permute_sgn", "BDG-RNN / MPS-RNN ansatz helper")
 constrain_make_charts = _out_of_scope("constrain_make_charts", "AR symmetry masks of the ansatz")

@@ -1,0 +1,63 @@
+"""Fixed-node Green's-function Monte-Carlo step (mirror of PyNQS' gfmc/walker.py:167-279).
+
+green_kernel(): for every walker x the row G(x' <- x) = psi(x') <x'|Lambda - H_eff|x> / psi(x) over its S+D
+list, the fixed-node effective Hamiltonian with the sign-flip potential on the diagonal, and the local energy;
+sample_update(): one multinomial move per walker by inverse-CDF (row cumsum + searchsorted).
+Enumeration and matrix elements come from the fused HIP kernel; psi from pynqs_amd.energy.Func.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .C_extension import get_comb_hij_fused
+from .energy import Func
+from .public_function import WavefunctionLUT
+
+
+def green_kernel(x: Tensor, Lambda: float, h1e: Tensor, h2e: Tensor, ansatz, ansatz_batch: Callable[..., Tensor], sorb: int,
+                 nele: int, noa: int, nob: int, dtype: torch.dtype = torch.double, WF_LUT: Optional[WavefunctionLUT] = None,
+                 use_unique: bool = True) -> Tuple[Tensor, Tensor, Tensor, bool, Tensor]:
+    """gfmc/walker.py:167-235.  Returns (eloc[n], green_kernel[n, ncomb], comb_x[n, ncomb, 8*len], stop_flag,
+    mask of walkers whose diagonal kernel was negative and has been clamped to 0)."""
+    with torch.no_grad():
+        assert x.dim() == 2
+        batch = x.shape[0]
+        device = h1e.device
+        f = partial(ansatz_batch, func=ansatz)
+        comb_x, comb_hij = get_comb_hij_fused(x, h1e, h2e, sorb, nele, noa, nob)
+        bra_len = comb_x.shape[2]
+        gamma = torch.where(comb_hij >= 0, 0, torch.pi)  # H = |H| exp(i gamma)
+        psi_x1 = Func(f, comb_x.reshape(-1, bra_len), WF_LUT, use_unique).reshape(batch, -1).real
+        phase = torch.angle(psi_x1)
+        alpha = phase - phase[..., 0].unsqueeze(-1)
+        mask = torch.cos(alpha + gamma) < 0.0  # sign-preserving moves
+        mask[..., 0] = True
+        ratio = psi_x1 / psi_x1[..., 0].unsqueeze(-1)
+        hij_eff = torch.where(mask, comb_hij, 0.0).to(psi_x1.dtype)
+        v_sf = torch.sum(torch.where(~mask, comb_hij, 0.0) * ratio, -1)  # sign-flip potential
+        hij_eff[..., 0] += v_sf
+        eloc = (ratio * hij_eff).sum(-1)
+        K = -hij_eff
+        K[..., 0] += Lambda
+        gk = psi_x1.conj() * K.conj() / psi_x1[..., 0].unsqueeze(-1).conj()
+        neg = gk[..., 0] < 0
+        gk[..., 0][neg] = 0.0
+        assert torch.all(gk[..., 1:] >= 0)
+        return eloc, gk, comb_x, False, neg
+
+
+def sample_update(x: Tensor, weight: Tensor, comb_x: Tensor, green_kernel: Tensor, rand_num: Optional[Tensor] = None):
+    """gfmc/walker.py:260-279: x_new ~ G(. <- x) / beta, weight *= beta."""
+    beta = green_kernel.sum(-1, keepdim=True)
+    cum_prob = green_kernel.cumsum(-1) / beta
+    if rand_num is None:
+        rand_num = torch.rand_like(beta)
+    index = torch.searchsorted(cum_prob, rand_num, right=False).reshape(-1)
+    x_new = comb_x[torch.arange(beta.size(0), device=comb_x.device), index]
+    weight_new = weight * beta.squeeze()
+    accept_nums = index.nonzero().size(0)
+    return x_new, weight_new, beta, accept_nums

@@ -146,3 +146,55 @@ def test_spin_flip_and_multi_psi_paths_agree_with_plain_tensor_algebra(env):
     e2, _, _, _ = energy.local_energy(x, env["h1e"], env["h2e"], env["rbm"], ab, 40, 30, 15, 15, use_spin_flip=True, extra_norm=en,
                                       reduce_psi=True, eps=0.0)
     np.testing.assert_allclose(e2.cpu().numpy(), eloc.cpu().numpy(), rtol=0, atol=1e-10)
+
+
+def test_spin_flip_rand_reaches_exactly_the_sd_space(env):
+    """Like cpp_src/test/test-spin-flip.py: the set of proposed states == the rows of get_comb_tensor, and the
+    move index is uniform on [0, ncomb]."""
+    from pynqs_amd import C_extension as cx
+
+    for (sorb, noA, noB) in [(8, 2, 2), (12, 3, 2), (130, 2, 1)]:
+        L = (sorb - 1) // 64 + 1
+        occ = torch.zeros(sorb, dtype=torch.uint8)
+        occ[[2 * i for i in range(noA)]] = 1; occ[[2 * i + 1 + 2 * (i % 2) for i in range(noB)]] = 1
+        x0 = cx.tensor_to_onv(occ.cuda(), sorb)
+        comb, _ = cx.get_comb_tensor(x0, sorb, noA + noB, noA, noB)
+        ncomb = comb.size(1)
+        n = 400 * ncomb
+        pm, new = cx.spin_flip_rand(x0.repeat(n, 1).contiguous(), sorb, noA + noB, noA, noB, seed=1234)
+        assert new.shape == (n, 8 * L) and torch.equal(pm, cx.onv_to_tensor(new, sorb))
+        uniq, counts = torch.unique(new, dim=0, return_counts=True)
+        assert torch.equal(uniq, torch.unique(comb[0], dim=0))
+        # x itself is produced by r0 = 0 only: expected share 1/(nsd+1) each (chi-square style bound)
+        exp = n / ncomb
+        assert float(((counts - exp) ** 2 / exp).sum()) < 2.0 * ncomb
+        pm2, new2 = cx.spin_flip_rand(x0.repeat(n, 1).contiguous(), sorb, noA + noB, noA, noB, seed=1234)
+        assert not torch.equal(new, new2)  # a fresh stream on every call
+
+
+def test_gfmc_step_matches_direct_tensor_algebra(env):
+    from pynqs_amd import C_extension as cx, gfmc
+
+    x = env["x"][:5].contiguous()
+    ab = _ab(env)
+    eloc, gk, comb, stop, neg = gfmc.green_kernel(x, -100.0, env["h1e"], env["h2e"], env["rbm"], ab, 40, 30, 15, 15)
+    comb2, hm = cx.get_comb_hij_fused(x, env["h1e"], env["h2e"], 40, 30, 15, 15)
+    with torch.no_grad():
+        psi = ab(comb2.reshape(-1, 8), env["rbm"]).reshape(5, -1)
+    ratio = psi / psi[:, :1]
+    keep = (torch.sign(hm) * torch.sign(ratio)) < 0  # cos(alpha + gamma) < 0 for real psi
+    keep[:, 0] = True
+    heff = torch.where(keep, hm, 0.0)
+    heff[:, 0] += (torch.where(~keep, hm, 0.0) * ratio).sum(-1)
+    want_e = (ratio * heff).sum(-1)
+    np.testing.assert_allclose(eloc.cpu().numpy(), want_e.cpu().numpy(), rtol=0, atol=1e-9)
+    K = -heff; K[:, 0] += -100.0
+    np.testing.assert_allclose(gk.cpu().numpy(), torch.clamp(ratio * K, min=0.0).cpu().numpy() if bool(neg.any()) else (ratio * K).cpu().numpy(),
+                               rtol=1e-12, atol=1e-12)
+    assert torch.equal(comb, comb2) and stop is False
+    # the fixed-node E_loc equals the plain E_loc when psi has no sign structure issue: sum_k ratio*H
+    r = torch.full((5, 1), 0.37, dtype=torch.float64, device=x.device)
+    x_new, w_new, beta, acc = gfmc.sample_update(x, torch.ones(5, dtype=torch.float64, device=x.device), comb, gk, r)
+    cum = gk.cumsum(-1) / gk.sum(-1, keepdim=True)
+    idx = (cum < 0.37).sum(-1)
+    assert torch.equal(x_new, comb[torch.arange(5), idx]) and torch.allclose(w_new, gk.sum(-1))
