@@ -155,16 +155,34 @@ __global__ __launch_bounds__(kBlock) void hij_pairs_kernel(const uint64_t *__res
 }
 
 // -------------------------------------------------------------------------------------------------
-// onstate.h:45-63 : one lane per output element, +1 occupied / -1 empty.
+// onstate.h:45-63 : +1 occupied / -1 empty.  The output is one flat array; a lane writes 16 consecutive
+// bytes of it (2 doubles / 4 floats, possibly across a row boundary) with one store.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void onv_to_pm1_kernel(const uint64_t *__restrict__ bra, uint64_t n, int sorb, int len,
                                                             T *__restrict__ out) {
-  const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n * (uint64_t)sorb) return;
-  const uint64_t w = idx / (uint32_t)sorb;
-  const int o = (int)(idx - w * (uint32_t)sorb);
-  const uint64_t word = bra[w * len + (o >> 6)];
-  out[idx] = ((word >> (o & 63)) & 1ull) ? T(1) : T(-1);
+  constexpr int V = 16 / sizeof(T);
+  typedef T TV __attribute__((ext_vector_type(V)));
+  const uint64_t total = n * (uint64_t)sorb;
+  const uint64_t e0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * V;
+  if (e0 >= total) return;
+  uint64_t w = e0 / (uint32_t)sorb;
+  int o = (int)(e0 - w * (uint32_t)sorb);
+  T v[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const bool in = e0 + i < total;
+    const uint64_t word = in ? bra[w * len + (o >> 6)] : 0;
+    v[i] = ((word >> (o & 63)) & 1ull) ? T(1) : T(-1);
+    if (++o == sorb) { o = 0; ++w; }
+  }
+  if (e0 + V <= total) {
+    TV pack;
+#pragma unroll
+    for (int i = 0; i < V; ++i) pack[i] = v[i];
+    *reinterpret_cast<TV *>(out + e0) = pack;
+  } else {
+    for (int i = 0; e0 + i < total; ++i) out[e0 + i] = v[i];
+  }
 }
 
 // cpu_tensor.cpp:8-44 : one wave per output word; lane l tests byte l, ballot packs the word.
@@ -287,8 +305,10 @@ extern "C" int pynqs_onv_to_pm1(const uint64_t *bra, int64_t n, int sorb, int dt
   if (!bra || !out) return set_error(PYNQS_EINVAL, "null pointer");
   const int len = (sorb - 1) / 64 + 1;
   const uint64_t total = (uint64_t)n * (uint64_t)sorb;
-  const uint64_t grid = (total + kBlock - 1) / kBlock;
+  const uint64_t per = dtype == PYNQS_F64 ? 2 : 4;  // elements per lane (16-byte stores)
+  const uint64_t grid = ((total + per - 1) / per + kBlock - 1) / kBlock;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "n*sorb too large for one launch");
+  if ((uintptr_t)out & 15u) return set_error(PYNQS_EINVAL, "out must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == PYNQS_F64)
     hipLaunchKernelGGL((onv_to_pm1_kernel<double>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, (uint64_t)n, sorb, len, (double *)out);
