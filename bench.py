@@ -228,9 +228,10 @@ class SampleSpaceFused(Workload):
         st = torch.cuda.current_stream(self.dev)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        rc = self.lib.pynqs_eloc_sample_space(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB, self.plan.data_ptr(),
-                                              self.lut.bra_key.data_ptr(), self.lut.bra_key.size(0), self.lut.wf_value.data_ptr(), 1,
-                                              self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
+        ht = self.lut.hashtable
+        rc = self.lib.pynqs_eloc_sample_space_hash(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
+                                                   self.plan.data_ptr(), ht.table.data_ptr(), ht.nkeys, self.lut.wf_value.data_ptr(), 1,
+                                                   self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
         e1.record(st)
         self.N.check(rc, "pynqs_eloc_sample_space")
         # <E_loc>, variance: one packed all-reduce over the ranks (RCCL), no barrier

@@ -121,6 +121,22 @@ int pynqs_eloc_sample_space(const uint64_t *bra, int64_t nbatch, int sorb, int n
                             const void *plan, const uint64_t *keys, int64_t nkeys, const double *wf,
                             int wf_is_complex, double *eloc, double *psi0, void *stream);
 
+/* ---- hash table over the sorted sample keys (the reference's optional GPU table: cuda/hashTable.cu,
+ * cuda_tensor.cpp:489-559 hash_build / hash_lookup, off by default: utils/public_function.py:23 USE_HASH).
+ * Open addressing in caller-owned memory; values are the positions in the SORTED key array, so a lookup returns
+ * exactly what pynqs_wavefunction_lut returns.
+ *   pynqs_hash_bytes  : [host] table size in bytes for nkeys keys
+ *   pynqs_hash_build  : fill `table` from keys uint64[nkeys][len] (any order, distinct)
+ *   pynqs_hash_lookup : idx[i] = position of onv[i] in the key array or -1, mask[i] = found
+ *   pynqs_eloc_sample_space_hash : pynqs_eloc_sample_space with the table instead of the sorted keys        */
+int64_t pynqs_hash_bytes(int64_t nkeys, int sorb);
+int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, void *table, void *stream);
+int pynqs_hash_lookup(const void *table, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb, int64_t *idx,
+                      uint8_t *mask, void *stream);
+int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                 const void *plan, const void *table, int64_t nkeys, const double *wf,
+                                 int wf_is_complex, double *eloc, double *psi0, void *stream);
+
 /* REDUCE method front end: vmc/energy/eloc.py:205-324 with eps_sample == 0 keeps the columns with
  * |<x|H|x'>| >= eps (eloc.py:297-298; column 0 is treated like any other).  Two passes, nothing materialised:
  *   pynqs_reduce_count : counts[nbatch] = kept columns per walker

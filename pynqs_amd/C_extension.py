@@ -30,7 +30,7 @@ USE_PLAN = True  # route get_comb_hij_fused through the cached integral plan (Fa
 
 __all__ = [
     "tensor_to_onv", "onv_to_tensor", "get_comb_tensor", "get_hij_torch", "get_comb_hij_fused",
-    "wavefunction_lut", "merge_rank_sample", "spin_flip_rand", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
+    "wavefunction_lut", "hash_build", "hash_lookup", "HashTable", "merge_rank_sample", "spin_flip_rand", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
     "MAX_SORB", "MAX_SORB_LEN", "MAX_NELE",
 ]
 
@@ -268,6 +268,48 @@ def wavefunction_lut(bra_key: Tensor, onv: Tensor, sorb: int, little_endian: boo
     N.check(N.lib().pynqs_wavefunction_lut(k.data_ptr(), k.size(0), q.data_ptr(), n, sorb, idx.data_ptr(), mask.data_ptr(),
                                            _stream(dev)), "wavefunction_lut")
     return (idx.cpu(), mask.cpu()) if any_cpu else (idx, mask)
+
+
+class HashTable:
+    """Device hash table over a set of onv keys (the reference's optional `HashTable`, bind.cpp:363-379 /
+    cuda/hashTable.cu).  Values are positions in the key array handed to hash_build."""
+
+    def __init__(self, table: Tensor, nkeys: int, sorb: int) -> None:
+        self.table, self.nkeys, self.sorb = table, nkeys, sorb
+
+    @property
+    def memory(self) -> int:
+        return self.table.numel() * self.table.element_size()
+
+    def cleanMemory(self) -> None:
+        self.table = None
+
+
+def hash_build(bra_key: Tensor, sorb: int) -> HashTable:
+    """cuda_tensor.cpp:489-534 (hash_build): keys uint8[nkeys, 8*len] (distinct) -> HashTable on the GPU."""
+    _check_onv(bra_key, "bra_key", sorb, (2,))
+    dev, (k,), _ = _stage(bra_key)
+    nbytes = N.lib().pynqs_hash_bytes(k.size(0), sorb)
+    table = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    N.check(N.lib().pynqs_hash_build(k.data_ptr(), k.size(0), sorb, table.data_ptr(), _stream(dev)), "hash_build")
+    if k is not bra_key:
+        torch.cuda.current_stream(dev).synchronize()
+    return HashTable(table, k.size(0), sorb)
+
+
+def hash_lookup(ht: HashTable, onv: Tensor) -> Tuple[Tensor, Tensor]:
+    """cuda_tensor.cpp:536-559 (hash_lookup): (idx int64[n] or -1, mask bool[n]); same answers as wavefunction_lut
+    on the key array the table was built from."""
+    _check_onv(onv, "onv", ht.sorb, (2,))
+    n = onv.size(0)
+    dev = ht.table.device
+    q = onv if onv.device == dev else onv.to(dev)
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    mask = torch.empty(n, dtype=torch.bool, device=dev)
+    if n:
+        N.check(N.lib().pynqs_hash_lookup(ht.table.data_ptr(), ht.nkeys, q.data_ptr(), n, ht.sorb, idx.data_ptr(), mask.data_ptr(),
+                                          _stream(dev)), "hash_lookup")
+    return (idx.cpu(), mask.cpu()) if onv.device.type == "cpu" else (idx, mask)
 
 
 _SPIN_FLIP_CALLS = 0

@@ -35,6 +35,10 @@ SIGNATURES = {
     "pynqs_plan_build": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_comb_hij_fused_plan": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
     "pynqs_eloc_sample_space": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
+    "pynqs_hash_bytes": (_i64, [_i64, _int]),
+    "pynqs_hash_build": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "pynqs_hash_lookup": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
+    "pynqs_eloc_sample_space_hash": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "pynqs_reduce_count": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp]),
     "pynqs_reduce_emit": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -180,6 +180,101 @@ __device__ __forceinline__ int64_t lut_find(const uint64_t *__restrict__ keys, i
   return -1;
 }
 
+// ---- hash table over the same keys (open addressing, linear probing, load factor <= 1/4) -----------
+// slot = 2 (one-word keys) or 4 (two/three-word keys) 64-bit words: the key words first, the LAST word is the
+// index into the sorted key array (-1 = empty).  A slot is read with 16-byte loads: one vector-memory
+// instruction per probe for one-word keys -- the fused local-energy kernel is bound by the number of such
+// instructions (TA busy 82 %, profiles/r01_fe2s2_eloc_sample_space_v1.txt), not by bytes.  The low load factor
+// keeps the wave-wide maximum probe count (which is what a wave pays) near 2.
+// Replaces the 15-24 dependent probes of the binary search (the reference has an optional GPU hash table for the
+// same purpose, cuda/hashTable.cu, disabled by USE_HASH = False in utils/public_function.py:23).
+typedef uint64_t hash_u64x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ inline uint64_t hash_capacity(int64_t nkeys) {
+  uint64_t c = 64;
+  while (c < 4 * (uint64_t)(nkeys > 0 ? nkeys : 1)) c <<= 1;
+  return c;
+}
+
+__host__ __device__ constexpr int hash_slot_words(int len) { return len == 1 ? 2 : 4; }
+
+__host__ __device__ inline uint64_t hash_mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+template <int LEN>
+__device__ __forceinline__ uint64_t hash_of(const uint64_t (&q)[LEN]) {
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) h = hash_mix(h ^ q[w]);
+  return h;
+}
+
+// First probe only: the slot content (to let a caller issue several independent first probes back to back).
+template <int LEN>
+struct HashProbe {
+  uint64_t w[hash_slot_words(LEN)];
+  uint64_t s;
+};
+
+template <int LEN>
+__device__ __forceinline__ HashProbe<LEN> hash_probe_first(const uint64_t *__restrict__ table, uint64_t cap,
+                                                           const uint64_t (&q)[LEN]) {
+  constexpr int W = hash_slot_words(LEN);
+  HashProbe<LEN> pr;
+  pr.s = hash_of<LEN>(q) & (cap - 1);
+  const hash_u64x2 *slot = reinterpret_cast<const hash_u64x2 *>(table + pr.s * W);
+#pragma unroll
+  for (int i = 0; i < W / 2; ++i) { const hash_u64x2 v = slot[i]; pr.w[2 * i] = v[0]; pr.w[2 * i + 1] = v[1]; }
+  return pr;
+}
+
+// Finish a lookup whose first slot has been read: almost always decided right away (load factor 1/4).
+template <int LEN>
+__device__ __forceinline__ int64_t hash_resolve(const HashProbe<LEN> &pr, const uint64_t *__restrict__ table, uint64_t cap,
+                                                const uint64_t (&q)[LEN]) {
+  constexpr int W = hash_slot_words(LEN);
+  uint64_t w[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) w[i] = pr.w[i];
+  uint64_t s = pr.s;
+  for (uint64_t probes = 0; probes < cap; ++probes) {
+    const int64_t idx = (int64_t)w[W - 1];
+    if (idx < 0) return -1;
+    bool eq = true;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) eq = eq && w[i] == q[i];
+    if (eq) return idx;
+    s = (s + 1) & (cap - 1);
+    const hash_u64x2 *slot = reinterpret_cast<const hash_u64x2 *>(table + s * W);
+#pragma unroll
+    for (int i = 0; i < W / 2; ++i) { const hash_u64x2 v = slot[i]; w[2 * i] = v[0]; w[2 * i + 1] = v[1]; }
+  }
+  return -1;
+}
+
+template <int LEN>
+__device__ __forceinline__ int64_t hash_find(const uint64_t *__restrict__ table, uint64_t cap, const uint64_t (&q)[LEN]) {
+  constexpr int W = hash_slot_words(LEN);
+  uint64_t s = hash_of<LEN>(q) & (cap - 1);
+  for (uint64_t probes = 0; probes < cap; ++probes) {  // bounded: terminates even on a full table
+    const hash_u64x2 *slot = reinterpret_cast<const hash_u64x2 *>(table + s * W);
+    uint64_t w[W];
+#pragma unroll
+    for (int i = 0; i < W / 2; ++i) { const hash_u64x2 v = slot[i]; w[2 * i] = v[0]; w[2 * i + 1] = v[1]; }
+    const int64_t idx = (int64_t)w[W - 1];
+    if (idx < 0) return -1;
+    bool eq = true;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) eq = eq && w[i] == q[i];
+    if (eq) return idx;
+    s = (s + 1) & (cap - 1);
+  }
+  return -1;
+}
+
 // ---- per-walker LDS state ------------------------------------------------------------------------
 // merged[sorb]  : onstate.cpp:147-193 slot list (u8 orbitals)
 // occv[nele]    : occupied orbitals in the order singles visit them (word ascending, bit 63 -> 0)

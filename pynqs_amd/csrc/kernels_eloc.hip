@@ -9,6 +9,7 @@
 #include "launch.h"
 #include "plan.h"
 #include "plan_dev.h"
+#include "plan_tiles.h"
 
 namespace pynqs {
 
@@ -49,10 +50,50 @@ __host__ __device__ inline size_t lds_bytes_eloc(const SDParams &p, size_t elem)
 }
 
 // -------------------------------------------------------------------------------------------------
-// SAMPLE_SPACE local energy.  acc[walker] += sum_cols h * psi(ket); the first chunk also stores psi(x).
-// One workgroup per (walker, chunk); with more than one chunk per walker partial sums meet through
-// float atomics (then the summation order, and the last bits, depend on arrival order).
-template <int LEN, bool CPLX>
+// SAMPLE_SPACE local energy: the tile scheduler of the drop-in kernel (plan_tiles.h) with a sink that, instead
+// of storing the column, looks psi(x') up and accumulates h * psi(x') in registers.  acc[walker] receives the
+// sum; the workgroup that owns column 0 also stores psi(x).  One workgroup per (walker, chunk); with more than
+// one chunk per walker partial sums meet through float atomics (the last bits then depend on arrival order).
+// HASH: `keys` is a hash table built by pynqs_hash_build (nkeys = its capacity) instead of the sorted keys.
+template <int LEN, bool CPLX, bool HASH>
+struct LookupSink {
+  const uint64_t *__restrict__ keys;
+  int64_t nkeys;
+  const double *__restrict__ wf;
+  double *__restrict__ psi0;  // this walker's psi(x) slot
+  double re, im;
+  __device__ __forceinline__ void add(uint32_t col, double h, const uint64_t (&ket)[LEN]) {
+    const int64_t pos = HASH ? hash_find<LEN>(keys, (uint64_t)nkeys, ket) : lut_find<LEN>(keys, nkeys, ket);
+    accumulate(col, h, pos);
+  }
+  __device__ __forceinline__ void accumulate(uint32_t col, double h, int64_t pos) {
+    double vr = 0.0, vi = 0.0;
+    if (pos >= 0) {
+      if constexpr (CPLX) { vr = wf[2 * pos]; vi = wf[2 * pos + 1]; }
+      else vr = wf[pos];
+    }
+    re += h * vr;
+    if constexpr (CPLX) im += h * vi;
+    if (col == 0) {
+      psi0[0] = vr;
+      if constexpr (CPLX) psi0[1] = vi;
+    }
+  }
+  __device__ __forceinline__ void one(uint32_t col, double h, const uint64_t (&ket)[LEN]) { add(col, h, ket); }
+  __device__ __forceinline__ void pair(uint32_t col, double h0, double h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) {
+    if constexpr (HASH) {  // both first probes in flight together
+      const HashProbe<LEN> p0 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k0);
+      const HashProbe<LEN> p1 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k1);
+      accumulate(col, h0, hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0));
+      accumulate(col + 1, h1, hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1));
+    } else {
+      add(col, h0, k0);
+      add(col + 1, h1, k1);
+    }
+  }
+};
+
+template <int LEN, bool CPLX, bool HASH>
 __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
                                                                    uint32_t nchunks, uint32_t chunk_len,
                                                                    const double *__restrict__ plan,
@@ -61,34 +102,21 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
                                                                    double *__restrict__ psi0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double red[2][kBlock / 64];
+  __shared__ uint32_t next_tile;
   const uint64_t wg = blockIdx.x;
   const uint64_t walker = wg / nchunks;
   const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
   const int tid = threadIdx.x;
+  if (tid == 0) next_tile = 0;
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
-  double *hs = reinterpret_cast<double *>(smem + lds_bytes(p, sizeof(double)));
-  const uint32_t ncomb = p.nsd + 1;
-  const uint32_t lo = chunk * chunk_len, hi = min(lo + chunk_len, ncomb);
-  if (lo <= p.d1) singles_and_diag_to_lds<LEN, double>(p, pl, L, nocc, plan, hs);
-
-  double re = 0.0, im = 0.0;
-  for (uint32_t col = lo + tid; col < hi; col += kBlock) {
-    uint64_t ket[LEN];
-    const double h = column_element<LEN, double>(col, p, pl, L, plan, wk, hs, ket);
-    const int64_t pos = lut_find<LEN>(keys, nkeys, ket);
-    if (pos >= 0) {
-      if constexpr (CPLX) { re += h * wf[2 * pos]; im += h * wf[2 * pos + 1]; }
-      else re += h * wf[pos];
-    }
-    if (col == 0) {
-      if constexpr (CPLX) { psi0[2 * walker] = pos >= 0 ? wf[2 * pos] : 0.0; psi0[2 * walker + 1] = pos >= 0 ? wf[2 * pos + 1] : 0.0; }
-      else psi0[walker] = pos >= 0 ? wf[pos] : 0.0;
-    }
-  }
-  // fixed-order reduction: lanes (xor butterfly), then waves
+  LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0};
+  visit_tiles<LEN, double>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+  double re = sink.re, im = sink.im;
+  // fixed-order reduction: lanes (xor butterfly), then waves.  (Which tile a wave gets is dynamic, so the
+  // order of the additions inside a lane, and with it the last bits of the sum, can vary from run to run.)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     re += __shfl_xor(re, o);
@@ -107,6 +135,44 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
       else atomicAdd(acc + walker, sr);
     }
   }
+}
+
+// Insert key i of the sorted key array: claim a slot by CAS on its index word, then write the key words
+// (lookups only start after the build kernel has finished).
+template <int LEN>
+__global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__restrict__ keys, int64_t nkeys, uint64_t cap,
+                                                            uint64_t *__restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nkeys) return;
+  uint64_t q[LEN];
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) q[w] = keys[i * LEN + w];
+  constexpr int W = hash_slot_words(LEN);
+  uint64_t s = hash_of<LEN>(q) & (cap - 1);
+  for (uint64_t probes = 0; probes < cap; ++probes) {
+    unsigned long long *idxp = reinterpret_cast<unsigned long long *>(table + s * W + (W - 1));
+    const unsigned long long old = atomicCAS(idxp, ~0ull, (unsigned long long)i);
+    if (old == ~0ull) {
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) table[s * W + w] = q[w];
+      return;
+    }
+    s = (s + 1) & (cap - 1);
+  }
+}
+
+template <int LEN>
+__global__ __launch_bounds__(kBlock) void hash_lookup_kernel(const uint64_t *__restrict__ table, uint64_t cap,
+                                                             const uint64_t *__restrict__ onv, uint64_t n,
+                                                             int64_t *__restrict__ idx, uint8_t *__restrict__ mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint64_t q[LEN];
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) q[w] = onv[i * LEN + w];
+  const int64_t r = hash_find<LEN>(table, cap, q);
+  idx[i] = r;
+  mask[i] = r >= 0;
 }
 
 // eloc = acc / psi0 (complex division when CPLX), in place on acc
@@ -197,9 +263,9 @@ static int eloc_common_checks(int sorb, int nele, int noA, int noB, int64_t nbat
   return PYNQS_OK;
 }
 
-extern "C" int pynqs_eloc_sample_space(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
-                                       const void *plan, const uint64_t *keys, int64_t nkeys, const double *wf,
-                                       int wf_is_complex, double *eloc, double *psi0, void *stream) {
+static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                                  const uint64_t *keys, int64_t nkeys, bool hash, const double *wf, int wf_is_complex,
+                                  double *eloc, double *psi0, void *stream) {
   SDParams p;
   PlanLayout pl;
   int rc = eloc_common_checks(sorb, nele, noA, noB, nbatch, &p, &pl);
@@ -210,25 +276,72 @@ extern "C" int pynqs_eloc_sample_space(const uint64_t *bra, int64_t nbatch, int 
   hipStream_t st = (hipStream_t)stream;
   uint32_t nchunks, chunk_len;
   plan_chunks(nbatch, p.nsd + 1, &nchunks, &chunk_len);
-  const size_t lds = lds_bytes_eloc(p, sizeof(double));
-  if (lds > 64 * 1024) return set_error(PYNQS_EINVAL, "too many single excitations for the LDS staging buffer");
+  const size_t lds = lds_bytes(p, sizeof(double));
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   const double *pd = (const double *)plan;
+  const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
+#define PYNQS_SS_LAUNCH(C, H)                                                                                              \
+  hipLaunchKernelGGL((eloc_sample_space_kernel<LEN, C, H>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, \
+                     chunk_len, pd, keys, size_arg, wf, eloc, psi0)
   DISPATCH_LEN(len, {
-    if (wf_is_complex)
-      hipLaunchKernelGGL((eloc_sample_space_kernel<LEN, true>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                         chunk_len, pd, keys, nkeys, wf, eloc, psi0);
-    else
-      hipLaunchKernelGGL((eloc_sample_space_kernel<LEN, false>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                         chunk_len, pd, keys, nkeys, wf, eloc, psi0);
+    if (wf_is_complex) { if (hash) PYNQS_SS_LAUNCH(true, true); else PYNQS_SS_LAUNCH(true, false); }
+    else { if (hash) PYNQS_SS_LAUNCH(false, true); else PYNQS_SS_LAUNCH(false, false); }
   });
+#undef PYNQS_SS_LAUNCH
   const uint32_t g2 = (uint32_t)((nbatch + kBlock - 1) / kBlock);
   if (wf_is_complex) hipLaunchKernelGGL((eloc_divide_kernel<true>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
   else hipLaunchKernelGGL((eloc_divide_kernel<false>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
   return check_launch("eloc_sample_space");
+}
+
+extern "C" int pynqs_eloc_sample_space(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                       const void *plan, const uint64_t *keys, int64_t nkeys, const double *wf,
+                                       int wf_is_complex, double *eloc, double *psi0, void *stream) {
+  return eloc_sample_space_impl(bra, nbatch, sorb, nele, noA, noB, plan, keys, nkeys, false, wf, wf_is_complex, eloc, psi0, stream);
+}
+
+extern "C" int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                            const void *plan, const void *table, int64_t nkeys, const double *wf,
+                                            int wf_is_complex, double *eloc, double *psi0, void *stream) {
+  return eloc_sample_space_impl(bra, nbatch, sorb, nele, noA, noB, plan, (const uint64_t *)table, nkeys, true, wf, wf_is_complex,
+                                eloc, psi0, stream);
+}
+
+extern "C" int64_t pynqs_hash_bytes(int64_t nkeys, int sorb) {
+  if (nkeys < 0 || sorb < 1 || sorb > kMaxSorb) return -1;
+  const int len = (sorb - 1) / 64 + 1;
+  return (int64_t)(hash_capacity(nkeys) * (uint64_t)hash_slot_words(len) * 8);
+}
+
+extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, void *table, void *stream) {
+  if (nkeys < 0 || sorb < 1 || sorb > kMaxSorb) return set_error(PYNQS_EINVAL, "bad nkeys/sorb");
+  if (!table || (nkeys > 0 && !keys)) return set_error(PYNQS_EINVAL, "null pointer");
+  const int len = (sorb - 1) / 64 + 1;
+  const uint64_t cap = hash_capacity(nkeys);
+  hipStream_t st = (hipStream_t)stream;
+  if ((uintptr_t)table & 15u) return set_error(PYNQS_EINVAL, "table must be 16-byte aligned");
+  if (hipMemsetAsync(table, 0xFF, cap * (size_t)hash_slot_words(len) * 8, st) != hipSuccess) return check_launch("hash memset");
+  if (nkeys == 0) return PYNQS_OK;
+  const uint32_t grid = (uint32_t)((nkeys + kBlock - 1) / kBlock);
+  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table));
+  return check_launch("hash_build");
+}
+
+extern "C" int pynqs_hash_lookup(const void *table, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb, int64_t *idx,
+                                 uint8_t *mask, void *stream) {
+  if (nkeys < 0 || n < 0 || sorb < 1 || sorb > kMaxSorb) return set_error(PYNQS_EINVAL, "bad nkeys/n/sorb");
+  if (n == 0) return PYNQS_OK;
+  if (!table || !onv || !idx || !mask) return set_error(PYNQS_EINVAL, "null pointer");
+  const int len = (sorb - 1) / 64 + 1;
+  const uint64_t grid = ((uint64_t)n + kBlock - 1) / kBlock;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "n too large for one launch");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_lookup_kernel<LEN>), dim3((uint32_t)grid), dim3(kBlock), 0, st, (const uint64_t *)table,
+                                       hash_capacity(nkeys), onv, (uint64_t)n, idx, mask));
+  return check_launch("hash_lookup");
 }
 
 template <bool EMIT>

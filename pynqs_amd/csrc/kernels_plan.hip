@@ -12,6 +12,7 @@
 #include "launch.h"
 #include "plan.h"
 #include "plan_dev.h"
+#include "plan_tiles.h"
 
 namespace pynqs {
 
@@ -100,56 +101,21 @@ __device__ __forceinline__ void store_ket2(uint64_t *__restrict__ crow, uint32_t
   for (int i = 0; i < LEN; ++i) { u64x2 v = {w[2 * i], w[2 * i + 1]}; dst[i] = v; }
 }
 
-#ifndef PYNQS_U
-#define PYNQS_U 2
-#endif
-
-// One class of doubles restricted to this workgroup's rank range, cut into pair slots:
-// slot m = ranks (r_e + 2m, r_e + 2m + 1).  `odd_base` = parity of the walker's first element index
-// (walker * ncomb): r_e is the first rank whose column has an even element index, so that the 16-byte stores
-// of a slot are aligned; at most one leading and one trailing column have no partner (8-byte stores).
-struct ClassRange {
-  uint32_t a0, a1;   // ranks [a0, a1)
-  uint32_t r_e;      // first paired rank
-  uint32_t npairs;   // complete pairs
+// The drop-in kernel: every column of the walker's range goes to HBM (comb and Hmat in the reference layout).
+template <int LEN, typename T, bool WRITE_COMB>
+struct StoreSink {
+  T *__restrict__ hrow;
+  uint64_t *__restrict__ crow;
+  __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&ket)[LEN]) const {
+    store_h<T>(hrow, col, h);
+    if constexpr (WRITE_COMB) store_ket<LEN>(crow, col, ket);
+  }
+  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) const {
+    store_h2<T>(hrow, col, h0, h1);
+    if constexpr (WRITE_COMB) store_ket2<LEN>(crow, col, k0, k1);
+  }
 };
 
-__device__ __forceinline__ ClassRange class_range(uint32_t b0, uint32_t b1, uint32_t rlo, uint32_t rhi, uint32_t odd_base) {
-  ClassRange g;
-  g.a0 = max(rlo, b0);
-  g.a1 = max(g.a0, min(rhi, b1));
-  g.r_e = g.a0 + ((odd_base + g.a0 + 1) & 1u);
-  g.npairs = g.a1 > g.r_e ? (g.a1 - g.r_e) / 2 : 0;
-  return g;
-}
-
-template <int LEN, typename T, bool WRITE_COMB>
-__device__ __forceinline__ void emit_one(uint32_t r, const DoubleClass &c, const LdsLayout &L, const T *__restrict__ V,
-                                         const Walker<LEN> &wk, T *__restrict__ hrow, uint64_t *__restrict__ crow) {
-  uint64_t ket[LEN];
-  const PendingDouble<T> d = fetch_double<LEN, T>(r, c, L, V);
-  const T h = finish_double<LEN, T>(d, c, wk, ket);
-  store_h<T>(hrow, r + 1, h);
-  if constexpr (WRITE_COMB) store_ket<LEN>(crow, r + 1, ket);
-}
-
-template <int LEN, typename T, bool WRITE_COMB>
-__device__ __forceinline__ void emit_pair(const PendingDouble<T> &d0, const PendingDouble<T> &d1, uint32_t col,
-                                          const DoubleClass &c, const Walker<LEN> &wk, T *__restrict__ hrow,
-                                          uint64_t *__restrict__ crow) {
-  uint64_t k0[LEN], k1[LEN];
-  const T h0 = finish_double<LEN, T>(d0, c, wk, k0);
-  const T h1 = finish_double<LEN, T>(d1, c, wk, k1);
-  store_h2<T>(hrow, col, h0, h1);
-  if constexpr (WRITE_COMB) store_ket2<LEN>(crow, col, k0, k1);
-}
-
-// Work distribution inside a workgroup.  After the (workgroup-wide) table build there is NO barrier: every wave
-// pulls tiles from an LDS counter until none is left.  Tile 0 holds the odd jobs (the few unpaired columns and
-// column 0 with its ordered diagonal sum, ~4k cycles of one lane), then come tiles of 64 singles (one per lane,
-// ordered sum in registers), then tiles of 64*U pair slots of the doubles (classes padded to whole tiles).
-// Earlier versions ran singles and diagonal as workgroup-wide, barrier-separated phases: 2 % of the columns
-// cost 0.08-0.1 ms of a 0.26 ms kernel (tools/ab.sh ablations).
 template <int LEN, typename T, bool WRITE_COMB>
 __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
                                                                uint32_t nchunks, uint32_t chunk_len,
@@ -157,103 +123,18 @@ __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *_
                                                                T *__restrict__ hmat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t next_tile;
-  constexpr int U = PYNQS_U;                 // pair slots per lane and tile (2*U gathers in flight)
-  constexpr uint32_t kTile = 64u * U;        // pair slots per tile
   const uint64_t wg = blockIdx.x;
   const uint64_t walker = wg / nchunks;
   const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) next_tile = 0;
+  if (threadIdx.x == 0) next_tile = 0;
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a workgroup barrier
-
   const uint32_t ncomb = p.nsd + 1;
-  const uint32_t lo = chunk * chunk_len;
-  const uint32_t hi = min(lo + chunk_len, ncomb);
-  // excitation ranks handled here: [rlo, rhi) (column k = rank + 1)
-  const uint32_t rlo = lo == 0 ? 0 : lo - 1, rhi = hi - 1;
-  T *__restrict__ hrow = hmat + (size_t)walker * ncomb;
-  uint64_t *__restrict__ crow = comb + (size_t)walker * ncomb * LEN;
-  const uint32_t odd_base = (uint32_t)((walker * (uint64_t)ncomb) & 1u);
-
-  const ClassRange gA = class_range(p.d1, p.d2, rlo, rhi, odd_base);
-  const ClassRange gB = class_range(p.d2, p.d3, rlo, rhi, odd_base);
-  const ClassRange gO = class_range(p.d3, p.nsd, rlo, rhi, odd_base);
-  const uint32_t tA = (gA.npairs + kTile - 1) / kTile, tB = (gB.npairs + kTile - 1) / kTile, tO = (gO.npairs + kTile - 1) / kTile;
-  // The singles tiles of the walker are dealt round-robin to its workgroups (they cost far more per column
-  // than doubles; left to the first chunk they would make it the straggler when rows are cut into many chunks).
-  const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
-  const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
-  // tile 0 = the odd jobs (unpaired columns, column 0 with the ordered diagonal sum), then singles, then doubles
-  const uint32_t ntiles = 1 + tS + tA + tB + tO;
-  const T *__restrict__ Vss = plan + pl.offVss;
-  const T *__restrict__ Vab = plan + pl.offVab;
-  (void)wave;
-
-  for (;;) {
-    uint32_t tile = 0;
-    if (lane == 0) tile = atomicAdd(&next_tile, 1u);
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    if (tile >= ntiles) break;
-    if (tile == 0) {
-      // unpaired columns of the three classes: lanes 0..5
-      if (lane < 6) {
-        const int k = lane >> 1;
-        const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
-        const uint32_t tail = g.r_e + 2 * g.npairs;
-        const bool head = (lane & 1) == 0;
-        if (head ? (g.r_e > g.a0 && g.a0 < g.a1) : (tail < g.a1)) {
-          const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
-          emit_one<LEN, T, WRITE_COMB>(head ? g.a0 : tail, c, L, k == 2 ? Vab : Vss + (size_t)k * pl.NP * pl.NP, wk, hrow, crow);
-        }
-      }
-      if (lo == 0) {
-        if constexpr (WRITE_COMB) {
-          if (lane < LEN) crow[lane] = pick<LEN>(wk.w, lane);
-        }
-        diag_wave<T>(p, pl, L, plan, [&](T v) { hrow[0] = v; });  // the only user of L.scratch in this kernel
-      }
-      continue;
-    }
-    if (tile <= tS) {
-      const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSinglesPerTile;
-      singles_tile<T>(r0, min(r0 + kSinglesPerTile, p.d1), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
-        store_h<T>(hrow, r + 1, v);
-        if constexpr (WRITE_COMB) {
-          uint64_t ket[LEN];
-#pragma unroll
-          for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
-          toggle<LEN>(ket, e & 0xff);
-          toggle<LEN>(ket, (e >> 8) & 0xff);
-          store_ket<LEN>(crow, r + 1, ket);
-        }
-      });
-      continue;
-    }
-    tile -= 1 + tS;
-    // which class (wave-uniform)
-    const int k = tile < tA ? 0 : (tile < tA + tB ? 1 : 2);
-    const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
-    const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kTile;  // first pair slot of the tile
-    const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
-    const T *__restrict__ V = k == 2 ? Vab : Vss + (size_t)k * pl.NP * pl.NP;
-    if (first + kTile <= g.npairs) {  // full tile: no guards
-      PendingDouble<T> d[U][2];
-#pragma unroll
-      for (int u = 0; u < U; ++u) fetch_double2<LEN, T>(g.r_e + 2 * (first + u * 64 + lane), c, L, V, d[u][0], d[u][1]);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        emit_pair<LEN, T, WRITE_COMB>(d[u][0], d[u][1], g.r_e + 2 * (first + u * 64 + lane) + 1, c, wk, hrow, crow);
-    } else {
-      for (uint32_t m = first + lane; m < g.npairs; m += 64) {
-        PendingDouble<T> d0, d1;
-        fetch_double2<LEN, T>(g.r_e + 2 * m, c, L, V, d0, d1);
-        emit_pair<LEN, T, WRITE_COMB>(d0, d1, g.r_e + 2 * m + 1, c, wk, hrow, crow);
-      }
-    }
-  }
+  StoreSink<LEN, T, WRITE_COMB> sink{hmat + (size_t)walker * ncomb, comb + (size_t)walker * ncomb * LEN};
+  const uint32_t odd_base = (uint32_t)((walker * (uint64_t)ncomb) & 1u);  // 16-byte alignment of the pair stores
+  visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, odd_base, &next_tile, sink);
 }
 
 }  // namespace pynqs

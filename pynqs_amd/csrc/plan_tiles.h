@@ -1,0 +1,146 @@
+// plan_tiles.h -- the tile scheduler shared by the plan-based kernels: visits every column of a walker's
+// row range exactly once and hands (column, <x|H|x'>, ket) to a sink.  The drop-in kernel's sink stores to
+// comb / Hmat (kernels_plan.hip); the fused local-energy kernel's sink looks psi(x') up and accumulates
+// (kernels_eloc.hip).
+//
+// Work distribution inside a workgroup.  After the (workgroup-wide) table build there is NO barrier: every wave
+// pulls tiles from an LDS counter until none is left.  Tile 0 holds the odd jobs (the few unpaired columns and
+// column 0 with its ordered diagonal sum, ~4k cycles of one lane), then come tiles of kSinglesPerTile singles
+// (coalesced gather staged in the wave's private LDS quarter, ordered sum by one lane per single), then tiles of
+// 64*U pair slots of the doubles (classes padded to whole tiles; a lane produces two consecutive columns).
+// Earlier versions ran singles and diagonal as workgroup-wide, barrier-separated phases: 2 % of the columns
+// cost 0.08-0.1 ms of a 0.26 ms kernel (tools/ab.sh ablations).
+#pragma once
+
+#include "detcore.h"
+#include "plan.h"
+#include "plan_dev.h"
+
+namespace pynqs {
+
+#ifndef PYNQS_U
+#define PYNQS_U 2
+#endif
+
+// One class of doubles restricted to this workgroup's rank range, cut into pair slots:
+// slot m = ranks (r_e + 2m, r_e + 2m + 1).  `odd_base` = parity of the walker's first element index
+// (walker * ncomb): r_e is the first rank whose column has an even element index, so that 16-byte stores of a
+// slot are aligned; at most one leading and one trailing column have no partner.
+struct ClassRange {
+  uint32_t a0, a1;   // ranks [a0, a1)
+  uint32_t r_e;      // first paired rank
+  uint32_t npairs;   // complete pairs
+};
+
+__device__ __forceinline__ ClassRange class_range(uint32_t b0, uint32_t b1, uint32_t rlo, uint32_t rhi, uint32_t odd_base) {
+  ClassRange g;
+  g.a0 = max(rlo, b0);
+  g.a1 = max(g.a0, min(rhi, b1));
+  g.r_e = g.a0 + ((odd_base + g.a0 + 1) & 1u);
+  g.npairs = g.a1 > g.r_e ? (g.a1 - g.r_e) / 2 : 0;
+  return g;
+}
+
+// Sink concept:
+//   void one(uint32_t col, T h, const uint64_t (&ket)[LEN]);                       // a single column
+//   void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]);  // col, col+1
+// `next_tile` is a workgroup-shared counter that must be 0 when the first wave arrives (set it before
+// build_walker_tables, whose final barrier publishes it).
+template <int LEN, typename T, typename Sink>
+__device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
+                                            const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
+                                            uint32_t chunk_len, uint32_t odd_base, uint32_t *next_tile, Sink &sink) {
+  constexpr int U = PYNQS_U;           // pair slots per lane and tile (2*U gathers in flight)
+  constexpr uint32_t kTile = 64u * U;  // pair slots per tile
+  const int lane = threadIdx.x & 63;
+  const uint32_t ncomb = p.nsd + 1;
+  const uint32_t lo = chunk * chunk_len;
+  const uint32_t hi = min(lo + chunk_len, ncomb);
+  const uint32_t rlo = lo == 0 ? 0 : lo - 1, rhi = hi - 1;  // excitation ranks [rlo, rhi): column = rank + 1
+
+  const ClassRange gA = class_range(p.d1, p.d2, rlo, rhi, odd_base);
+  const ClassRange gB = class_range(p.d2, p.d3, rlo, rhi, odd_base);
+  const ClassRange gO = class_range(p.d3, p.nsd, rlo, rhi, odd_base);
+  const uint32_t tA = (gA.npairs + kTile - 1) / kTile, tB = (gB.npairs + kTile - 1) / kTile, tO = (gO.npairs + kTile - 1) / kTile;
+  // The singles tiles of the walker are dealt round-robin to its workgroups (they cost far more per column
+  // than doubles; left to the first chunk they would make it the straggler when rows are cut into many chunks).
+  const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+  const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
+  const uint32_t ntiles = 1 + tS + tA + tB + tO;
+  const T *__restrict__ Vss = plan + pl.offVss;
+  const T *__restrict__ Vab = plan + pl.offVab;
+
+  auto emit_pair = [&](const PendingDouble<T> &d0, const PendingDouble<T> &d1, uint32_t col, const DoubleClass &c) {
+    uint64_t k0[LEN], k1[LEN];
+    const T h0 = finish_double<LEN, T>(d0, c, wk, k0);
+    const T h1 = finish_double<LEN, T>(d1, c, wk, k1);
+    sink.pair(col, h0, h1, k0, k1);
+  };
+
+  for (;;) {
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(next_tile, 1u);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (tile >= ntiles) break;
+    if (tile == 0) {
+      // unpaired columns of the three classes: lanes 0..5
+      if (lane < 6) {
+        const int k = lane >> 1;
+        const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
+        const uint32_t tail = g.r_e + 2 * g.npairs;
+        const bool head = (lane & 1) == 0;
+        if (head ? (g.r_e > g.a0 && g.a0 < g.a1) : (tail < g.a1)) {
+          const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
+          const uint32_t r = head ? g.a0 : tail;
+          uint64_t ket[LEN];
+          const PendingDouble<T> d = fetch_double<LEN, T>(r, c, L, k == 2 ? Vab : Vss + (size_t)k * pl.NP * pl.NP);
+          const T h = finish_double<LEN, T>(d, c, wk, ket);
+          sink.one(r + 1, h, ket);
+        }
+      }
+      if (lo == 0) {
+        diag_wave<T>(p, pl, L, plan, [&](T v) {
+          uint64_t ket[LEN];
+#pragma unroll
+          for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+          sink.one(0u, v, ket);
+        });
+      }
+      continue;
+    }
+    if (tile <= tS) {
+      const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSinglesPerTile;
+      singles_tile<T>(r0, min(r0 + kSinglesPerTile, p.d1), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
+        uint64_t ket[LEN];
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+        toggle<LEN>(ket, e & 0xff);
+        toggle<LEN>(ket, (e >> 8) & 0xff);
+        sink.one(r + 1, v, ket);
+      });
+      continue;
+    }
+    tile -= 1 + tS;
+    // which class (wave-uniform)
+    const int k = tile < tA ? 0 : (tile < tA + tB ? 1 : 2);
+    const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
+    const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kTile;  // first pair slot of the tile
+    const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
+    const T *__restrict__ V = k == 2 ? Vab : Vss + (size_t)k * pl.NP * pl.NP;
+    if (first + kTile <= g.npairs) {  // full tile: no guards
+      PendingDouble<T> d[U][2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) fetch_double2<LEN, T>(g.r_e + 2 * (first + u * 64 + lane), c, L, V, d[u][0], d[u][1]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) emit_pair(d[u][0], d[u][1], g.r_e + 2 * (first + u * 64 + lane) + 1, c);
+    } else {
+      for (uint32_t m = first + lane; m < g.npairs; m += 64) {
+        PendingDouble<T> d0, d1;
+        fetch_double2<LEN, T>(g.r_e + 2 * m, c, L, V, d0, d1);
+        emit_pair(d0, d1, g.r_e + 2 * m + 1, c);
+      }
+    }
+  }
+}
+
+}  // namespace pynqs

@@ -4,7 +4,7 @@ Hot-path names come from pynqs_amd.C_extension.  Names of the reference module t
 local-energy path are present so that `vmc/sample.py:19-26` and `utils/public_function.py:17`
 import cleanly; the ones not implemented raise NotImplementedError when CALLED, never at import."""
 from pynqs_amd.C_extension import (MAX_NELE, MAX_SORB, MAX_SORB_LEN, check_sorb, compress_h1e_h2e,  # noqa: F401
-                                   decompress_h1e_h2e, get_comb_hij_fused, get_comb_tensor, get_hij_torch,
+                                   decompress_h1e_h2e, get_comb_hij_fused, hash_build, hash_lookup, HashTable, get_comb_tensor, get_hij_torch,
                                    merge_rank_sample, onv_to_tensor, spin_flip_rand, tensor_to_onv, wavefunction_lut)
 
 

@@ -149,8 +149,13 @@ def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT) -> Tuple[Tens
     eloc = torch.empty(n, dtype=WF_LUT.dtype, device=dev)
     psi0 = torch.empty(n, dtype=WF_LUT.dtype, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
-    rc = N.lib().pynqs_eloc_sample_space(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
-                                         WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+    ht = getattr(WF_LUT, "hashtable", None)
+    if ht is not None:  # 1-2 probes per x' instead of log2(nkeys) dependent ones
+        rc = N.lib().pynqs_eloc_sample_space_hash(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
+                                                  ht.nkeys, wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+    else:
+        rc = N.lib().pynqs_eloc_sample_space(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
+                                             WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
     N.check(rc, "pynqs_eloc_sample_space")
     return eloc, psi0
 

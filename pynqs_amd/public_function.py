@@ -15,6 +15,8 @@ from . import C_extension as CX
 from .C_extension import get_Num_SinglesDoubles, onv_to_tensor, wavefunction_lut  # noqa: F401 (re-exported)
 from .distributed import get_rank, get_world_size
 
+USE_HASH = True  # WavefunctionLUT keeps a GPU hash table next to the sorted keys (reference: USE_HASH = False, :23)
+
 
 def check_para(bra: Tensor) -> None:
     """utils/public_function.py: onv tensors must be uint8."""
@@ -84,6 +86,9 @@ class WavefunctionLUT:
             self._bra_key = bra_key.to(device).contiguous()
             self._wf_value = wf_value.to(device)
         self.sorb = sorb
+        self.hashtable = None
+        if USE_HASH and self._bra_key.is_cuda and self._bra_key.size(0) > 0:
+            self.hashtable = CX.hash_build(self._bra_key, sorb)  # values = positions in the sorted key array
         self.rank = get_rank()
         self.world_size = get_world_size()
         rank_idx = [0] + split_length_idx(bra_key.size(0), self.world_size)
@@ -106,6 +111,7 @@ class WavefunctionLUT:
     def to(self, device) -> None:
         self._bra_key = self._bra_key.to(device=device)
         self._wf_value = self._wf_value.to(device=device)
+        self.hashtable = CX.hash_build(self._bra_key, self.sorb) if (USE_HASH and self._bra_key.is_cuda) else None
 
     @property
     def memory(self) -> float:
@@ -115,7 +121,10 @@ class WavefunctionLUT:
         """(indices of onv found, indices not found, psi of the found ones) -- public_function.py:817-838."""
         nbatch = onv.size(0)
         baseline = torch.arange(nbatch, device=onv.device, dtype=torch.int64)
-        idx_array, mask = wavefunction_lut(self._bra_key, onv, self.sorb)
+        if self.hashtable is not None and onv.is_cuda:
+            idx_array, mask = CX.hash_lookup(self.hashtable, onv)
+        else:
+            idx_array, mask = wavefunction_lut(self._bra_key, onv, self.sorb)
         idx_array, mask = idx_array.to(onv.device), mask.to(onv.device)
         onv_idx = baseline[mask]
         onv_not_idx = baseline[torch.logical_not(mask)]

@@ -145,6 +145,11 @@ def test_wavefunction_lut(cx):
         assert np.array_equal(idx.cpu().numpy(), d[k + "_idx"]) and np.array_equal(mask.cpu().numpy(), d[k + "_mask"])
         i2, m2 = cx.wavefunction_lut(torch.from_numpy(d[k + "_keys"]), G(d[k + "_query"]), sorb)
         assert i2.device.type == "cpu" and np.array_equal(i2.numpy(), d[k + "_idx"])
+        # the hash table returns the same positions
+        ht = cx.hash_build(G(d[k + "_keys"]), sorb)
+        i3, m3 = cx.hash_lookup(ht, G(d[k + "_query"]))
+        assert np.array_equal(i3.cpu().numpy(), d[k + "_idx"]) and np.array_equal(m3.cpu().numpy(), d[k + "_mask"])
+        assert ht.memory >= 4 * d[k + "_keys"].shape[0] * 16
 
 
 def test_random_against_oracle(cx):
