@@ -394,6 +394,35 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # pragma: no cover  (keeps the primary line intact)
                 extra[name] = {"error": repr(e)}
+        # the generic amplitude path: psi(x') by a PyTorch-ROCm module (real RBM, alpha = 2) through
+        # pynqs_amd.energy.local_energy -- SIMPLE (every column) and REDUCE (eps = 1e-2, the Fe2S2 example's setting)
+        try:
+            from pynqs_amd import energy as E, public_function as pf
+            from pynqs_amd.rbm import RealRBM
+
+            d = load_fe2s2()
+            sorb, nele, noA, noB = int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"])
+            g = torch.Generator().manual_seed(7)
+            rbm = RealRBM(0.01 * (torch.rand(2 * sorb, sorb, generator=g, dtype=torch.float64) - 0.5),
+                          0.01 * (torch.rand(2 * sorb, generator=g, dtype=torch.float64) - 0.5),
+                          0.1 * (torch.rand(sorb, generator=g, dtype=torch.float64) - 0.5)).to(dev)
+            h1g, h2g = torch.from_numpy(d["h1e"]).to(dev), torch.from_numpy(d["h2e"]).to(dev)
+            old_default = torch.get_default_dtype()
+            torch.set_default_dtype(torch.float64)
+            for tag, nw, kw in (("fe2s2_eloc_simple_rbm_torch", 512, {}), ("fe2s2_eloc_reduce_eps1e-2_rbm_torch", 8192, {"reduce_psi": True, "eps": 1e-2})):
+                xg = torch.from_numpy(np.ascontiguousarray(d["ci_space"][:nw])).to(dev)
+                fn = lambda: E.total_energy(xg, nw, 2_000_000, h1g, h2g, rbm, sorb, nele, noA, noB, use_unique=False, **kw)
+                fn(); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter(); reps = 3
+                for _ in range(reps):
+                    e_, _, _ = fn()
+                torch.cuda.synchronize(dev)
+                el3 = (time.perf_counter() - t0) / reps
+                extra[tag] = {"value": nw / el3, "unit": "local energies/s", "walkers": nw, "ms_per_step": el3 * 1e3,
+                              "mean_eloc": float(e_.mean().item())}
+            torch.set_default_dtype(old_default)
+        except Exception as e:  # pragma: no cover
+            extra["fe2s2_eloc_rbm_torch"] = {"error": repr(e)}
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out))
