@@ -95,7 +95,7 @@ __device__ __forceinline__ void diag_phase_plan(const SDParams &p, const PlanLay
   if (tid == kBlock - 1) sink(acc);
 }
 
-// ---- wave-private variants ---------------------------------------------------------------------------------
+// ---- wave-private variants (used by the tile scheduler, plan_tiles.h) ------------------------------------------
 // The same two computations carried out by ONE wave with no workgroup barrier, so that the other waves of the
 // workgroup can run the doubles meanwhile (ablation, profiles/: with workgroup-wide phases the singles and
 // the diagonal, 2 % of the columns, cost 0.08 ms of a 0.26 ms kernel in barrier-separated, mostly idle steps).
@@ -105,76 +105,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <typename T, typename Sink>
-__device__ __forceinline__ void singles_wave(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
-                                             const T *__restrict__ plan, uint32_t s_lo, uint32_t s_hi, Sink sink) {
-  if (s_lo >= s_hi) return;
-  const int lane = threadIdx.x & 63;
-  const uint32_t K = (uint32_t)pl.K;
-  T *tile = reinterpret_cast<T *>(L.scratch);
-  const int stride = nocc | 1;
-  const int per_tile = max(1, min(64, kDiagTile / stride));  // one summing lane per staged single
-  const T *__restrict__ S2 = plan + pl.offS2;
-  const T *__restrict__ S1 = plan + pl.offS1;
-  const int G = nocc <= 16 ? 16 : (nocc <= 32 ? 32 : 64);
-  const int gshift = nocc <= 16 ? 4 : (nocc <= 32 ? 5 : 6);
-  const int per_iter = 64 >> gshift;
-  const int my_s = lane >> gshift, my_j = lane & (G - 1);
-  for (uint32_t t0 = s_lo; t0 < s_hi; t0 += per_tile) {
-    const int cnt = (int)min((uint32_t)per_tile, s_hi - t0);
-    // gather: 4 independent requests in flight per lane before the LDS writes (one wave has to hide the
-    // L2 latency by itself)
-    for (int sl0 = my_s; sl0 < cnt; sl0 += 4 * per_iter) {
-      T val[4];
-      bool ok[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int sl = sl0 + u * per_iter;
-        ok[u] = sl < cnt && my_j < nocc;
-        val[u] = T(0);
-        if (ok[u]) {
-          const uint32_t r = t0 + sl;
-          const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-          const uint32_t spin = r >= p.d0;
-          const uint32_t hm = (e & 0xff) >> 1, qm = ((e >> 8) & 0xff) >> 1;
-          val[u] = S2[((size_t)(spin * K + hm) * K + qm) * p.sorb + L.occv[my_j]];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ok[u]) tile[(sl0 + u * per_iter) * stride + my_j] = val[u];
-    }
-    if (nocc > 64) {  // more electrons than lanes: remaining terms of each single
-      for (int sl = 0; sl < cnt; ++sl) {
-        const uint32_t r = t0 + sl;
-        const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-        const uint32_t spin = r >= p.d0;
-        const uint32_t hm = (e & 0xff) >> 1, qm = ((e >> 8) & 0xff) >> 1;
-        const T *__restrict__ rowp = S2 + ((size_t)(spin * K + hm) * K + qm) * p.sorb;
-        for (int j = 64 + lane; j < nocc; j += 64) tile[sl * stride + j] = rowp[L.occv[j]];
-      }
-    }
-    wave_sync();
-    if (lane < cnt) {
-      const uint32_t r = t0 + lane;
-      const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-      const uint32_t spin = r >= p.d0;
-      const int h = e & 0xff, q = (e >> 8) & 0xff;
-      T acc = T(0);
-      acc += S1[(size_t)(spin * K + (h >> 1)) * K + (q >> 1)];
-      const T *__restrict__ mine = tile + lane * stride;
-      int j = 0;
-      for (; j + 4 <= nocc; j += 4) {  // same order of additions; the four LDS reads are issued together
-        const T t0_ = mine[j], t1_ = mine[j + 1], t2_ = mine[j + 2], t3_ = mine[j + 3];
-        acc += t0_; acc += t1_; acc += t2_; acc += t3_;
-      }
-      for (; j < nocc; ++j) acc += mine[j];
-      sink(r, ((e >> 16) & 1u) ? -acc : acc, h, q);
-    }
-    wave_sync();
-  }
 }
 
 template <typename T, typename Sink>
@@ -314,29 +244,6 @@ __device__ __forceinline__ void singles_tile(uint32_t r0, uint32_t r_end, const 
     }
     wave_sync();
   }
-}
-
-// One single excitation per lane, no staging: the lane walks its own S2 row (nocc gathers, 8 in flight) and
-// adds in the reference's order.  Each wave instruction touches up to 64 different lines, but they are the
-// same ~3 lines per lane for the whole walk (L1/L2 hits) and there is no barrier and no LDS round trip.
-template <typename T>
-__device__ __forceinline__ T single_direct(uint32_t e, uint32_t spin, const SDParams &p, const PlanLayout &pl,
-                                           const LdsLayout &L, int nocc, const T *__restrict__ plan) {
-  const uint32_t K = (uint32_t)pl.K;
-  const uint32_t hm = (e & 0xff) >> 1, qm = ((e >> 8) & 0xff) >> 1;
-  const T *__restrict__ rowp = plan + pl.offS2 + ((size_t)(spin * K + hm) * K + qm) * p.sorb;
-  T acc = T(0);
-  acc += plan[pl.offS1 + (size_t)(spin * K + hm) * K + qm];
-  int j = 0;
-  for (; j + 8 <= nocc; j += 8) {
-    T v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = rowp[L.occv[j + u]];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
-  }
-  for (; j < nocc; ++j) acc += rowp[L.occv[j]];
-  return ((e >> 16) & 1u) ? -acc : acc;
 }
 
 // ---- doubles ----------------------------------------------------------------------------------------------
