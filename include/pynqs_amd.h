@@ -137,6 +137,24 @@ int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, 
                                  const void *plan, const void *table, int64_t nkeys, const double *wf,
                                  int wf_is_complex, double *eloc, double *psi0, void *stream);
 
+/* ---- SIMPLE method with a real RBM amplitude, fully fused, f64 -------------------------------------------
+ * vmc/energy/eloc.py:121-203 (_simple: get_comb_hij_fused + ansatz on all nbatch*ncomb kets + contraction) for
+ * the reference's RBMWavefunction with rbm_type "real" (vmc/ansatz/rbm/rbm.py:186-211):
+ *   psi(x) = exp(visible_bias . x) * prod_h 2 cosh(hidden_bias[h] + sum_o weights[h][o] x_o),  x_o = +1 / -1.
+ * The parameters are re-laid out once per parameter update into a caller-owned "RBM table" (pynqs_amd/csrc/rbm.h):
+ *   pynqs_rbm_table_bytes : [host] size of the table in bytes, or -1 for bad sizes
+ *   pynqs_rbm_table_build : weights double[nhidden][sorb] (row-major, the reference's parameter shape),
+ *                           hidden_bias double[nhidden], visible_bias double[sorb] or NULL (= 0)
+ *   pynqs_eloc_rbm        : eloc[nbatch] = sum_x' <x|H|x'> psi(x')/psi(x) over x' = x and all singles/doubles;
+ *                           psi (may be NULL) receives psi(x).  The amplitude ratios are evaluated from the
+ *                           2 or 4 flipped orbitals (no overflow for any theta); results agree with the
+ *                           materialised path to rounding (tests: 1e-8 Ha). */
+int64_t pynqs_rbm_table_bytes(int sorb, int nhidden);
+int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb,
+                          int nhidden, void *table, void *stream);
+int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                   const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream);
+
 /* REDUCE method front end: vmc/energy/eloc.py:205-324 with eps_sample == 0 keeps the columns with
  * |<x|H|x'>| >= eps (eloc.py:297-298; column 0 is treated like any other).  Two passes, nothing materialised:
  *   pynqs_reduce_count : counts[nbatch] = kept columns per walker

@@ -30,7 +30,7 @@ USE_PLAN = True  # route get_comb_hij_fused through the cached integral plan (Fa
 
 __all__ = [
     "tensor_to_onv", "onv_to_tensor", "get_comb_tensor", "get_hij_torch", "get_comb_hij_fused",
-    "wavefunction_lut", "hash_build", "hash_lookup", "HashTable", "merge_rank_sample", "spin_flip_rand", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
+    "wavefunction_lut", "hash_build", "hash_lookup", "HashTable", "RBMTable", "eloc_rbm", "merge_rank_sample", "spin_flip_rand", "check_sorb", "compress_h1e_h2e", "decompress_h1e_h2e", "get_Num_SinglesDoubles",
     "MAX_SORB", "MAX_SORB_LEN", "MAX_NELE",
 ]
 
@@ -313,6 +313,60 @@ def hash_lookup(ht: HashTable, onv: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 _SPIN_FLIP_CALLS = 0
+
+
+class RBMTable:
+    """Device-resident re-layout of a real RBM's parameters for the fused SIMPLE local energy
+    (include/pynqs_amd.h: pynqs_rbm_table_build; reference amplitude: vmc/ansatz/rbm/rbm.py:186-211).
+    weights [num_hidden, sorb], hidden_bias [num_hidden], visible_bias [sorb] or None; float64.
+    Rebuild after every parameter update (one small kernel)."""
+
+    def __init__(self, weights: Tensor, hidden_bias: Tensor, visible_bias: "Tensor | None" = None) -> None:
+        if weights.dim() != 2 or hidden_bias.numel() != weights.size(0):
+            raise RuntimeError("weights must be [num_hidden, sorb] and hidden_bias [num_hidden]")
+        if visible_bias is not None and visible_bias.numel() != weights.size(1):
+            raise RuntimeError("visible_bias must be [sorb]")
+        ts = [weights, hidden_bias] + ([visible_bias] if visible_bias is not None else [])
+        if any(t.dtype != torch.float64 for t in ts):
+            raise RuntimeError("the fused RBM local energy is float64 only")
+        dev, ts, _ = _stage(*[t.detach().contiguous() for t in ts])
+        self.nhidden, self.sorb, self.device = int(weights.size(0)), int(weights.size(1)), dev
+        nbytes = N.lib().pynqs_rbm_table_bytes(self.sorb, self.nhidden)
+        if nbytes < 0:
+            raise RuntimeError(f"bad RBM sizes: sorb = {self.sorb}, num_hidden = {self.nhidden}")
+        self.buf = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+        N.check(N.lib().pynqs_rbm_table_build(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr() if len(ts) > 2 else None,
+                                              self.sorb, self.nhidden, self.buf.data_ptr(), _stream(dev)), "rbm_table_build")
+        torch.cuda.current_stream(dev).synchronize()  # ts may be temporaries
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+
+def eloc_rbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: RBMTable, sorb: int, nele: int, noA: int, noB: int,
+             want_psi: bool = True) -> Tuple[Tensor, "Tensor | None"]:
+    """SIMPLE local energy with the real-RBM amplitude ratio evaluated on chip (pynqs_eloc_rbm):
+    (eloc float64[n], psi(x) float64[n] or None).  Equivalent to vmc/energy/eloc.py:121-203 with
+    ansatz = RBMWavefunction(rbm_type="real")."""
+    _check_onv(bra, "bra", sorb, (2,))
+    if table.sorb != sorb:
+        raise RuntimeError(f"RBM table was built for sorb = {table.sorb}, not {sorb}")
+    if _fdtype(h1e, h2e) != N.PYNQS_F64:
+        raise RuntimeError("the fused RBM local energy is float64 only")
+    plan = plan_for(h1e, h2e, sorb)
+    if plan is None:
+        raise RuntimeError("the fused RBM local energy needs an even sorb")
+    dev, (x,), all_cpu = _stage(bra)
+    if plan.device != dev or table.device != dev:
+        raise RuntimeError("bra, integrals and RBM table must be on the same device")
+    n = x.size(0)
+    eloc = torch.empty(n, dtype=torch.float64, device=dev)
+    psi = torch.empty(n, dtype=torch.float64, device=dev) if want_psi else None
+    N.check(N.lib().pynqs_eloc_rbm(x.data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), table.data_ptr(), table.nhidden,
+                                   eloc.data_ptr(), psi.data_ptr() if want_psi else None, _stream(dev)), "pynqs_eloc_rbm")
+    if all_cpu and bra.device.type == "cpu":
+        return eloc.cpu(), (psi.cpu() if want_psi else None)
+    return eloc, psi
 
 
 def spin_flip_rand(bra: Tensor, sorb: int, nele: int, noA: int, noB: int, seed: int, in_place: bool = False) -> Tuple[Tensor, Tensor]:

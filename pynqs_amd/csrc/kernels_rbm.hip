@@ -1,0 +1,345 @@
+// kernels_rbm.hip -- SIMPLE local energy (vmc/energy/eloc.py:121-203, _simple) with the amplitude ratio of a real
+// RBM (vmc/ansatz/rbm/rbm.py:186-211) evaluated on chip: nothing of size nbatch x ncomb ever reaches HBM.
+//
+//   E_loc(x) = sum_x' <x|H|x'> psi(x') / psi(x),     psi(x) = exp(a.x) prod_h 2 cosh(theta_h(x))
+//
+// An excitation flips 2 or 4 orbitals F (occupied x_o = +1 -> -1, empty -1 -> +1): theta'_h = theta_h - delta_h,
+// delta_h = 2 sum_{o in F} W[h][o] x_o.  With s_h = sign(theta_h), rho_h = exp(-2|theta_h|), m_h = 1/(1+rho_h):
+//   cosh(theta_h - delta_h) / cosh(theta_h) = exp(-s_h delta_h) * (m_h + m_h rho_h * prod_{o in F} q_h(o)),
+//   q_h(o) = exp(4 s_h W[h][o] x_o)
+// (no overflow for any theta; the reference's psi(x')/psi(x) of two products over-/underflows first), so
+//   psi(x')/psi(x) = prod_{o in F} C(o) * prod_h (m_h + n_h prod_{o in F} q_h(o)),
+//   C(o) = exp(-2 x_o (a_o + sum_h s_h W[h][o])),  n_h = m_h rho_h.
+// Per walker the workgroup builds q[o][h] in LDS (one read of exp(+-4W) per element, no transcendental in the
+// inner loop) and C(o); then every lane owns a 4 x 4 block of excitations -- 4 entries of a class's "fast"
+// excitation table x 4 entries of its "slow" table (hole pairs x particle pairs, alpha singles x beta singles:
+// detcore.h) -- and runs over the hidden units with 16 running products in registers:
+//   per hidden unit and lane: 16 LDS reads, 12 multiplications for the 8 pair products, 16 x (fma + mul).
+// The kernel is bound by the f64 vector rate and the LDS read rate, not by HBM.
+// Matrix elements come from the integral plan exactly as in kernels_plan.hip.
+#include "detcore.h"
+#include "launch.h"
+#include "plan.h"
+#include "plan_dev.h"
+#include "rbm.h"
+
+namespace pynqs {
+
+// W[H][sorb], hb[H], vb[sorb] (row-major, the reference's parameter shapes) -> RBM table (rbm.h)
+__global__ __launch_bounds__(kBlock) void rbm_table_kernel(const double *__restrict__ W, const double *__restrict__ hb,
+                                                           const double *__restrict__ vb, RbmLayout rl, double *__restrict__ tab) {
+  const int64_t row = (int64_t)rl.sorb * rl.Hq;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < row) {
+    const int o = (int)(i / rl.Hq), h = (int)(i - (int64_t)o * rl.Hq);
+    const double w = h < rl.H ? W[(int64_t)h * rl.sorb + o] : 0.0;
+    tab[rl.offWt + i] = w;
+    tab[rl.offE4p + i] = exp(4.0 * w);
+    tab[rl.offE4m + i] = exp(-4.0 * w);
+  }
+  if (i < rl.Hq) tab[rl.offHb + i] = i < rl.H ? hb[i] : 0.0;
+  if (i < rl.total - rl.offVb) tab[rl.offVb + i] = (vb && i < rl.sorb) ? vb[i] : 0.0;
+}
+
+// How the excitations of one walker are cut into 4 x 4 blocks: class k has nbf[k] x nbs[k] blocks
+// (k = 0 singles x nothing, 1 alpha-alpha, 2 beta-beta, 3 alpha-beta); b[k] = cumulative block counts.
+struct RbmBlocks {
+  uint32_t nbf[4];
+  uint32_t b[4];
+  uint32_t ntiles;  // tiles of 64 blocks
+};
+
+static inline RbmBlocks make_rbm_blocks(const SDParams &p) {
+  RbmBlocks B;
+  const uint32_t nf[4] = {p.d1, (uint32_t)p.noAA, (uint32_t)p.noBB, (uint32_t)p.nSa};
+  const uint32_t ns[4] = {p.d1 ? 1u : 0u, (uint32_t)p.nvAA, (uint32_t)p.nvBB, (uint32_t)p.nSb};
+  uint32_t acc = 0;
+  for (int k = 0; k < 4; ++k) {
+    B.nbf[k] = (nf[k] + 3) / 4;
+    acc += B.nbf[k] * ((ns[k] + 3) / 4);
+    B.b[k] = acc;
+  }
+  B.ntiles = (acc + 63) / 64;
+  return B;
+}
+
+// LDS after the walker tables: [q / staging][hs][mn][sh][Cq][part]
+struct RbmLds {
+  double *q;     // [sorb + 1][Hq]; row `sorb` is all ones (the partner of a single); aliases the staging scratch
+  double *hs;    // [d1 + 2]: <x|H|x>, then the singles
+  double *mn;    // [Hq][2]: m_h, n_h (1, 0 in the padding)
+  double *sh;    // [Hq]: s_h
+  double *Cq;    // [sorb + 2]: C(o), 1 for the dummy orbital
+  double *part;  // [4 sorb]
+};
+
+__host__ __device__ inline size_t rbm_region_bytes(const SDParams &p, const RbmLayout &rl) {
+  const size_t a = (size_t)kDiagTile * 8, b = (size_t)(p.sorb + 1) * rl.Hq * 8 + 16;
+  return a > b ? a : b;
+}
+
+__host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayout &rl) {
+  return lds_fixed_bytes(p) + rbm_region_bytes(p, rl) + 8 * ((size_t)(p.d1 + 2) + 3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + 4 * (size_t)p.sorb);
+}
+
+template <int LEN>
+__global__ __launch_bounds__(kBlock) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
+                                                          RbmBlocks B, uint32_t nchunks, const double *__restrict__ plan,
+                                                          const double *__restrict__ rbm, double *__restrict__ eloc,
+                                                          double *__restrict__ psi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ double red[kBlock / 64];
+  __shared__ uint32_t next_tile;
+  const uint64_t wg = blockIdx.x;
+  const uint64_t walker = wg / nchunks;
+  const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) next_tile = 0;
+  Walker<LEN> wk;
+  load_walker<LEN>(bra + walker * LEN, wk);
+  const LdsLayout L = carve_lds(smem, p);
+  const int nocc = build_walker_tables<LEN>(wk, p, L);
+  const int sorb = p.sorb, H = rl.H, Hq = rl.Hq;
+  RbmLds R;
+  {
+    // (plain offsets from the LDS array: a pointer that went through an integer cast is no longer known to be LDS
+    // and its loads become flat_load with full waits)
+    const size_t fixed = lds_fixed_bytes(p);
+    R.q = reinterpret_cast<double *>(smem + ((fixed + 15) & ~(size_t)15));
+    R.hs = reinterpret_cast<double *>(smem + fixed + rbm_region_bytes(p, rl));
+    R.mn = R.hs + (p.d1 + 2);
+    R.sh = R.mn + 2 * Hq;
+    R.Cq = R.sh + Hq;
+    R.part = R.Cq + (sorb + 2);
+  }
+  // matrix elements of the singles and the diagonal (staged through the region q will occupy afterwards)
+  const uint32_t tS = (B.b[0] + 63) / 64;
+  if (chunk < max(tS, 1u)) singles_and_diag_to_lds<LEN, double>(p, pl, L, nocc, plan, R.hs);
+
+  // theta_h, m_h, n_h, s_h; ln psi(x) on the way
+  const double *__restrict__ Wt = rbm + rl.offWt;
+  double lnpsi = 0.0;
+  for (int h = tid; h < Hq; h += kBlock) {
+    double m = 1.0, n = 0.0, s = 1.0;
+    if (h < H) {
+      double th = rbm[rl.offHb + h];
+      for (int o = 0; o < sorb; ++o) {
+        const double w = Wt[(size_t)o * Hq + h];
+        th += bit_of<LEN>(wk.w, o) ? w : -w;
+      }
+      const double a = fabs(th), rho = exp(-2.0 * a);
+      m = 1.0 / (1.0 + rho);
+      n = m * rho;
+      s = th >= 0.0 ? 1.0 : -1.0;
+      lnpsi += a + log1p(rho);
+    }
+    R.mn[2 * h] = m; R.mn[2 * h + 1] = n; R.sh[h] = s;
+  }
+  __syncthreads();  // also: staging scratch free
+  // C(o): 4 partial sums per orbital
+  for (int idx = tid; idx < 4 * sorb; idx += kBlock) {
+    const int o = idx >> 2;
+    double acc = 0.0;
+    for (int h = idx & 3; h < H; h += 4) acc += R.sh[h] * Wt[(size_t)o * Hq + h];
+    R.part[idx] = acc;
+  }
+  // q[o][h] = exp(4 s_h x_o W[h][o]); one wave per row
+  for (int o = wave; o <= sorb; o += kBlock / 64) {
+    const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
+    for (int h = lane; h < Hq; h += 64) {
+      double v = 1.0;
+      if (o < sorb && h < H) v = rbm[((R.sh[h] > 0.0) == occ ? rl.offE4p : rl.offE4m) + (size_t)o * Hq + h];
+      R.q[(size_t)o * Hq + h] = v;
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < sorb + 2; o += kBlock) {
+    double c = 1.0;
+    if (o < sorb) {
+      const double S = rbm[rl.offVb + o] + ((R.part[4 * o] + R.part[4 * o + 1]) + (R.part[4 * o + 2] + R.part[4 * o + 3]));
+      const double x = bit_of<LEN>(wk.w, o) ? 1.0 : -1.0;
+      c = exp(-2.0 * x * S);
+      if (chunk == 0) lnpsi += x * rbm[rl.offVb + o];
+    }
+    R.Cq[o] = c;
+  }
+  __syncthreads();
+
+  // ---- tiles of 64 blocks, pulled by the waves from an LDS counter --------------------------------------------
+  const double *__restrict__ Vss = plan + pl.offVss;
+  const double *__restrict__ Vab = plan + pl.offVab;
+  const uint32_t my_tiles = B.ntiles > chunk ? (B.ntiles - chunk + nchunks - 1) / nchunks : 0;
+  double esum = 0.0;
+  for (;;) {
+    uint32_t lt = 0;
+    if (lane == 0) lt = atomicAdd(&next_tile, 1u);
+    lt = __builtin_amdgcn_readfirstlane(lt);
+    if (lt >= my_tiles) break;
+    const uint32_t id = (chunk + lt * nchunks) * 64u + (uint32_t)lane;
+    // class and block of this lane
+    int cls = 4;
+    uint32_t bid = 0, nbf = 1, offF = 0, offS = 0, nF = 0, nS = 0;
+    if (id < B.b[0]) { cls = 0; bid = id; nbf = B.nbf[0]; offF = p.offSa; nF = p.d1; nS = 1; }
+    else if (id < B.b[1]) { cls = 1; bid = id - B.b[0]; nbf = B.nbf[1]; offF = p.offHPa; offS = p.offPPa; nF = p.noAA; nS = p.nvAA; }
+    else if (id < B.b[2]) { cls = 2; bid = id - B.b[1]; nbf = B.nbf[2]; offF = p.offHPb; offS = p.offPPb; nF = p.noBB; nS = p.nvBB; }
+    else if (id < B.b[3]) { cls = 3; bid = id - B.b[2]; nbf = B.nbf[3]; offF = p.offSa; offS = p.offSb; nF = p.nSa; nS = p.nSb; }
+    const uint32_t bs = bid / nbf, bf = bid - bs * nbf;
+    uint32_t ef[4], es[4];
+    uint32_t qo[16];  // LDS row offsets (in doubles) of the 8 entries' orbitals
+    const uint32_t dummy = (uint32_t)sorb * (uint32_t)Hq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t f = 4 * bf + i;
+      ef[i] = (cls < 4) ? L.tab[offF + min(f, nF - 1)] : 0u;
+      qo[2 * i] = cls < 4 ? (ef[i] & 0xff) * Hq : dummy;
+      qo[2 * i + 1] = cls < 4 ? ((ef[i] >> 8) & 0xff) * Hq : dummy;
+      const uint32_t s = 4 * bs + i;
+      const bool real_slow = cls >= 1 && cls < 4;
+      es[i] = real_slow ? L.tab[offS + min(s, nS - 1)] : 0u;
+      qo[8 + 2 * i] = real_slow ? (es[i] & 0xff) * Hq : dummy;
+      qo[8 + 2 * i + 1] = real_slow ? ((es[i] >> 8) & 0xff) * Hq : dummy;
+    }
+    double acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 1.0;
+    const double *__restrict__ qb = R.q;
+    for (int h = 0; h < rl.Hloop; h += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const double m = R.mn[2 * (h + u)], n = R.mn[2 * (h + u) + 1];
+        double gf[4], gs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          gf[i] = (qb[qo[2 * i] + h + u] * qb[qo[2 * i + 1] + h + u]) * n;
+          gs[i] = qb[qo[8 + 2 * i] + h + u] * qb[qo[8 + 2 * i + 1] + h + u];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[4 * i + j] *= fma(gf[i], gs[j], m);
+      }
+    }
+    // matrix elements, prefactors, sum
+    if (cls < 4) {
+      double cf[4], cs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cf[i] = R.Cq[ef[i] & 0xff] * R.Cq[(ef[i] >> 8) & 0xff];
+        cs[i] = cls == 0 ? 1.0 : R.Cq[es[i] & 0xff] * R.Cq[(es[i] >> 8) & 0xff];
+      }
+      if (cls == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t f = 4 * bf + i;
+          if (f < nF) esum += R.hs[1 + f] * (acc[4 * i] * cf[i]);
+        }
+      } else {
+        const bool opp = cls == 3;
+        const double *__restrict__ V = opp ? Vab : Vss + (size_t)(cls - 1) * pl.NP * pl.NP;
+        const uint32_t mul = opp ? (uint32_t)(pl.K * pl.K) : (uint32_t)pl.NP;
+        const uint32_t mask = opp ? 0x7fffu : 0x1fffu;
+        double hv[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hv[4 * i + j] = V[((es[j] >> 17) & mask) * mul + ((ef[i] >> 17) & mask)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a0 = ef[i] & 0xff, a1 = (ef[i] >> 8) & 0xff;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int b0 = es[j] & 0xff, b1 = (es[j] >> 8) & 0xff;
+            uint32_t par = ((ef[i] ^ es[j]) >> 16) & 1u;  // as plan_dev.h: finish_double
+            if (opp) par ^= (uint32_t)(a0 < b1) ^ (uint32_t)(b0 < a1) ^ 1u;
+            else par ^= (uint32_t)(a0 < b0) ^ (uint32_t)(a1 < b0) ^ (uint32_t)(a0 < b1) ^ (uint32_t)(a1 < b1);
+            const bool ok = 4 * bf + i < nF && 4 * bs + j < nS;
+            const double t = (acc[4 * i + j] * cf[i]) * cs[j];
+            if (ok) esum += (par ? -hv[4 * i + j] : hv[4 * i + j]) * t;
+          }
+        }
+      }
+    }
+  }
+  if (chunk == 0 && tid == 0) esum += R.hs[0];  // x' = x
+  // fixed-order reductions: lanes, then waves
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { esum += __shfl_xor(esum, o); lnpsi += __shfl_xor(lnpsi, o); }
+  if (lane == 0) red[wave] = esum;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+    if (nchunks == 1) eloc[walker] = s;
+    else atomicAdd(eloc + walker, s);
+  }
+  if (psi != nullptr && chunk == 0) {  // workgroup-uniform
+    __syncthreads();
+    if (lane == 0) red[wave] = lnpsi;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+      psi[walker] = exp(s);
+    }
+  }
+}
+
+}  // namespace pynqs
+
+// =================================================================================================
+using namespace pynqs;
+
+extern "C" int64_t pynqs_rbm_table_bytes(int sorb, int nhidden) {
+  RbmLayout rl;
+  if (!make_rbm_layout(sorb, nhidden, &rl)) return -1;
+  return rl.total * 8;
+}
+
+extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb,
+                                     int nhidden, void *table, void *stream) {
+  RbmLayout rl;
+  if (!make_rbm_layout(sorb, nhidden, &rl)) return set_error(PYNQS_EINVAL, "bad sorb / nhidden");
+  if (!weights || !hidden_bias || !table) return set_error(PYNQS_EINVAL, "null pointer");
+  const int64_t n = (int64_t)rl.sorb * rl.Hq;
+  const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(rbm_table_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, weights, hidden_bias, visible_bias, rl,
+                     (double *)table);
+  return check_launch("rbm_table_build");
+}
+
+extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                              const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream) {
+  SDParams p;
+  PlanLayout pl;
+  RbmLayout rl;
+  if (!make_sd_params(sorb, nele, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
+  if (!make_plan_layout(sorb, &pl)) return set_error(PYNQS_EINVAL, "plan needs an even sorb in [2, 192]");
+  if (!make_rbm_layout(sorb, nhidden, &rl)) return set_error(PYNQS_EINVAL, "bad nhidden");
+  if (nbatch < 0 || nbatch > 0x7fffffffll) return set_error(PYNQS_EINVAL, "bad nbatch");
+  if (nbatch == 0) return PYNQS_OK;
+  if (!bra || !plan || !rbm_table || !eloc) return set_error(PYNQS_EINVAL, "null pointer");
+  const size_t lds = lds_bytes_rbm(p, rl);
+  if (lds > 158 * 1024) return set_error(PYNQS_EINVAL, "RBM table of this sorb x nhidden does not fit the 160 KB LDS");
+  const RbmBlocks B = make_rbm_blocks(p);
+  // few walkers: cut a walker's tiles over several workgroups (each repeats the per-walker set-up)
+  uint32_t nchunks = 1;
+  if (nbatch < 1024) {
+    nchunks = (uint32_t)((1024 + nbatch - 1) / nbatch);
+    const uint32_t maxc = B.ntiles / 4 > 0 ? B.ntiles / 4 : 1;
+    if (nchunks > maxc) nchunks = maxc;
+  }
+  const uint64_t grid = (uint64_t)nbatch * nchunks;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (nchunks > 1 && hipMemsetAsync(eloc, 0, 8 * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
+  const int len = (sorb - 1) / 64 + 1;
+  DISPATCH_LEN(len, {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute");
+    hipLaunchKernelGGL((eloc_rbm_kernel<LEN>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, rl, B, nchunks,
+                       (const double *)plan, (const double *)rbm_table, eloc, psi);
+  });
+  return check_launch("eloc_rbm");
+}

@@ -95,6 +95,16 @@ __device__ __forceinline__ void diag_phase_plan(const SDParams &p, const PlanLay
   if (tid == kBlock - 1) sink(acc);
 }
 
+// <x|H|x'> of the singles [0, d1) and of the diagonal into LDS: hs[0] = <x|H|x>, hs[1 + r] = single r
+// (same arithmetic as comb_hij_plan_kernel: plan_dev.h).  `hs` holds 1 + d1 values.
+template <int LEN, typename T>
+__device__ __forceinline__ void singles_and_diag_to_lds(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
+                                                        const T *__restrict__ plan, T *__restrict__ hs) {
+  singles_phase<T>(p, pl, L, nocc, plan, 0u, p.d1, [&](uint32_t r, T v, int, int) { hs[1 + r] = v; });
+  diag_phase_plan<T>(p, pl, L, plan, [&](T v) { hs[0] = v; });
+  __syncthreads();
+}
+
 // ---- wave-private variants (used by the tile scheduler, plan_tiles.h) ------------------------------------------
 // The same two computations carried out by ONE wave with no workgroup barrier, so that the other waves of the
 // workgroup can run the doubles meanwhile (ablation, profiles/: with workgroup-wide phases the singles and

@@ -134,6 +134,32 @@ def _fused_lds_ok(sorb: int, noa: int, nob: int, elem: int = 8) -> bool:
     return fixed + 2048 * elem + (d1 + 2) * elem <= 64 * 1024
 
 
+def _real_rbm_params(ansatz):
+    """(weights [H, sorb], hidden_bias [H], visible_bias [sorb]) if `ansatz` (possibly DDP-wrapped) is a real RBM
+    with the reference's formula (pynqs_amd.rbm.RealRBM, or PyNQS' RBMWavefunction with rbm_type == "real"), else None."""
+    from .rbm import RealRBM
+
+    m = getattr(ansatz, "module", ansatz)
+    if not (isinstance(m, RealRBM) or getattr(m, "rbm_type", None) == "real"):
+        return None
+    W, hb, vb = getattr(m, "weights", None), getattr(m, "hidden_bias", None), getattr(m, "visible_bias", None)
+    if W is None or hb is None or vb is None or W.dtype != torch.float64 or not W.is_cuda or W.dim() != 2:
+        return None
+    return W.detach(), hb.detach().reshape(-1), vb.detach().reshape(-1)
+
+
+def _rbm_lds_ok(sorb: int, noa: int, nob: int, nhidden: int) -> bool:
+    """pynqs_eloc_rbm keeps exp(+-4W) of all (orbital, hidden unit) pairs in LDS (160 KiB per workgroup)."""
+    k = sorb // 2
+    nva, nvb = k - noa, k - nob
+    d1 = noa * nva + nob * nvb
+    tab = d1 + noa * (noa - 1) // 2 + nva * (nva - 1) // 2 + nob * (nob - 1) // 2 + nvb * (nvb - 1) // 2
+    fixed = (tab * 4 + 3 * 192 + 7) // 8 * 8 + (tab * 8 if sorb <= 64 else 0)
+    hq = (nhidden + 3) // 4 * 4 + 1
+    region = max(2048 * 8, (sorb + 1) * hq * 8 + 16)
+    return fixed + region + 8 * (d1 + 2 + 3 * hq + sorb + 2 + 4 * sorb) <= 158 * 1024
+
+
 def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa=0, nob=0) -> bool:
     return (FUSED and _fused_lds_ok(sorb, noa, nob) and WF_LUT is not None and WF_LUT.sort and not (use_spin_raising or use_multi_psi or use_spin_flip)
             and sorb % 2 == 0 and h1e.dtype == torch.float64 and WF_LUT.dtype in (torch.float64, torch.complex128)
@@ -211,6 +237,15 @@ def local_energy(
             eloc, psi0 = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT)
             t1 = time.time_ns()
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
+
+        # ---- fast path: SIMPLE with a real RBM, amplitude ratios on chip -----------------------------------
+        if (FUSED and not reduce_psi and not use_sample_space and WF_LUT is None and dtype == torch.double and x.is_cuda
+                and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0 and h1e.dtype == torch.float64):
+            prm = _real_rbm_params(ansatz)
+            if prm is not None and _rbm_lds_ok(sorb, noa, nob, prm[0].size(0)):
+                eloc, psi0 = CX.eloc_rbm(x, h1e, h2e, CX.RBMTable(*prm), sorb, nele, noa, nob)
+                t1 = time.time_ns()
+                return eloc, torch.zeros_like(eloc), psi0, ((t1 - t0) / 1e6, 0.0, 0.0)
 
         if use_multi_psi:
             ansatz_extra = partial(ansatz_batch, func=ansatz.module.extra)

@@ -40,14 +40,22 @@ def _le(env, **kw):
     return env["energy"].local_energy(env["x"], env["h1e"], env["h2e"], env["rbm"], _ab(env), 40, 30, 15, 15, dtype=kw.pop("dtype", torch.double), **kw)
 
 
-def test_simple_matches_reference_python(env):
-    d = env["d"]
-    eloc, sloc, psi, times = _le(env, use_unique=True)
-    np.testing.assert_allclose(psi.cpu().numpy(), d["psi_simple"], rtol=1e-12)
-    np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_simple"], rtol=0, atol=TOL)
-    assert float(sloc.abs().max()) == 0.0 and len(times) == 3
-    e2, _, _, _ = _le(env, use_unique=False)
-    np.testing.assert_allclose(e2.cpu().numpy(), d["eloc_simple"], rtol=0, atol=TOL)
+@pytest.mark.parametrize("fused", [True, False])
+def test_simple_matches_reference_python(env, fused):
+    """fused: the RealRBM ansatz takes the on-chip amplitude-ratio kernel (pynqs_eloc_rbm); else the generic
+    materialise-and-forward path.  Both against the reference's Python."""
+    d, energy = env["d"], env["energy"]
+    old = energy.FUSED
+    energy.FUSED = fused
+    try:
+        eloc, sloc, psi, times = _le(env, use_unique=True)
+        np.testing.assert_allclose(psi.cpu().numpy(), d["psi_simple"], rtol=1e-12)
+        np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_simple"], rtol=0, atol=TOL)
+        assert float(sloc.abs().max()) == 0.0 and len(times) == 3
+        e2, _, _, _ = _le(env, use_unique=False)
+        np.testing.assert_allclose(e2.cpu().numpy(), d["eloc_simple"], rtol=0, atol=TOL)
+    finally:
+        energy.FUSED = old
 
 
 @pytest.mark.parametrize("fused", [True, False])
