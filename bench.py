@@ -267,6 +267,81 @@ class SampleSpaceFused(Workload):
                 "sample": f"{reps} x oracle eloc_sample_space (C restatement, OpenMP) on the first {sample} walkers of the same batch ({el:.1f} s)"}
 
 
+class RbmFused(Workload):
+    """Complete local energies, SIMPLE method (vmc/energy/eloc.py:121-203) with the reference's real RBM amplitude
+    (vmc/ansatz/rbm/rbm.py:186-211, alpha = num_hidden / sorb), in ONE kernel: enumerate, <x|H|x'>, psi(x')/psi(x)
+    from the flipped orbitals, contraction.  SURVEY.md 8(d) 'fused E_loc (RBM configs)'.  Bound by the f64 vector
+    rate, not by HBM: `flops_per_walker` = 3 ncomb num_hidden (one fma + one multiplication per excitation and
+    hidden unit), peak 78.6 TFLOP/s."""
+
+    F64_VECTOR_PEAK_TFLOPS = 78.6
+
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev, alpha=2):
+        from pynqs_amd import C_extension as cx
+
+        self.cx = cx
+        self.name = f"{tag}_eloc_rbm"
+        self.sorb, self.nele, self.noA, self.noB = sorb, nele, noA, noB
+        self.h1, self.h2, self.x = h1.to(dev), h2.to(dev), walkers.to(dev).contiguous()
+        self.n = self.x.size(0)
+        dropin, self.ncomb = algorithmic_bytes_dropin(sorb, nele, noA, noB)
+        L = (sorb - 1) // 64 + 1
+        self.bytes_per_walker = dropin - self.ncomb * (8 + 8 * L) + 8
+        self.H = int(alpha * sorb)
+        self.flops_per_walker = 3.0 * self.ncomb * self.H
+        g = torch.Generator().manual_seed(7)  # SURVEY.md 8(d): weights 0.01 (rand - 0.5), seed 7
+        self.W = (0.01 * (torch.rand(self.H, sorb, generator=g, dtype=torch.float64) - 0.5)).to(dev)
+        self.hb = (0.01 * (torch.rand(self.H, generator=g, dtype=torch.float64) - 0.5)).to(dev)
+        self.vb = (1.0 * (torch.rand(sorb, generator=g, dtype=torch.float64) - 0.5)).to(dev)
+        st = torch.cuda.current_stream(dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        self.plan = cx.plan_for(self.h1, self.h2, sorb)
+        e1.record(st); e1.synchronize()
+        self.plan_build_ms = e0.elapsed_time(e1)
+        self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
+        self.dev, self.path, self.kernel = dev, "plan", "eloc_rbm_kernel"
+        self.stats = None
+        self.eloc = self.psi = None
+
+    def step(self):
+        st = torch.cuda.current_stream(self.dev)
+        # the parameters change every optimisation step: the table build is part of the step
+        tab = self.cx.RBMTable(self.W, self.hb, self.vb)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        self.eloc, self.psi = self.cx.eloc_rbm(self.x, self.h1, self.h2, tab, self.sorb, self.nele, self.noA, self.noB)
+        e1.record(st)
+        from pynqs_amd.stats import dist_stats_onepass
+        from pynqs_amd.distributed import get_world_size
+
+        self.stats = dist_stats_onepass(self.eloc, self.prob, None, get_world_size())
+        return e0, e1
+
+    def _oracle(self, m, nthreads=0):
+        from oracle import oracle as O
+
+        return O.eloc_simple_rbm(self.x[:m].cpu().numpy(), self.h1.cpu().numpy(), self.h2.cpu().numpy(), self.sorb, self.nele,
+                                 self.noA, self.noB, self.W.cpu().numpy(), self.hb.cpu().numpy(), self.vb.cpu().numpy(), nthreads=nthreads)
+
+    def parity_gate(self):
+        m = min(self.n, 8)
+        e, p0 = self._oracle(m)
+        de = float(np.abs(self.eloc[:m].cpu().numpy() - e).max())
+        return bool(np.allclose(self.psi[:m].cpu().numpy(), p0, rtol=1e-12, atol=0)), de
+
+    def cpu_baseline(self, budget_s=15.0):
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        self._oracle(min(self.n, 16), cores)
+        sample = min(self.n, 256)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s * 0.8 and reps < 200:
+            self._oracle(sample, cores); reps += 1
+        el = time.perf_counter() - t0
+        return {"value": sample * reps / el, "unit": "local energies/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} x oracle eloc_simple_rbm (C restatement: materialise + RBM forward on every x', OpenMP) on the first {sample} walkers ({el:.1f} s)"}
+
+
 def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -> Workload:
     if name == "fe2s2_eloc_sample_space":
         d = load_fe2s2()
@@ -274,6 +349,12 @@ def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -
         idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
         return SampleSpaceFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
                                 torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), torch.from_numpy(ci.copy()), dev)
+    if name == "fe2s2_eloc_rbm":
+        d = load_fe2s2()
+        ci = d["ci_space"]
+        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        return RbmFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
+                        torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev)
     if name == "fe2s2_dropin":
         d = load_fe2s2()
         ci = d["ci_space"]
@@ -342,6 +423,11 @@ def main():
         return float(tmax.item()), kern_ms
 
     def roofline(w, kern_ms):
+        if hasattr(w, "flops_per_walker"):  # f64 vector-ALU bound kernel
+            ach = w.flops_per_walker * w.n / (kern_ms * 1e-3) / 1e12
+            return {"bound": "valu_f64", "kernel": w.kernel, "achieved": ach, "peak": w.F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / w.F64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel_ms": kern_ms,
+                    "algorithmic_flops_per_launch": w.flops_per_walker * w.n}
         ach = w.bytes_per_walker * w.n / (kern_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_{w.name}.json")
@@ -380,7 +466,8 @@ def main():
     # secondary measurements (same run, N = 1 only): the complete fused local energy and the larger word counts
     if world == 1 and not args.no_extra and args.workload == "fe2s2_dropin":
         extra = {}
-        for name, nw, steps in (("fe2s2_eloc_sample_space", args.walkers, 20), ("syn120_dropin", 64, 10), ("syn184_dropin", 16, 5)):
+        for name, nw, steps in (("fe2s2_eloc_sample_space", args.walkers, 20), ("fe2s2_eloc_rbm", args.walkers, 20),
+                                ("syn120_dropin", 64, 10), ("syn184_dropin", 16, 5)):
             try:
                 w2 = make_workload(name, nw, rank, dev, args.path)
                 el2, k2 = timed(w2, 2, steps)
@@ -388,7 +475,7 @@ def main():
                 extra[w2.name] = {"value": w2.n * steps / el2, "unit": "local energies/s", "walkers": w2.n, "ncomb": w2.ncomb,
                                   "ms_per_step": el2 / steps * 1e3, "roofline": roofline(w2, k2),
                                   "parity": {"exact_part_bit_exact": bool(ok2), "max_abs_diff_vs_oracle": d2}}
-                if name == "fe2s2_eloc_sample_space" and not args.no_cpu_baseline:
+                if name in ("fe2s2_eloc_sample_space", "fe2s2_eloc_rbm") and not args.no_cpu_baseline:
                     extra[w2.name]["cpu_baseline"] = w2.cpu_baseline(budget_s=8.0)
                 del w2
                 torch.cuda.empty_cache()
@@ -409,6 +496,7 @@ def main():
             h1g, h2g = torch.from_numpy(d["h1e"]).to(dev), torch.from_numpy(d["h2e"]).to(dev)
             old_default = torch.get_default_dtype()
             torch.set_default_dtype(torch.float64)
+            old_fused_rbm, E.FUSED_RBM = E.FUSED_RBM, False  # this line measures the generic module path
             for tag, nw, kw in (("fe2s2_eloc_simple_rbm_torch", 512, {}), ("fe2s2_eloc_reduce_eps1e-2_rbm_torch", 8192, {"reduce_psi": True, "eps": 1e-2})):
                 xg = torch.from_numpy(np.ascontiguousarray(d["ci_space"][:nw])).to(dev)
                 fn = lambda: E.total_energy(xg, nw, 2_000_000, h1g, h2g, rbm, sorb, nele, noA, noB, use_unique=False, **kw)
@@ -421,6 +509,7 @@ def main():
                 extra[tag] = {"value": nw / el3, "unit": "local energies/s", "walkers": nw, "ms_per_step": el3 * 1e3,
                               "mean_eloc": float(e_.mean().item())}
             torch.set_default_dtype(old_default)
+            E.FUSED_RBM = old_fused_rbm
         except Exception as e:  # pragma: no cover
             extra["fe2s2_eloc_rbm_torch"] = {"error": repr(e)}
         out["extra"] = extra

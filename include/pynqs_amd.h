@@ -142,6 +142,8 @@ int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, 
  * the reference's RBMWavefunction with rbm_type "real" (vmc/ansatz/rbm/rbm.py:186-211):
  *   psi(x) = exp(visible_bias . x) * prod_h 2 cosh(hidden_bias[h] + sum_o weights[h][o] x_o),  x_o = +1 / -1.
  * The parameters are re-laid out once per parameter update into a caller-owned "RBM table" (pynqs_amd/csrc/rbm.h):
+ *   pynqs_eloc_rbm_supported : [host] 1 if exp(+-4 W) of all (orbital, hidden unit) pairs of this problem fits the
+ *                           CU's LDS next to the walker tables (the kernel's working set), else 0
  *   pynqs_rbm_table_bytes : [host] size of the table in bytes, or -1 for bad sizes
  *   pynqs_rbm_table_build : weights double[nhidden][sorb] (row-major, the reference's parameter shape),
  *                           hidden_bias double[nhidden], visible_bias double[sorb] or NULL (= 0)
@@ -149,6 +151,7 @@ int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, 
  *                           psi (may be NULL) receives psi(x).  The amplitude ratios are evaluated from the
  *                           2 or 4 flipped orbitals (no overflow for any theta); results agree with the
  *                           materialised path to rounding (tests: 1e-8 Ha). */
+int pynqs_eloc_rbm_supported(int sorb, int nele, int noA, int noB, int nhidden);
 int64_t pynqs_rbm_table_bytes(int sorb, int nhidden);
 int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb,
                           int nhidden, void *table, void *stream);

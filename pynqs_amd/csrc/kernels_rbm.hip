@@ -63,107 +63,180 @@ static inline RbmBlocks make_rbm_blocks(const SDParams &p) {
   return B;
 }
 
-// LDS after the walker tables: [q / staging][hs][mn][sh][Cq][part]
+// LDS after the walker tables (16-byte aligned): [q / staging][mn][sh][Cq][hs]
+//   q   [sorb + 1][Hq]  row r(o) = o/2 for alpha, sorb/2 + o/2 for beta orbitals (a wave mostly reads rows of one
+//                       spin: consecutive rows -> different 16-byte slots); row `sorb` is all ones (the partner
+//                       of a single); aliases the scratch the singles / diagonal are staged in
+//   mn  [2][Hq]         m_h, then (m_h rho_h)^(1/4) (1, 0 in the padding)
+//   sh  [Hq]            s_h
+//   Cq  [sorb + 2]      C(o) by orbital, 1 for the dummy orbital `sorb`
+//   hs  [d1 + 2]        <x|H|x>, then the singles
+typedef double rbm_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const double lds_cdouble;  // read through a 32-bit LDS address
+
 struct RbmLds {
-  double *q;     // [sorb + 1][Hq]; row `sorb` is all ones (the partner of a single); aliases the staging scratch
-  double *hs;    // [d1 + 2]: <x|H|x>, then the singles
-  double *mn;    // [Hq][2]: m_h, n_h (1, 0 in the padding)
-  double *sh;    // [Hq]: s_h
-  double *Cq;    // [sorb + 2]: C(o), 1 for the dummy orbital
-  double *part;  // [4 sorb]
+  double *q, *mn, *sh, *Cq, *hs;
 };
 
+__host__ __device__ inline size_t rbm_q_offset(const SDParams &p) { return (lds_fixed_bytes(p) + 15) & ~(size_t)15; }
+
 __host__ __device__ inline size_t rbm_region_bytes(const SDParams &p, const RbmLayout &rl) {
-  const size_t a = (size_t)kDiagTile * 8, b = (size_t)(p.sorb + 1) * rl.Hq * 8 + 16;
-  return a > b ? a : b;
+  const size_t a = (size_t)kDiagTile * 8 + 16, b = (size_t)(p.sorb + 1) * rl.Hq * 8;
+  return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 
 __host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayout &rl) {
-  return lds_fixed_bytes(p) + rbm_region_bytes(p, rl) + 8 * ((size_t)(p.d1 + 2) + 3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + 4 * (size_t)p.sorb);
+  return rbm_q_offset(p) + rbm_region_bytes(p, rl) +
+         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 48;  // + red, tile counter
 }
 
+__device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o >> 1) + ((o & 1u) ? K : 0u); }
+
 template <int LEN>
-__global__ __launch_bounds__(kBlock) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
+__global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
                                                           RbmBlocks B, uint32_t nchunks, const double *__restrict__ plan,
                                                           const double *__restrict__ rbm, double *__restrict__ eloc,
                                                           double *__restrict__ psi) {
+  // no static __shared__ here: with the dynamic region at LDS address 0 the row offsets below are the addresses and
+  // the ds_read immediates carry the rest (a static in front costs one v_add per read)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ double red[kBlock / 64];
-  __shared__ uint32_t next_tile;
+  double *red = reinterpret_cast<double *>(smem + lds_bytes_rbm(p, rl) - 48);  // [kBlock / 64]
+  uint32_t *next_tile_p = reinterpret_cast<uint32_t *>(red + kBlock / 64);
+  uint32_t *next_single_p = next_tile_p + 1;
+#define next_tile (*next_tile_p)
   const uint64_t wg = blockIdx.x;
   const uint64_t walker = wg / nchunks;
   const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) next_tile = 0;
+  if (tid == 0) { next_tile = 0; *next_single_p = 0; }
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
   const int sorb = p.sorb, H = rl.H, Hq = rl.Hq;
+  const uint32_t K = (uint32_t)sorb >> 1;
   RbmLds R;
   {
     // (plain offsets from the LDS array: a pointer that went through an integer cast is no longer known to be LDS
     // and its loads become flat_load with full waits)
-    const size_t fixed = lds_fixed_bytes(p);
-    R.q = reinterpret_cast<double *>(smem + ((fixed + 15) & ~(size_t)15));
-    R.hs = reinterpret_cast<double *>(smem + fixed + rbm_region_bytes(p, rl));
-    R.mn = R.hs + (p.d1 + 2);
+    R.q = reinterpret_cast<double *>(smem + rbm_q_offset(p));
+    R.mn = reinterpret_cast<double *>(smem + rbm_q_offset(p) + rbm_region_bytes(p, rl));
     R.sh = R.mn + 2 * Hq;
     R.Cq = R.sh + Hq;
-    R.part = R.Cq + (sorb + 2);
+    R.hs = R.Cq + (sorb + 2);
   }
-  // matrix elements of the singles and the diagonal (staged through the region q will occupy afterwards)
+#if defined(PYNQS_RBM_STOP) && PYNQS_RBM_STOP == 1
+  if (tid == 0) eloc[walker] = (double)nocc;
+  return;
+#endif
+  // ---- phase A, no barrier inside: three independent jobs on different waves -----------------------------------
+  //   last wave  : <x|H|x> (ordered sum of nele(nele+1)/2 terms by one lane: the longest serial job)
+  //   other waves: theta_h -> m_h, n_h, s_h (and ln psi(x)), then the singles' matrix elements in tiles of 16
+  // The singles / diagonal are staged in wave-private quarters of the region q will occupy afterwards.
   const uint32_t tS = (B.b[0] + 63) / 64;
-  if (chunk < max(tS, 1u)) singles_and_diag_to_lds<LEN, double>(p, pl, L, nocc, plan, R.hs);
-
-  // theta_h, m_h, n_h, s_h; ln psi(x) on the way
+  const bool need_hs = chunk < max(tS, 1u);
   const double *__restrict__ Wt = rbm + rl.offWt;
   double lnpsi = 0.0;
-  for (int h = tid; h < Hq; h += kBlock) {
-    double m = 1.0, n = 0.0, s = 1.0;
-    if (h < H) {
-      double th = rbm[rl.offHb + h];
-      for (int o = 0; o < sorb; ++o) {
-        const double w = Wt[(size_t)o * Hq + h];
-        th += bit_of<LEN>(wk.w, o) ? w : -w;
+  constexpr int kThetaThreads = kBlock - 64;
+  if (wave == kBlock / 64 - 1) {
+    if (need_hs) diag_wave<double>(p, pl, L, plan, [&](double v) { R.hs[0] = v; });
+  } else {
+    for (int h = tid; h < Hq; h += kThetaThreads) {
+      double m = 1.0, n = 0.0, s = 1.0;
+      if (h < H) {
+        double th = rbm[rl.offHb + h];
+#pragma unroll 16
+        for (int o = 0; o < sorb; ++o) {  // independent loads: 16 in flight per round trip (L2 latency ~0.6 us)
+          const double w = Wt[(size_t)o * Hq + h];
+          th += bit_of<LEN>(wk.w, o) ? w : -w;
+        }
+        const double a = fabs(th), rho = exp(-2.0 * a), lc = a + log1p(rho);  // lc = ln 2cosh(theta)
+        m = 1.0 / (1.0 + rho);
+        n = exp(-0.25 * (a + lc));  // (m rho)^(1/4): every excitation multiplies four rows (singles: two + dummy twice)
+        s = th >= 0.0 ? 1.0 : -1.0;
+        lnpsi += lc;
       }
-      const double a = fabs(th), rho = exp(-2.0 * a);
-      m = 1.0 / (1.0 + rho);
-      n = m * rho;
-      s = th >= 0.0 ? 1.0 : -1.0;
-      lnpsi += a + log1p(rho);
+      R.mn[h] = m; R.mn[Hq + h] = n; R.sh[h] = s;
     }
-    R.mn[2 * h] = m; R.mn[2 * h + 1] = n; R.sh[h] = s;
   }
-  __syncthreads();  // also: staging scratch free
-  // C(o): 4 partial sums per orbital
-  for (int idx = tid; idx < 4 * sorb; idx += kBlock) {
-    const int o = idx >> 2;
-    double acc = 0.0;
-    for (int h = idx & 3; h < H; h += 4) acc += R.sh[h] * Wt[(size_t)o * Hq + h];
-    R.part[idx] = acc;
-  }
-  // q[o][h] = exp(4 s_h x_o W[h][o]); one wave per row
-  for (int o = wave; o <= sorb; o += kBlock / 64) {
-    const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
-    for (int h = lane; h < Hq; h += 64) {
-      double v = 1.0;
-      if (o < sorb && h < H) v = rbm[((R.sh[h] > 0.0) == occ ? rl.offE4p : rl.offE4m) + (size_t)o * Hq + h];
-      R.q[(size_t)o * Hq + h] = v;
+  if (need_hs) {  // every wave, as it becomes free
+    const uint32_t nst = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+    for (;;) {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(next_single_p, 1u);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= nst) break;
+      const uint32_t r0 = t * kSinglesPerTile;
+      singles_tile<double>(r0, min(r0 + kSinglesPerTile, p.d1), p, pl, L, nocc, plan,
+                           [&](uint32_t r, double v, uint32_t) { R.hs[1 + r] = v; });
     }
   }
   __syncthreads();
-  for (int o = tid; o < sorb + 2; o += kBlock) {
-    double c = 1.0;
-    if (o < sorb) {
-      const double S = rbm[rl.offVb + o] + ((R.part[4 * o] + R.part[4 * o + 1]) + (R.part[4 * o + 2] + R.part[4 * o + 3]));
-      const double x = bit_of<LEN>(wk.w, o) ? 1.0 : -1.0;
-      c = exp(-2.0 * x * S);
-      if (chunk == 0) lnpsi += x * rbm[rl.offVb + o];
+#if defined(PYNQS_RBM_STOP) && PYNQS_RBM_STOP == 2
+  if (tid == 0) eloc[walker] = R.hs[0];
+  return;
+#endif
+  // ---- phase B: q[o][h] = exp(4 s_h x_o W[h][o]) and C(o) = exp(-2 x_o (a_o + sum_h s_h W[h][o])), a wave per row --
+  // (kRowBatch rows x 2 columns per lane are requested together: an un-batched loop pays one L2 round trip per row)
+  constexpr int kRowBatch = 4, kWaves = kBlock / 64;
+  for (int o0 = wave; o0 <= sorb; o0 += kWaves * kRowBatch) {
+    double e4[kRowBatch][2], wv[kRowBatch][2], sg[2], fq[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      sg[c] = lane + 64 * c < H ? R.sh[lane + 64 * c] : 0.0;
+      fq[c] = lane + 64 * c < H ? R.mn[Hq + lane + 64 * c] : 0.0;
     }
-    R.Cq[o] = c;
+#pragma unroll
+    for (int b = 0; b < kRowBatch; ++b) {
+      const int o = o0 + b * kWaves;
+      const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int h = lane + 64 * c;
+        e4[b][c] = 1.0; wv[b][c] = 0.0;
+        if (o < sorb && h < H) {
+          e4[b][c] = rbm[((sg[c] > 0.0) == occ ? rl.offE4p : rl.offE4m) + (size_t)o * Hq + h];
+          wv[b][c] = Wt[(size_t)o * Hq + h];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < kRowBatch; ++b) {
+      const int o = o0 + b * kWaves;
+      if (o > sorb) break;  // wave-uniform
+      const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
+      const uint32_t row = o < sorb ? rbm_row(o, K) : (uint32_t)sorb;
+      double S = sg[0] * wv[b][0] + sg[1] * wv[b][1];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (lane + 64 * c < Hq) R.q[(size_t)row * Hq + lane + 64 * c] = e4[b][c] * fq[c];
+      for (int h = lane + 128; h < Hq; h += 64) {  // more than 128 hidden units: the rest of the row
+        double v = 1.0;
+        if (o < sorb && h < H) {
+          const double s2 = R.sh[h];
+          v = rbm[((s2 > 0.0) == occ ? rl.offE4p : rl.offE4m) + (size_t)o * Hq + h];
+          S += s2 * Wt[(size_t)o * Hq + h];
+        }
+        R.q[(size_t)row * Hq + h] = h < H ? v * R.mn[Hq + h] : 0.0;
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) S += __shfl_xor(S, d);
+      if (lane == 0) {
+        double c = 1.0;
+        if (o < sorb) {
+          const double x = occ ? 1.0 : -1.0, a = rbm[rl.offVb + o];
+          c = exp(-2.0 * x * (a + S));
+          lnpsi += x * a;
+        }
+        R.Cq[o] = c;
+      }
+    }
   }
   __syncthreads();
+#if defined(PYNQS_RBM_STOP) && PYNQS_RBM_STOP == 3
+  if (tid == 0) eloc[walker] = R.hs[0] + R.Cq[0] + R.q[5];
+  return;
+#endif
 
   // ---- tiles of 64 blocks, pulled by the waves from an LDS counter --------------------------------------------
   const double *__restrict__ Vss = plan + pl.offVss;
@@ -185,39 +258,51 @@ __global__ __launch_bounds__(kBlock) void eloc_rbm_kernel(const uint64_t *__rest
     else if (id < B.b[3]) { cls = 3; bid = id - B.b[2]; nbf = B.nbf[3]; offF = p.offSa; offS = p.offSb; nF = p.nSa; nS = p.nSb; }
     const uint32_t bs = bid / nbf, bf = bid - bs * nbf;
     uint32_t ef[4], es[4];
-    uint32_t qo[16];  // LDS row offsets (in doubles) of the 8 entries' orbitals
-    const uint32_t dummy = (uint32_t)sorb * (uint32_t)Hq;
+    // the q rows of the 8 entries' orbitals as 32-bit LDS addresses (the dynamic region starts at the static size;
+    // an array of generic pointers loses the address space and its loads become flat_load)
+    uint32_t rb[16];
+    const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)rbm_q_offset(p), rowB = (uint32_t)Hq * 8u, dummy = qbase + (uint32_t)sorb * rowB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t f = 4 * bf + i;
       ef[i] = (cls < 4) ? L.tab[offF + min(f, nF - 1)] : 0u;
-      qo[2 * i] = cls < 4 ? (ef[i] & 0xff) * Hq : dummy;
-      qo[2 * i + 1] = cls < 4 ? ((ef[i] >> 8) & 0xff) * Hq : dummy;
+      rb[2 * i] = cls < 4 ? qbase + rbm_row(ef[i] & 0xff, K) * rowB : dummy;
+      rb[2 * i + 1] = cls < 4 ? qbase + rbm_row((ef[i] >> 8) & 0xff, K) * rowB : dummy;
       const uint32_t s = 4 * bs + i;
       const bool real_slow = cls >= 1 && cls < 4;
       es[i] = real_slow ? L.tab[offS + min(s, nS - 1)] : 0u;
-      qo[8 + 2 * i] = real_slow ? (es[i] & 0xff) * Hq : dummy;
-      qo[8 + 2 * i + 1] = real_slow ? ((es[i] >> 8) & 0xff) * Hq : dummy;
+      rb[8 + 2 * i] = real_slow ? qbase + rbm_row(es[i] & 0xff, K) * rowB : dummy;
+      rb[8 + 2 * i + 1] = real_slow ? qbase + rbm_row((es[i] >> 8) & 0xff, K) * rowB : dummy;
     }
     double acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 1.0;
-    const double *__restrict__ qb = R.q;
-    for (int h = 0; h < rl.Hloop; h += 2) {
+    // One hidden unit per sub-step: 16 ds_read_b64 (2 LDS cycles each, 256 B/clk) feed 8 + 32 f64 operations
+    // (the rows carry (m_h rho_h)^(1/4), so the product of an excitation's four rows is n_h prod q).
+    // Eight sub-steps share one update of the row addresses (immediate offsets); the empty asm keeps the compiler
+    // from fusing the loads of neighbouring hidden units into ds_read2_b64 (half the LDS rate) or into 16-byte
+    // loads (twice the registers: the kernel must stay below 128 VGPRs for 4 waves per SIMD).
+    for (int h = 0; h < rl.Hloop; h += 8) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const double m = R.mn[2 * (h + u)], n = R.mn[2 * (h + u) + 1];
+      for (int c = 0; c < 8; ++c) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<lds_cdouble *>(rb[k] + 8 * c);
+        const double m = R.mn[h + c];
         double gf[4], gs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          gf[i] = (qb[qo[2 * i] + h + u] * qb[qo[2 * i + 1] + h + u]) * n;
-          gs[i] = qb[qo[8 + 2 * i] + h + u] * qb[qo[8 + 2 * i + 1] + h + u];
+          gf[i] = v[2 * i] * v[2 * i + 1];
+          gs[i] = v[8 + 2 * i] * v[8 + 2 * i + 1];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[4 * i + j] *= fma(gf[i], gs[j], m);
+        asm volatile("" ::: "memory");
       }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) rb[k] += 64;
     }
     // matrix elements, prefactors, sum
     if (cls < 4) {
@@ -284,15 +369,26 @@ __global__ __launch_bounds__(kBlock) void eloc_rbm_kernel(const uint64_t *__rest
   }
 }
 
+#undef next_tile
 }  // namespace pynqs
 
 // =================================================================================================
 using namespace pynqs;
 
+static constexpr size_t kRbmMaxLds = 158 * 1024;  // of the CU's 160 KiB
+
 extern "C" int64_t pynqs_rbm_table_bytes(int sorb, int nhidden) {
   RbmLayout rl;
   if (!make_rbm_layout(sorb, nhidden, &rl)) return -1;
   return rl.total * 8;
+}
+
+extern "C" int pynqs_eloc_rbm_supported(int sorb, int nele, int noA, int noB, int nhidden) {
+  SDParams p;
+  PlanLayout pl;
+  RbmLayout rl;
+  if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl) || !make_rbm_layout(sorb, nhidden, &rl)) return 0;
+  return lds_bytes_rbm(p, rl) <= kRbmMaxLds ? 1 : 0;
 }
 
 extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb,
@@ -319,7 +415,7 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   if (nbatch == 0) return PYNQS_OK;
   if (!bra || !plan || !rbm_table || !eloc) return set_error(PYNQS_EINVAL, "null pointer");
   const size_t lds = lds_bytes_rbm(p, rl);
-  if (lds > 158 * 1024) return set_error(PYNQS_EINVAL, "RBM table of this sorb x nhidden does not fit the 160 KB LDS");
+  if (lds > kRbmMaxLds) return set_error(PYNQS_EINVAL, "RBM table of this sorb x nhidden does not fit the 160 KB LDS");
   const RbmBlocks B = make_rbm_blocks(p);
   // few walkers: cut a walker's tiles over several workgroups (each repeats the per-walker set-up)
   uint32_t nchunks = 1;

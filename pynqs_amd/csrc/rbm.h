@@ -8,8 +8,8 @@
 //   E4m [sorb][Hq]   exp(-4 W[h][o])   (padding 1)
 //   hb  [Hq]         hidden bias b (padding 0)
 //   vb  [sorb]       visible bias a (0 when the caller passes none)
-// Hq = row stride = H rounded up to a multiple of 4, plus 1: odd, so that in LDS the rows of 32 consecutive
-// orbitals start in 32 different 8-byte bank pairs.
+// Hq = row stride = H rounded up to a multiple of 8, plus 1: odd, so that in LDS (read with ds_read_b64: banks
+// = 8-byte pairs of a 256-byte row, conflicts among 32 lanes) 32 consecutive rows start in 32 different pairs.
 #pragma once
 
 #include <stdint.h>
@@ -17,14 +17,14 @@
 namespace pynqs {
 
 struct RbmLayout {
-  int sorb, H, Hq, Hloop;  // Hloop = H rounded up to a multiple of 4 (what the hidden-unit loop runs over)
+  int sorb, H, Hq, Hloop;  // Hloop = H rounded up to a multiple of 8 (what the hidden-unit loop runs over)
   int64_t offWt, offE4p, offE4m, offHb, offVb, total;  // in doubles
 };
 
 inline bool make_rbm_layout(int sorb, int H, RbmLayout *L) {
   if (sorb < 1 || sorb > 192 || H < 1 || H > 8192) return false;
   L->sorb = sorb; L->H = H;
-  L->Hloop = (H + 3) & ~3;
+  L->Hloop = (H + 7) & ~7;
   L->Hq = L->Hloop + 1;
   const int64_t row = (int64_t)sorb * L->Hq;
   L->offWt = 0; L->offE4p = row; L->offE4m = 2 * row; L->offHb = 3 * row;

@@ -34,6 +34,7 @@ from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, che
                               spin_flip_onv, spin_flip_sign, split_batch_idx)
 
 FUSED = True  # use the fused sample-space / reduce kernels when the configuration allows it
+FUSED_RBM = True  # SIMPLE method: evaluate a real RBM ansatz inside the kernel (pynqs_eloc_rbm) instead of calling the module
 
 
 def Func(func: Callable[..., Tensor], x: Tensor, WF_LUT: Optional[WavefunctionLUT] = None, use_unique: bool = False) -> Tensor:
@@ -148,16 +149,9 @@ def _real_rbm_params(ansatz):
     return W.detach(), hb.detach().reshape(-1), vb.detach().reshape(-1)
 
 
-def _rbm_lds_ok(sorb: int, noa: int, nob: int, nhidden: int) -> bool:
+def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
     """pynqs_eloc_rbm keeps exp(+-4W) of all (orbital, hidden unit) pairs in LDS (160 KiB per workgroup)."""
-    k = sorb // 2
-    nva, nvb = k - noa, k - nob
-    d1 = noa * nva + nob * nvb
-    tab = d1 + noa * (noa - 1) // 2 + nva * (nva - 1) // 2 + nob * (nob - 1) // 2 + nvb * (nvb - 1) // 2
-    fixed = (tab * 4 + 3 * 192 + 7) // 8 * 8 + (tab * 8 if sorb <= 64 else 0)
-    hq = (nhidden + 3) // 4 * 4 + 1
-    region = max(2048 * 8, (sorb + 1) * hq * 8 + 16)
-    return fixed + region + 8 * (d1 + 2 + 3 * hq + sorb + 2 + 4 * sorb) <= 158 * 1024
+    return bool(N.lib().pynqs_eloc_rbm_supported(sorb, nele, noa, nob, nhidden))
 
 
 def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa=0, nob=0) -> bool:
@@ -239,10 +233,10 @@ def local_energy(
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 
         # ---- fast path: SIMPLE with a real RBM, amplitude ratios on chip -----------------------------------
-        if (FUSED and not reduce_psi and not use_sample_space and WF_LUT is None and dtype == torch.double and x.is_cuda
+        if (FUSED and FUSED_RBM and not reduce_psi and not use_sample_space and WF_LUT is None and dtype == torch.double and x.is_cuda
                 and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0 and h1e.dtype == torch.float64):
             prm = _real_rbm_params(ansatz)
-            if prm is not None and _rbm_lds_ok(sorb, noa, nob, prm[0].size(0)):
+            if prm is not None and _rbm_lds_ok(sorb, nele, noa, nob, prm[0].size(0)):
                 eloc, psi0 = CX.eloc_rbm(x, h1e, h2e, CX.RBMTable(*prm), sorb, nele, noa, nob)
                 t1 = time.time_ns()
                 return eloc, torch.zeros_like(eloc), psi0, ((t1 - t0) / 1e6, 0.0, 0.0)

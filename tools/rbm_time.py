@@ -7,12 +7,12 @@ from pynqs_amd import C_extension as cx
 
 d = np.load("tests/golden/fe2s2_inputs.npz")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-alpha = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+alpha = float(sys.argv[2]) if len(sys.argv) > 2 else 2
 sorb = 40
 x = torch.from_numpy(d["ci_space"][:n].copy()).cuda()
 h1e, h2e = torch.from_numpy(d["h1e"]).cuda(), torch.from_numpy(d["h2e"]).cuda()
 g = torch.Generator().manual_seed(7)
-H = alpha * sorb
+H = int(alpha * sorb)
 W = (0.01 * (torch.rand(H, sorb, generator=g, dtype=torch.float64) - 0.5)).cuda()
 hb = (0.01 * (torch.rand(H, generator=g, dtype=torch.float64) - 0.5)).cuda()
 vb = (1.0 * (torch.rand(sorb, generator=g, dtype=torch.float64) - 0.5)).cuda()
