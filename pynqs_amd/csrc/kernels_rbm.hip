@@ -92,6 +92,40 @@ __host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayo
 
 __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o >> 1) + ((o & 1u) ? K : 0u); }
 
+// <x|H|x> and the singles' matrix elements for THIS kernel.  The drop-in kernels add these terms in the reference's
+// order, one lane per sum and staged through LDS, to be bit-identical (plan_dev.h); here E_loc is a sum of ~ncomb
+// rounded products anyway (tolerance 1e-8 Ha), so the terms are added in whatever order is cheapest:
+//   diagonal: lane a adds h(p_a,p_a) + sum_{b<a} <p_a p_b||p_a p_b>, then a butterfly over the wave;
+//   singles : one lane per single walks its S2 row over the occupied orbitals (its 2-3 cache lines stay in L1).
+__device__ __forceinline__ double rbm_diag(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, const double *__restrict__ plan) {
+  const int lane = threadIdx.x & 63;
+  const double *__restrict__ D1 = plan + pl.offD1;
+  const double *__restrict__ D2 = plan + pl.offD2;
+  double acc = 0.0;
+  for (int a = lane; a < p.nele; a += 64) {
+    const uint32_t pa = L.occa[a];
+    acc += D1[pa];
+    const double *__restrict__ row = D2 + pa * (uint32_t)p.sorb;
+#pragma unroll 4
+    for (int b = 0; b < a; ++b) acc += row[L.occa[b]];
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  return acc;
+}
+
+__device__ __forceinline__ void rbm_singles(uint32_t r, const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
+                                            const double *__restrict__ plan, double *__restrict__ hs) {
+  if (r >= p.d1) return;
+  const uint32_t e = L.tab[p.offSa + r], K = (uint32_t)pl.K;
+  const uint32_t pq = ((r >= p.d0 ? K : 0u) + ((e & 0xff) >> 1)) * K + (((e >> 8) & 0xff) >> 1);
+  const double *__restrict__ row = plan + pl.offS2 + (size_t)pq * p.sorb;
+  double acc = plan[pl.offS1 + pq];
+#pragma unroll 8
+  for (int j = 0; j < nocc; ++j) acc += row[L.occv[j]];
+  hs[1 + r] = ((e >> 16) & 1u) ? -acc : acc;
+}
+
 template <int LEN>
 __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
                                                           RbmBlocks B, uint32_t nchunks, const double *__restrict__ plan,
@@ -139,7 +173,10 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   double lnpsi = 0.0;
   constexpr int kThetaThreads = kBlock - 64;
   if (wave == kBlock / 64 - 1) {
-    if (need_hs) diag_wave<double>(p, pl, L, plan, [&](double v) { R.hs[0] = v; });
+    if (need_hs) {
+      const double hii = rbm_diag(p, pl, L, plan);
+      if (lane == 0) R.hs[0] = hii;
+    }
   } else {
     for (int h = tid; h < Hq; h += kThetaThreads) {
       double m = 1.0, n = 0.0, s = 1.0;
@@ -159,16 +196,14 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
       R.mn[h] = m; R.mn[Hq + h] = n; R.sh[h] = s;
     }
   }
-  if (need_hs) {  // every wave, as it becomes free
-    const uint32_t nst = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+  if (need_hs) {  // every wave, as it becomes free: 64 singles per pass
+    const uint32_t nst = (p.d1 + 63) / 64;
     for (;;) {
       uint32_t t = 0;
       if (lane == 0) t = atomicAdd(next_single_p, 1u);
       t = __builtin_amdgcn_readfirstlane(t);
       if (t >= nst) break;
-      const uint32_t r0 = t * kSinglesPerTile;
-      singles_tile<double>(r0, min(r0 + kSinglesPerTile, p.d1), p, pl, L, nocc, plan,
-                           [&](uint32_t r, double v, uint32_t) { R.hs[1 + r] = v; });
+      rbm_singles(t * 64 + lane, p, pl, L, nocc, plan, R.hs);
     }
   }
   __syncthreads();
@@ -179,24 +214,31 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   // ---- phase B: q[o][h] = exp(4 s_h x_o W[h][o]) and C(o) = exp(-2 x_o (a_o + sum_h s_h W[h][o])), a wave per row --
   // (kRowBatch rows x 2 columns per lane are requested together: an un-batched loop pays one L2 round trip per row)
   constexpr int kRowBatch = 4, kWaves = kBlock / 64;
-  for (int o0 = wave; o0 <= sorb; o0 += kWaves * kRowBatch) {
-    double e4[kRowBatch][2], wv[kRowBatch][2], sg[2], fq[2];
+  const double *__restrict__ E4 = rbm + rl.offE4p;
+  const uint32_t dE4 = (uint32_t)(rl.offE4m - rl.offE4p), uHq = (uint32_t)Hq;
+  bool pos[2];   // s_h > 0 for this lane's two columns
+  double fq[2];  // (m_h rho_h)^(1/4), 0 in the padding
+  double sgn[2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      sg[c] = lane + 64 * c < H ? R.sh[lane + 64 * c] : 0.0;
-      fq[c] = lane + 64 * c < H ? R.mn[Hq + lane + 64 * c] : 0.0;
-    }
+  for (int c = 0; c < 2; ++c) {
+    const int h = lane + 64 * c;
+    sgn[c] = h < H ? R.sh[h] : 0.0;
+    pos[c] = sgn[c] > 0.0;
+    fq[c] = h < H ? R.mn[Hq + h] : 0.0;
+  }
+  for (int o0 = wave; o0 <= sorb; o0 += kWaves * kRowBatch) {
+    double e4[kRowBatch][2], wv[kRowBatch][2];
 #pragma unroll
     for (int b = 0; b < kRowBatch; ++b) {
       const int o = o0 + b * kWaves;
       const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const int h = lane + 64 * c;
+        const uint32_t h = lane + 64 * c, idx = (uint32_t)o * uHq + h;
         e4[b][c] = 1.0; wv[b][c] = 0.0;
-        if (o < sorb && h < H) {
-          e4[b][c] = rbm[((sg[c] > 0.0) == occ ? rl.offE4p : rl.offE4m) + (size_t)o * Hq + h];
-          wv[b][c] = Wt[(size_t)o * Hq + h];
+        if (o < sorb && h < (uint32_t)H) {
+          e4[b][c] = E4[idx + (pos[c] == occ ? 0u : dE4)];
+          wv[b][c] = Wt[idx];
         }
       }
     }
@@ -205,32 +247,38 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
       const int o = o0 + b * kWaves;
       if (o > sorb) break;  // wave-uniform
       const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
-      const uint32_t row = o < sorb ? rbm_row(o, K) : (uint32_t)sorb;
-      double S = sg[0] * wv[b][0] + sg[1] * wv[b][1];
+      const uint32_t rowq = (o < sorb ? rbm_row(o, K) : (uint32_t)sorb) * uHq;
+      double S = sgn[0] * wv[b][0] + sgn[1] * wv[b][1];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        if (lane + 64 * c < Hq) R.q[(size_t)row * Hq + lane + 64 * c] = e4[b][c] * fq[c];
+        if (lane + 64 * c < Hq) R.q[rowq + lane + 64 * c] = e4[b][c] * fq[c];
       for (int h = lane + 128; h < Hq; h += 64) {  // more than 128 hidden units: the rest of the row
-        double v = 1.0;
-        if (o < sorb && h < H) {
+        double v = 0.0;
+        if (h < H) {
           const double s2 = R.sh[h];
-          v = rbm[((s2 > 0.0) == occ ? rl.offE4p : rl.offE4m) + (size_t)o * Hq + h];
-          S += s2 * Wt[(size_t)o * Hq + h];
+          v = R.mn[Hq + h];
+          if (o < sorb) {
+            const uint32_t idx = (uint32_t)o * uHq + h;
+            v *= E4[idx + ((s2 > 0.0) == occ ? 0u : dE4)];
+            S += s2 * Wt[idx];
+          }
         }
-        R.q[(size_t)row * Hq + h] = h < H ? v * R.mn[Hq + h] : 0.0;
+        R.q[rowq + h] = v;
       }
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) S += __shfl_xor(S, d);
-      if (lane == 0) {
-        double c = 1.0;
-        if (o < sorb) {
-          const double x = occ ? 1.0 : -1.0, a = rbm[rl.offVb + o];
-          c = exp(-2.0 * x * (a + S));
-          lnpsi += x * a;
-        }
-        R.Cq[o] = c;
-      }
+      if (lane == 0) R.Cq[o] = S;  // sum_h s_h W[h][o]; turned into C(o) below, all orbitals at once
     }
+  }
+  __syncthreads();
+  for (int o = tid; o <= sorb; o += kBlock) {
+    double c = 1.0;
+    if (o < sorb) {
+      const double x = bit_of<LEN>(wk.w, o) ? 1.0 : -1.0, a = rbm[rl.offVb + o];
+      c = exp(-2.0 * x * (a + R.Cq[o]));
+      lnpsi += x * a;
+    }
+    R.Cq[o] = c;
   }
   __syncthreads();
 #if defined(PYNQS_RBM_STOP) && PYNQS_RBM_STOP == 3
