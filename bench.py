@@ -361,6 +361,11 @@ def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -
         idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
         return DropinFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
                            torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev, path)
+    if name.startswith("syn") and name.endswith("_eloc_rbm"):
+        sorb = int(name[3:-9])
+        no = {56: 7, 120: 30, 184: 46}.get(sorb, sorb // 4)
+        h1, h2 = synth_integrals(sorb)
+        return RbmFused(f"syn{sorb}", sorb, 2 * no, no, no, h1, h2, synth_walkers(walkers, sorb, no, no, 4321 + rank), dev)
     if name.startswith("syn") and name.endswith("_dropin"):
         sorb = int(name[3:-7])
         no = {56: 7, 120: 30, 184: 46}.get(sorb, sorb // 4)
@@ -467,7 +472,7 @@ def main():
     if world == 1 and not args.no_extra and args.workload == "fe2s2_dropin":
         extra = {}
         for name, nw, steps in (("fe2s2_eloc_sample_space", args.walkers, 20), ("fe2s2_eloc_rbm", args.walkers, 20),
-                                ("syn120_dropin", 64, 10), ("syn184_dropin", 16, 5)):
+                                ("syn56_eloc_rbm", 4096, 10), ("syn120_dropin", 64, 10), ("syn184_dropin", 16, 5)):
             try:
                 w2 = make_workload(name, nw, rank, dev, args.path)
                 el2, k2 = timed(w2, 2, steps)

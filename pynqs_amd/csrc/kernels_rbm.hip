@@ -47,6 +47,7 @@ struct RbmBlocks {
   uint32_t nbf[4];
   uint32_t b[4];
   uint32_t ntiles;  // tiles of 64 blocks
+  MagicDiv dv[4];   // division by nbf[k]
 };
 
 static inline RbmBlocks make_rbm_blocks(const SDParams &p) {
@@ -56,6 +57,7 @@ static inline RbmBlocks make_rbm_blocks(const SDParams &p) {
   uint32_t acc = 0;
   for (int k = 0; k < 4; ++k) {
     B.nbf[k] = (nf[k] + 3) / 4;
+    B.dv[k] = make_magic(B.nbf[k]);
     acc += B.nbf[k] * ((ns[k] + 3) / 4);
     B.b[k] = acc;
   }
@@ -76,6 +78,7 @@ typedef __attribute__((address_space(3))) const double lds_cdouble;  // read thr
 
 struct RbmLds {
   double *q, *mn, *sh, *Cq, *hs;
+  uint32_t *rowaddr;  // [sorb + 2]: LDS byte address of an orbital's q row (the dummy's at index sorb)
 };
 
 __host__ __device__ inline size_t rbm_q_offset(const SDParams &p) { return (lds_fixed_bytes(p) + 15) & ~(size_t)15; }
@@ -87,7 +90,7 @@ __host__ __device__ inline size_t rbm_region_bytes(const SDParams &p, const RbmL
 
 __host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayout &rl) {
   return rbm_q_offset(p) + rbm_region_bytes(p, rl) +
-         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 48;  // + red, tile counter
+         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 48;  // + red, tile counter
 }
 
 __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o >> 1) + ((o & 1u) ? K : 0u); }
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   const uint64_t walker = wg / nchunks;
   const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthreads = blockDim.x, nwaves = nthreads >> 6;  // 3 or 4 waves: whichever divides the walker's tiles better
   if (tid == 0) { next_tile = 0; *next_single_p = 0; }
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
     R.sh = R.mn + 2 * Hq;
     R.Cq = R.sh + Hq;
     R.hs = R.Cq + (sorb + 2);
+    R.rowaddr = reinterpret_cast<uint32_t *>(R.hs + (p.d1 + 2));
   }
 #if defined(PYNQS_RBM_STOP) && PYNQS_RBM_STOP == 1
   if (tid == 0) eloc[walker] = (double)nocc;
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   const bool need_hs = chunk < max(tS, 1u);
   const double *__restrict__ Wt = rbm + rl.offWt;
   double lnpsi = 0.0;
-  constexpr int kThetaThreads = kBlock - 64;
-  if (wave == kBlock / 64 - 1) {
+  const int kThetaThreads = nthreads - 64;
+  if (wave == nwaves - 1) {
     if (need_hs) {
       const double hii = rbm_diag(p, pl, L, plan);
       if (lane == 0) R.hs[0] = hii;
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
 #endif
   // ---- phase B: q[o][h] = exp(4 s_h x_o W[h][o]) and C(o) = exp(-2 x_o (a_o + sum_h s_h W[h][o])), a wave per row --
   // (kRowBatch rows x 2 columns per lane are requested together: an un-batched loop pays one L2 round trip per row)
-  constexpr int kRowBatch = 4, kWaves = kBlock / 64;
+  constexpr int kRowBatch = 4;
+  const int kWaves = nwaves;
   const double *__restrict__ E4 = rbm + rl.offE4p;
   const uint32_t dE4 = (uint32_t)(rl.offE4m - rl.offE4p), uHq = (uint32_t)Hq;
   bool pos[2];   // s_h > 0 for this lane's two columns
@@ -271,7 +277,9 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
     }
   }
   __syncthreads();
-  for (int o = tid; o <= sorb; o += kBlock) {
+  const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)rbm_q_offset(p), rowB = (uint32_t)Hq * 8u;
+  for (int o = tid; o <= sorb; o += nthreads) {
+    R.rowaddr[o] = qbase + (o < sorb ? rbm_row(o, K) : (uint32_t)sorb) * rowB;
     double c = 1.0;
     if (o < sorb) {
       const double x = bit_of<LEN>(wk.w, o) ? 1.0 : -1.0, a = rbm[rl.offVb + o];
@@ -299,28 +307,26 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
     const uint32_t id = (chunk + lt * nchunks) * 64u + (uint32_t)lane;
     // class and block of this lane
     int cls = 4;
-    uint32_t bid = 0, nbf = 1, offF = 0, offS = 0, nF = 0, nS = 0;
-    if (id < B.b[0]) { cls = 0; bid = id; nbf = B.nbf[0]; offF = p.offSa; nF = p.d1; nS = 1; }
-    else if (id < B.b[1]) { cls = 1; bid = id - B.b[0]; nbf = B.nbf[1]; offF = p.offHPa; offS = p.offPPa; nF = p.noAA; nS = p.nvAA; }
-    else if (id < B.b[2]) { cls = 2; bid = id - B.b[1]; nbf = B.nbf[2]; offF = p.offHPb; offS = p.offPPb; nF = p.noBB; nS = p.nvBB; }
-    else if (id < B.b[3]) { cls = 3; bid = id - B.b[2]; nbf = B.nbf[3]; offF = p.offSa; offS = p.offSb; nF = p.nSa; nS = p.nSb; }
-    const uint32_t bs = bid / nbf, bf = bid - bs * nbf;
+    uint32_t bid = 0, nbf = 1, offF = 0, offS = 0, nF = 1, nS = 1;
+    MagicDiv dv = B.dv[0];
+    if (id < B.b[0]) { cls = 0; bid = id; nbf = B.nbf[0]; offF = p.offSa; nF = p.d1; }
+    else if (id < B.b[1]) { cls = 1; bid = id - B.b[0]; nbf = B.nbf[1]; dv = B.dv[1]; offF = p.offHPa; offS = p.offPPa; nF = p.noAA; nS = p.nvAA; }
+    else if (id < B.b[2]) { cls = 2; bid = id - B.b[1]; nbf = B.nbf[2]; dv = B.dv[2]; offF = p.offHPb; offS = p.offPPb; nF = p.noBB; nS = p.nvBB; }
+    else if (id < B.b[3]) { cls = 3; bid = id - B.b[2]; nbf = B.nbf[3]; dv = B.dv[3]; offF = p.offSa; offS = p.offSb; nF = p.nSa; nS = p.nSb; }
+    const uint32_t bs = mdiv(bid, dv), bf = bid - bs * nbf;
     uint32_t ef[4], es[4];
     // the q rows of the 8 entries' orbitals as 32-bit LDS addresses (the dynamic region starts at the static size;
     // an array of generic pointers loses the address space and its loads become flat_load)
     uint32_t rb[16];
-    const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)rbm_q_offset(p), rowB = (uint32_t)Hq * 8u, dummy = qbase + (uint32_t)sorb * rowB;
+    const bool real_fast = cls < 4, real_slow = cls >= 1 && cls < 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const uint32_t f = 4 * bf + i;
-      ef[i] = (cls < 4) ? L.tab[offF + min(f, nF - 1)] : 0u;
-      rb[2 * i] = cls < 4 ? qbase + rbm_row(ef[i] & 0xff, K) * rowB : dummy;
-      rb[2 * i + 1] = cls < 4 ? qbase + rbm_row((ef[i] >> 8) & 0xff, K) * rowB : dummy;
-      const uint32_t s = 4 * bs + i;
-      const bool real_slow = cls >= 1 && cls < 4;
-      es[i] = real_slow ? L.tab[offS + min(s, nS - 1)] : 0u;
-      rb[8 + 2 * i] = real_slow ? qbase + rbm_row(es[i] & 0xff, K) * rowB : dummy;
-      rb[8 + 2 * i + 1] = real_slow ? qbase + rbm_row((es[i] >> 8) & 0xff, K) * rowB : dummy;
+      ef[i] = real_fast ? L.tab[offF + min(4 * bf + i, nF - 1)] : 0u;
+      es[i] = real_slow ? L.tab[offS + min(4 * bs + i, nS - 1)] : 0u;
+      rb[2 * i] = R.rowaddr[real_fast ? (ef[i] & 0xff) : (uint32_t)sorb];
+      rb[2 * i + 1] = R.rowaddr[real_fast ? ((ef[i] >> 8) & 0xff) : (uint32_t)sorb];
+      rb[8 + 2 * i] = R.rowaddr[real_slow ? (es[i] & 0xff) : (uint32_t)sorb];
+      rb[8 + 2 * i + 1] = R.rowaddr[real_slow ? ((es[i] >> 8) & 0xff) : (uint32_t)sorb];
     }
     double acc[16];
 #pragma unroll
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   __syncthreads();
   if (tid == 0) {
     double s = 0.0;
-    for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+    for (int w = 0; w < nwaves; ++w) s += red[w];
     if (nchunks == 1) eloc[walker] = s;
     else atomicAdd(eloc + walker, s);
   }
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
     __syncthreads();
     if (tid == 0) {
       double s = 0.0;
-      for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+      for (int w = 0; w < nwaves; ++w) s += red[w];
       psi[walker] = exp(s);
     }
   }
@@ -477,12 +483,15 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   hipStream_t st = (hipStream_t)stream;
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, 8 * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   const int len = (sorb - 1) / 64 + 1;
+  // (3-wave workgroups divide Fe2S2's 9 tiles evenly but leave only 12 waves per CU -- LDS allows 4 workgroups --
+  // and were 8 % slower at 80 hidden units; the kernel itself runs with any multiple of 64 threads >= 128)
+  const uint32_t threads = kBlock;
   DISPATCH_LEN(len, {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return check_launch("hipFuncSetAttribute");
-    hipLaunchKernelGGL((eloc_rbm_kernel<LEN>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, rl, B, nchunks,
+    hipLaunchKernelGGL((eloc_rbm_kernel<LEN>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, rl, B, nchunks,
                        (const double *)plan, (const double *)rbm_table, eloc, psi);
   });
   return check_launch("eloc_rbm");
