@@ -70,6 +70,17 @@ struct LookupSink {
     }
   }
   __device__ __forceinline__ void one(uint32_t col, double h, const uint64_t (&ket)[LEN]) { add(col, h, ket); }
+  __device__ __forceinline__ void two(uint32_t c0, double h0, const uint64_t (&k0)[LEN], uint32_t c1, double h1, const uint64_t (&k1)[LEN]) {
+    if constexpr (HASH) {
+      const HashProbe<LEN> p0 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k0);
+      const HashProbe<LEN> p1 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k1);
+      accumulate(c0, h0, hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0));
+      accumulate(c1, h1, hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1));
+    } else {
+      add(c0, h0, k0);
+      add(c1, h1, k1);
+    }
+  }
   __device__ __forceinline__ void pair(uint32_t col, double h0, double h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) {
     if constexpr (HASH) {  // both first probes in flight together
       const HashProbe<LEN> p0 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k0);

@@ -84,9 +84,14 @@ __device__ __forceinline__ void store_h2(T *__restrict__ hrow, uint32_t col, T v
 }
 template <int LEN>
 __device__ __forceinline__ void store_ket(uint64_t *__restrict__ crow, uint32_t col, const uint64_t (&ket)[LEN]) {
-  uint64_t *dst = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(crow) + (size_t)(col * (uint32_t)(8 * LEN)));
+  char *dst = reinterpret_cast<char *>(crow) + (size_t)(col * (uint32_t)(8 * LEN));
+  if constexpr (LEN == 2) {  // one 16-byte store (rows of two-word kets are 16-byte aligned)
+    u64x2 v = {ket[0], ket[1]};
+    *reinterpret_cast<u64x2 *>(dst) = v;
+  } else {
 #pragma unroll
-  for (int i = 0; i < LEN; ++i) dst[i] = ket[i];
+    for (int i = 0; i < LEN; ++i) reinterpret_cast<uint64_t *>(dst)[i] = ket[i];
+  }
 }
 // two consecutive kets = 2*LEN words = LEN 16-byte stores; (row base + col) is even, so the address is
 // 16-byte aligned for every LEN
@@ -113,6 +118,11 @@ struct StoreSink {
   __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) const {
     store_h2<T>(hrow, col, h0, h1);
     if constexpr (WRITE_COMB) store_ket2<LEN>(crow, col, k0, k1);
+  }
+  __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&k0)[LEN], uint32_t c1, T h1, const uint64_t (&k1)[LEN]) const {
+    store_h<T>(hrow, c0, h0);
+    store_h<T>(hrow, c1, h1);
+    if constexpr (WRITE_COMB) { store_ket<LEN>(crow, c0, k0); store_ket<LEN>(crow, c1, k1); }
   }
 };
 

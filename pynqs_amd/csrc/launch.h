@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/pynqs_amd.h"
 
@@ -30,9 +31,10 @@ inline int check_launch(const char *what) {
 // chunks (multiples of 256 columns, never shorter than 2048 so that the per-workgroup table build
 // stays amortised).
 inline void plan_chunks(int64_t nbatch, uint32_t ncomb, uint32_t *nchunks, uint32_t *chunk_len) {
-  const int64_t want = 4096;  // workgroups in flight target: 2 waves of 256 CUs x 8
+  static const int64_t want = getenv("PYNQS_WANT_WG") ? atoll(getenv("PYNQS_WANT_WG")) : 4096;  // workgroups in flight target
+  static const int64_t minlen = getenv("PYNQS_MIN_CHUNK") ? atoll(getenv("PYNQS_MIN_CHUNK")) : 2048;
   int64_t c = nbatch >= want ? 1 : (want + nbatch - 1) / nbatch;
-  int64_t maxc = (ncomb + 2047) / 2048;
+  int64_t maxc = (ncomb + minlen - 1) / minlen;
   if (c > maxc) c = maxc;
   if (c < 1) c = 1;
   uint32_t len = (uint32_t)((ncomb + c - 1) / c);

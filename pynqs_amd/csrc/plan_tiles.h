@@ -32,18 +32,30 @@ struct ClassRange {
   uint32_t npairs;   // complete pairs
 };
 
+template <bool PAIRED>
 __device__ __forceinline__ ClassRange class_range(uint32_t b0, uint32_t b1, uint32_t rlo, uint32_t rhi, uint32_t odd_base) {
   ClassRange g;
   g.a0 = max(rlo, b0);
   g.a1 = max(g.a0, min(rhi, b1));
-  g.r_e = g.a0 + ((odd_base + g.a0 + 1) & 1u);
-  g.npairs = g.a1 > g.r_e ? (g.a1 - g.r_e) / 2 : 0;
+  if constexpr (PAIRED) {
+    g.r_e = g.a0 + ((odd_base + g.a0 + 1) & 1u);
+    g.npairs = g.a1 > g.r_e ? (g.a1 - g.r_e) / 2 : 0;
+  } else {  // slots are single ranks: npairs counts ranks
+    g.r_e = g.a0;
+    g.npairs = g.a1 - g.a0;
+  }
   return g;
 }
 
+// Multi-word ONVs (LEN >= 2) do NOT pair neighbouring columns: a ket is already 16 or 24 bytes, and a lane that
+// writes two neighbouring kets makes every store instruction cover only half (a third) of each cache line --
+// the L2 then sees two (three) partial write requests per line and the comb stream runs at 2.7 TB/s instead of
+// ~6 (measured at sorb 120, --no-comb ablation).  There a lane takes columns c + lane and c + 64 + lane, so that
+// each instruction writes one dense span.
 // Sink concept:
 //   void one(uint32_t col, T h, const uint64_t (&ket)[LEN]);                       // a single column
 //   void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]);  // col, col+1
+//   void two(uint32_t c0, T h0, const uint64_t (&k0)[LEN], uint32_t c1, T h1, const uint64_t (&k1)[LEN]);  // any two
 // `next_tile` is a workgroup-shared counter that must be 0 when the first wave arrives (set it before
 // build_walker_tables, whose final barrier publishes it).
 template <int LEN, typename T, typename Sink>
@@ -58,10 +70,12 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
   const uint32_t hi = min(lo + chunk_len, ncomb);
   const uint32_t rlo = lo == 0 ? 0 : lo - 1, rhi = hi - 1;  // excitation ranks [rlo, rhi): column = rank + 1
 
-  const ClassRange gA = class_range(p.d1, p.d2, rlo, rhi, odd_base);
-  const ClassRange gB = class_range(p.d2, p.d3, rlo, rhi, odd_base);
-  const ClassRange gO = class_range(p.d3, p.nsd, rlo, rhi, odd_base);
-  const uint32_t tA = (gA.npairs + kTile - 1) / kTile, tB = (gB.npairs + kTile - 1) / kTile, tO = (gO.npairs + kTile - 1) / kTile;
+  constexpr bool kPaired = LEN == 1;
+  constexpr uint32_t kSlots = kPaired ? kTile : 2 * kTile;  // slots per tile: pair slots, or single ranks
+  const ClassRange gA = class_range<kPaired>(p.d1, p.d2, rlo, rhi, odd_base);
+  const ClassRange gB = class_range<kPaired>(p.d2, p.d3, rlo, rhi, odd_base);
+  const ClassRange gO = class_range<kPaired>(p.d3, p.nsd, rlo, rhi, odd_base);
+  const uint32_t tA = (gA.npairs + kSlots - 1) / kSlots, tB = (gB.npairs + kSlots - 1) / kSlots, tO = (gO.npairs + kSlots - 1) / kSlots;
   // The singles tiles of the walker are dealt round-robin to its workgroups (they cost far more per column
   // than doubles; left to the first chunk they would make it the straggler when rows are cut into many chunks).
   const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
@@ -84,7 +98,7 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
     if (tile >= ntiles) break;
     if (tile == 0) {
       // unpaired columns of the three classes: lanes 0..5
-      if (lane < 6) {
+      if (kPaired && lane < 6) {
         const int k = lane >> 1;
         const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
         const uint32_t tail = g.r_e + 2 * g.npairs;
@@ -124,9 +138,35 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
     // which class (wave-uniform)
     const int k = tile < tA ? 0 : (tile < tA + tB ? 1 : 2);
     const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
-    const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kTile;  // first pair slot of the tile
+    const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kSlots;  // first slot of the tile
     const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
     const T *__restrict__ V = k == 2 ? Vab : Vss + (size_t)k * pl.NP * pl.NP;
+    if constexpr (!kPaired) {
+      // ranks first + (2u + v) * 64 + lane: every store instruction of the sink covers 64 neighbouring columns
+      if (first + kSlots <= g.npairs) {
+        PendingDouble<T> d[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) d[u][v] = fetch_double<LEN, T>(g.r_e + first + (2 * u + v) * 64 + lane, c, L, V);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          uint64_t k0[LEN], k1[LEN];
+          const T h0 = finish_double<LEN, T>(d[u][0], c, wk, k0);
+          const T h1 = finish_double<LEN, T>(d[u][1], c, wk, k1);
+          const uint32_t r0 = g.r_e + first + (2 * u) * 64 + lane;
+          sink.two(r0 + 1, h0, k0, r0 + 65, h1, k1);
+        }
+      } else {
+        for (uint32_t m = first + lane; m < g.npairs; m += 64) {
+          uint64_t ket[LEN];
+          const PendingDouble<T> d0 = fetch_double<LEN, T>(g.r_e + m, c, L, V);
+          const T h = finish_double<LEN, T>(d0, c, wk, ket);
+          sink.one(g.r_e + m + 1, h, ket);
+        }
+      }
+      continue;
+    }
     if (first + kTile <= g.npairs) {  // full tile: no guards
       PendingDouble<T> d[U][2];
 #pragma unroll
