@@ -107,10 +107,13 @@ __device__ __forceinline__ void store_ket2(uint64_t *__restrict__ crow, uint32_t
 }
 
 // The drop-in kernel: every column of the walker's range goes to HBM (comb and Hmat in the reference layout).
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+
 template <int LEN, typename T, bool WRITE_COMB>
 struct StoreSink {
   T *__restrict__ hrow;
   uint64_t *__restrict__ crow;
+  lds_u64 *stage;  // this wave's quarter of the LDS scratch (free while the wave is in a doubles tile)
   __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&ket)[LEN]) const {
     store_h<T>(hrow, col, h);
     if constexpr (WRITE_COMB) store_ket<LEN>(crow, col, ket);
@@ -119,10 +122,32 @@ struct StoreSink {
     store_h2<T>(hrow, col, h0, h1);
     if constexpr (WRITE_COMB) store_ket2<LEN>(crow, col, k0, k1);
   }
+  // columns c0 = b + lane and c1 = b + 64 + lane of every lane of the wave (plan_tiles.h)
   __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&k0)[LEN], uint32_t c1, T h1, const uint64_t (&k1)[LEN]) const {
     store_h<T>(hrow, c0, h0);
     store_h<T>(hrow, c1, h1);
-    if constexpr (WRITE_COMB) { store_ket<LEN>(crow, c0, k0); store_ket<LEN>(crow, c1, k1); }
+    if constexpr (WRITE_COMB) {
+      if constexpr (LEN == 3) {
+        // 24-byte kets: a lane storing its own ket covers a third of each line per instruction.  64 kets of the
+        // wave are one span of 192 words: pass them through the wave's LDS quarter and let lane l store words
+        // l, l + 64, l + 128: three dense 512-byte stores.  (LDS operations of one wave execute in order.)
+        const uint32_t lane = threadIdx.x & 63;
+        lds_u64 *st = stage;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) st[lane * 3 + i] = half ? k1[i] : k0[i];
+          __builtin_amdgcn_wave_barrier();
+          uint64_t *dst = crow + (size_t)((half ? c1 : c0) - lane) * 3;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dst[lane + 64 * k] = st[lane + 64 * k];
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
+        store_ket<LEN>(crow, c0, k0);
+        store_ket<LEN>(crow, c1, k1);
+      }
+    }
   }
 };
 
@@ -142,7 +167,9 @@ __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *_
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a workgroup barrier
   const uint32_t ncomb = p.nsd + 1;
-  StoreSink<LEN, T, WRITE_COMB> sink{hmat + (size_t)walker * ncomb, comb + (size_t)walker * ncomb * LEN};
+  static_assert((kDiagTile / 4) * sizeof(T) >= 192 * 8, "a wave's scratch quarter must hold 64 three-word kets");
+  StoreSink<LEN, T, WRITE_COMB> sink{hmat + (size_t)walker * ncomb, comb + (size_t)walker * ncomb * LEN,
+                                     (lds_u64 *)(reinterpret_cast<T *>(L.scratch) + (threadIdx.x >> 6) * (kDiagTile / 4))};
   const uint32_t odd_base = (uint32_t)((walker * (uint64_t)ncomb) & 1u);  // 16-byte alignment of the pair stores
   visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, odd_base, &next_tile, sink);
 }
