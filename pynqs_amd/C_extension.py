@@ -329,6 +329,7 @@ class RBMTable:
         ts = [weights, hidden_bias] + ([visible_bias] if visible_bias is not None else [])
         if any(t.dtype != torch.float64 for t in ts):
             raise RuntimeError("the fused RBM local energy is float64 only")
+        src = ts
         dev, ts, _ = _stage(*[t.detach().contiguous() for t in ts])
         self.nhidden, self.sorb, self.device = int(weights.size(0)), int(weights.size(1)), dev
         nbytes = N.lib().pynqs_rbm_table_bytes(self.sorb, self.nhidden)
@@ -337,7 +338,8 @@ class RBMTable:
         self.buf = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
         N.check(N.lib().pynqs_rbm_table_build(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr() if len(ts) > 2 else None,
                                               self.sorb, self.nhidden, self.buf.data_ptr(), _stream(dev)), "rbm_table_build")
-        torch.cuda.current_stream(dev).synchronize()  # ts may be temporaries
+        if any(a.data_ptr() != b.data_ptr() for a, b in zip(src, ts)):
+            torch.cuda.current_stream(dev).synchronize()  # staging copies must outlive the build kernel
 
     def data_ptr(self) -> int:
         return self.buf.data_ptr()

@@ -31,7 +31,7 @@ from . import _native as N
 from .C_extension import get_comb_hij_fused, get_hij_torch
 from .distributed import get_rank
 from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, check_para, get_Num_SinglesDoubles,
-                              spin_flip_onv, spin_flip_sign, split_batch_idx)
+                              spin_flip_onv, spin_flip_sign, split_batch_idx, unique_onv)
 
 FUSED = True  # use the fused sample-space / reduce kernels when the configuration allows it
 FUSED_RBM = True  # SIMPLE method: evaluate a real RBM ansatz inside the kernel (pynqs_eloc_rbm) instead of calling the module
@@ -46,7 +46,8 @@ def Func(func: Callable[..., Tensor], x: Tensor, WF_LUT: Optional[WavefunctionLU
         lut_idx, lut_not_idx, lut_value = WF_LUT.lookup(x)
     _x = x[lut_not_idx] if use_lut else x
     if use_unique:
-        unique_x, inverse = torch.unique(_x, dim=0, return_inverse=True)
+        unique_x, inverse = unique_onv(_x) if _x.dtype == torch.uint8 and _x.dim() == 2 and _x.size(1) % 8 == 0 \
+            else torch.unique(_x, dim=0, return_inverse=True)
         psi0 = torch.index_select(func(unique_x), 0, inverse)
     else:
         psi0 = func(_x)
@@ -259,7 +260,11 @@ def local_energy(
             first = col == 0
             psi_x[row[first]] = psi[first]
             w = (psi / psi_x[row]) * h.to(_real_dtype(dtype))
-            eloc = torch.zeros(batch, dtype=w.dtype, device=x.device).index_add_(0, row, w)
+            # rows are contiguous segments: a segmented sum instead of index_add_ (atomics: 2.7 of 5.0 ms on Fe2S2)
+            if w.is_complex():
+                eloc = torch.view_as_complex(torch.segment_reduce(torch.view_as_real(w).contiguous(), "sum", lengths=counts, unsafe=True))
+            else:
+                eloc = torch.segment_reduce(w, "sum", lengths=counts, unsafe=True)
             t3 = time.time_ns()
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi_x, ((t2 - t0) / 1e6, 0.0, (t3 - t2) / 1e6)
 

@@ -108,3 +108,21 @@ def test_split_helpers_and_sorting():
     byte = torch.tensor([[0b11011011, 0, 0, 0, 0, 0, 0, 0], [0b00111001, 0, 0, 0, 0, 0, 0, 0]], dtype=torch.uint8)
     assert pf.spin_flip_sign(byte, 8).tolist() == pf.spin_flip_sign(occ, 8).tolist() == [1, -1]
     assert pf.spin_flip_onv(byte, 8)[:, 0].tolist() == [0b11100111, 0b00110110]
+
+
+def test_unique_onv_matches_torch_unique():
+    """Word-wise unique of onv rows = torch.unique(dim=0) up to the order of the unique rows (1-3 words, empty)."""
+    import torch
+    from pynqs_amd.public_function import unique_onv
+
+    g = torch.Generator().manual_seed(3)
+    for L in (1, 2, 3):
+        x = torch.randint(0, 256, (64, 8 * L), dtype=torch.uint8, generator=g)
+        x = x[torch.randint(0, 64, (1000,), generator=g)]  # many duplicates
+        u, inv = unique_onv(x)
+        ref, _ = torch.unique(x, dim=0, return_inverse=True)
+        assert torch.equal(u[inv], x)
+        assert u.size(0) == ref.size(0)
+        assert torch.equal(torch.unique(u, dim=0), ref)
+    u, inv = unique_onv(torch.empty((0, 16), dtype=torch.uint8))
+    assert u.shape == (0, 16) and inv.numel() == 0
