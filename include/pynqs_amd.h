@@ -158,6 +158,14 @@ int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, cons
 int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                    const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream);
 
+/* ---- Green's-function Monte-Carlo move: gfmc/walker.py:260-279 (sample_update) in one kernel ---------------
+ * green double[n][ncomb] (the fixed-node Green's function row of each walker, >= 0), rand_num double[n] in [0, 1),
+ * comb uint64[n][ncomb][len] (get_comb_hij_fused's first output).  Per walker: beta = sum_k green[k];
+ * index = first k with (green[0] + ... + green[k]) >= rand_num * beta  (the reference's
+ * searchsorted(cumsum / beta, rand_num, right=False), clamped to ncomb - 1); x_new = comb[index]. */
+int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const double *rand_num, const uint64_t *comb,
+                      int sorb, int64_t *index, double *beta, uint64_t *x_new, void *stream);
+
 /* REDUCE method front end: vmc/energy/eloc.py:205-324 with eps_sample == 0 keeps the columns with
  * |<x|H|x'>| >= eps (eloc.py:297-298; column 0 is treated like any other).  Two passes, nothing materialised:
  *   pynqs_reduce_count : counts[nbatch] = kept columns per walker

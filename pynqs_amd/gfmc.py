@@ -50,8 +50,27 @@ def green_kernel(x: Tensor, Lambda: float, h1e: Tensor, h2e: Tensor, ansatz, ans
         return eloc, gk, comb_x, False, neg
 
 
+FUSED_SAMPLE = True  # one kernel for sum + cumsum + searchsorted + gather (pynqs_gfmc_sample) when the row is float64 on the GPU
+
+
 def sample_update(x: Tensor, weight: Tensor, comb_x: Tensor, green_kernel: Tensor, rand_num: Optional[Tensor] = None):
     """gfmc/walker.py:260-279: x_new ~ G(. <- x) / beta, weight *= beta."""
+    if (FUSED_SAMPLE and green_kernel.is_cuda and green_kernel.dtype == torch.float64 and green_kernel.dim() == 2
+            and comb_x.is_cuda and comb_x.dtype == torch.uint8 and green_kernel.size(0) > 0):
+        from . import _native as N
+
+        n, m = green_kernel.shape
+        L = comb_x.size(-1) // 8
+        dev = green_kernel.device
+        if rand_num is None:
+            rand_num = torch.rand((n, 1), dtype=torch.float64, device=dev)
+        gk, cx, rn = green_kernel.contiguous(), comb_x.contiguous(), rand_num.to(torch.float64).contiguous()
+        index = torch.empty(n, dtype=torch.int64, device=dev)
+        beta = torch.empty((n, 1), dtype=torch.float64, device=dev)
+        x_new = torch.empty((n, 8 * L), dtype=torch.uint8, device=dev)
+        N.check(N.lib().pynqs_gfmc_sample(gk.data_ptr(), n, m, rn.data_ptr(), cx.data_ptr(), 64 * L, index.data_ptr(), beta.data_ptr(),
+                                          x_new.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "pynqs_gfmc_sample")
+        return x_new, weight * beta.squeeze(), beta, int((index != 0).sum().item())
     beta = green_kernel.sum(-1, keepdim=True)
     cum_prob = green_kernel.cumsum(-1) / beta
     if rand_num is None:

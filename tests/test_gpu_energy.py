@@ -206,3 +206,49 @@ def test_gfmc_step_matches_direct_tensor_algebra(env):
     cum = gk.cumsum(-1) / gk.sum(-1, keepdim=True)
     idx = (cum < 0.37).sum(-1)
     assert torch.equal(x_new, comb[torch.arange(5), idx]) and torch.allclose(w_new, gk.sum(-1))
+
+
+@pytest.mark.parametrize("n,m,L", [(7, 1, 1), (5, 27, 1), (33, 255, 1), (9, 256, 2), (9, 257, 3), (64, 7876, 1), (3, 300_001, 2)])
+def test_gfmc_sample_kernel_matches_sequential_oracle(n, m, L):
+    """pynqs_gfmc_sample (sum + cumsum + searchsorted + gather in one kernel) against a sequential float64 cumsum:
+    index = first k with cum[k] >= u * beta (gfmc/walker.py:268-271); a different k is accepted only when the
+    running sum is within rounding of the target there.  Rows contain exact zeros, one row is a single spike and
+    the uniforms include 0 and 1 - 2^-53."""
+    from pynqs_amd import gfmc
+
+    g = torch.Generator().manual_seed(100 * n + m)
+    gk = torch.rand(n, m, generator=g, dtype=torch.float64)
+    gk[torch.rand(n, m, generator=g) < 0.6] = 0.0
+    gk[0] = 0.0
+    gk[0, m // 2] = 3.0
+    gk[:, 0] += 1e-3  # the diagonal (Lambda - H_00) is positive
+    u = torch.rand(n, 1, generator=g, dtype=torch.float64)
+    u[0, 0] = 0.0
+    if n > 1:
+        u[1, 0] = 1.0 - 2.0 ** -53
+    comb = torch.randint(0, 256, (n, m, 8 * L), generator=g, dtype=torch.uint8)
+    w = torch.rand(n, generator=g, dtype=torch.float64)
+    d = torch.device("cuda")
+    old = gfmc.FUSED_SAMPLE
+    try:
+        gfmc.FUSED_SAMPLE = True
+        x_new, w_new, beta, acc = gfmc.sample_update(None, w.to(d), comb.to(d), gk.to(d), u.to(d))
+    finally:
+        gfmc.FUSED_SAMPLE = old
+    cum = np.cumsum(gk.numpy(), axis=1)
+    tot = cum[:, -1]
+    np.testing.assert_allclose(beta.cpu().numpy().ravel(), tot, rtol=1e-13)
+    np.testing.assert_allclose(w_new.cpu().numpy(), w.numpy() * tot, rtol=1e-13)
+    xn = x_new.cpu()
+    nz = 0
+    for i in range(n):
+        hits = np.nonzero((comb[i] == xn[i]).all(dim=1).numpy())[0]
+        assert hits.size >= 1
+        target = u[i, 0].item() * tot[i]
+        want = min(int(np.searchsorted(cum[i], target, side="left")), m - 1)
+        if want not in hits:
+            k = int(hits[0])
+            lo = cum[i, k - 1] if k else 0.0
+            assert abs(cum[i, min(k, want)] - target) <= 1e-12 * tot[i] or (lo - 1e-12 * tot[i] <= target <= cum[i, k] + 1e-12 * tot[i]), (i, k, want)
+        nz += int(want != 0)
+    assert abs(acc - nz) <= 1
