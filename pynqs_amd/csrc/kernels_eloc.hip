@@ -361,14 +361,22 @@ static int launch_reduce(const uint64_t *bra, int64_t nbatch, int sorb, int nele
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
   const size_t lds = lds_bytes_eloc(p, esz);
-  if (lds > 64 * 1024) return set_error(PYNQS_EINVAL, "too many single excitations for the LDS staging buffer");
+  if (lds > 158 * 1024) return set_error(PYNQS_EINVAL, "too many single excitations for the LDS staging buffer");
   DISPATCH_LEN(len, {
-    if (dtype == PYNQS_F64)
+    if (dtype == PYNQS_F64) {
+      // beyond the default 64 KiB of dynamic LDS (sorb >~ 150) the kernel has to be told
+      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&reduce_kernel<LEN, double, EMIT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("hipFuncSetAttribute");
       hipLaunchKernelGGL((reduce_kernel<LEN, double, EMIT>), dim3((uint32_t)nbatch), dim3(kBlock), lds, st, bra, p, pl,
                          (const double *)plan, eps, counts, offsets, kept_col, kept_onv, (double *)kept_h);
-    else
+    } else {
+      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&reduce_kernel<LEN, float, EMIT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("hipFuncSetAttribute");
       hipLaunchKernelGGL((reduce_kernel<LEN, float, EMIT>), dim3((uint32_t)nbatch), dim3(kBlock), lds, st, bra, p, pl,
                          (const float *)plan, (float)eps, counts, offsets, kept_col, kept_onv, (float *)kept_h);
+    }
   });
   return check_launch(EMIT ? "reduce_emit" : "reduce_count");
 }

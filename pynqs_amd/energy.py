@@ -127,13 +127,15 @@ def _reduce_select(comb_hij: Tensor, eps: float, eps_sample: int) -> Tensor:
 
 
 def _fused_lds_ok(sorb: int, noa: int, nob: int, elem: int = 8) -> bool:
-    """The fused E_loc kernels stage all singles' matrix elements in LDS (<= 64 KiB static limit)."""
+    """The REDUCE compaction kernels stage all singles' matrix elements in LDS (the CU has 160 KiB)."""
     k = sorb // 2
     nva, nvb = k - noa, k - nob
     d1 = noa * nva + nob * nvb
     tab = d1 + noa * (noa - 1) // 2 + nva * (nva - 1) // 2 + nob * (nob - 1) // 2 + nvb * (nvb - 1) // 2
     fixed = (tab * 4 + 3 * 192 + 7) // 8 * 8
-    return fixed + 2048 * elem + (d1 + 2) * elem <= 64 * 1024
+    if sorb <= 64:
+        fixed += tab * 8  # ket-mask tables of one-word determinants
+    return fixed + 2048 * elem + (d1 + 2) * elem <= 158 * 1024
 
 
 def _real_rbm_params(ansatz):

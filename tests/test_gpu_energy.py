@@ -252,3 +252,24 @@ def test_gfmc_sample_kernel_matches_sequential_oracle(n, m, L):
             assert abs(cum[i, min(k, want)] - target) <= 1e-12 * tot[i] or (lo - 1e-12 * tot[i] <= target <= cum[i, k] + 1e-12 * tot[i]), (i, k, want)
         nz += int(want != 0)
     assert abs(acc - nz) <= 1
+
+
+def test_reduce_compaction_beyond_64k_lds():
+    """sorb 160 with 40 + 40 electrons: walker tables + staging + 3200 singles' elements need 67 KiB of LDS (the
+    default dynamic limit is 64): the compaction must still equal |Hmat| >= eps of the materialised row."""
+    from conftest import rand_occ, synth_integrals
+    from pynqs_amd import C_extension as cx, energy
+
+    sorb, no = 160, 40
+    h1, h2 = synth_integrals(sorb)
+    d = torch.device("cuda")
+    h1e, h2e = torch.from_numpy(h1).to(d), torch.from_numpy(h2).to(d)
+    x = cx.tensor_to_onv(torch.from_numpy(rand_occ(2, sorb, no, no, seed=9)).to(d), sorb)
+    assert energy._fused_lds_ok(sorb, no, no)
+    row, col, onv, h, counts = energy.reduce_compact(x, h1e, h2e, sorb, 2 * no, no, no, 0.49)
+    comb, hm = cx.get_comb_hij_fused(x, h1e, h2e, sorb, 2 * no, no, no)
+    keep = hm.abs() >= 0.49
+    r2, c2 = torch.where(keep)
+    assert torch.equal(row, r2) and torch.equal(col.long(), c2)
+    assert torch.equal(h, hm[keep]) and torch.equal(onv, comb[keep])
+    assert torch.equal(counts, keep.sum(1))
