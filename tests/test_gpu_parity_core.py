@@ -195,3 +195,23 @@ def test_edge_cases_and_errors(cx, fe2s2):
     with pytest.raises(OverflowError):
         cx.check_sorb(184, 130)
     cx.check_sorb(56, 14)  # accepted here (run-time word count); the reference's L=1 build rejects it
+
+
+@pytest.mark.parametrize("sorb", [8, 40, 64, 72, 128, 184, 192, 12, 66])
+def test_tensor_to_onv_aligned_and_unaligned_rows(sorb):
+    """tensor_to_onv (cpu_tensor.cpp:8-44): 1 = occupied, ANY other byte = empty; the 8-bytes-per-load kernel
+    (sorb % 8 == 0) and the byte kernel must both equal a numpy packing, also from an unaligned view."""
+    from pynqs_amd import C_extension as cx
+
+    g = np.random.default_rng(sorb)
+    occ = g.choice(np.array([0, 1, 1, 2, 255], dtype=np.uint8), size=(257, sorb))
+    L = (sorb - 1) // 64 + 1
+    bits = np.zeros((257, 64 * L), dtype=np.uint8)
+    bits[:, :sorb] = occ == 1
+    want = np.packbits(bits.reshape(257, 8 * L, 8), axis=-1, bitorder="little").reshape(257, 8 * L)
+    got = cx.tensor_to_onv(torch.from_numpy(occ).cuda(), sorb)
+    assert np.array_equal(got.cpu().numpy(), want)
+    flat = torch.zeros(257 * sorb + 3, dtype=torch.uint8, device="cuda")
+    flat[3:] = torch.from_numpy(occ).cuda().reshape(-1)
+    got2 = cx.tensor_to_onv(flat[3:].view(257, sorb), sorb)  # storage offset 3: not 8-byte aligned
+    assert np.array_equal(got2.cpu().numpy(), want)
