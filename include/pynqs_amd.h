@@ -167,14 +167,20 @@ int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const doubl
                       int sorb, int64_t *index, double *beta, uint64_t *x_new, void *stream);
 
 /* REDUCE method front end: vmc/energy/eloc.py:205-324 with eps_sample == 0 keeps the columns with
- * |<x|H|x'>| >= eps (eloc.py:297-298; column 0 is treated like any other).  Two passes, nothing materialised:
- *   pynqs_reduce_count : counts[nbatch] = kept columns per walker
- *   pynqs_reduce_emit  : offsets[nbatch] = exclusive prefix sum of counts (caller) -> kept_col int32[total],
- *                        kept_onv uint64[total][len], kept_h T[total], ascending column order per walker. */
+ * |<x|H|x'>| >= eps (eloc.py:297-298; column 0 is treated like any other).  Two passes, nothing materialised, no
+ * atomics.  A walker's row is visited in tiles; T = pynqs_reduce_tiles(...) tiles per walker:
+ *   pynqs_reduce_tiles : [host] T for this batch size and system (-1 on bad arguments)
+ *   pynqs_reduce_count : tile_counts uint32[nbatch][T] = kept columns per tile (0 for unused tiles)
+ *   pynqs_reduce_emit  : tile_offsets int64[nbatch][T] = exclusive prefix sum of tile_counts over the whole flattened
+ *                        array (caller) -> kept_col int32[total], kept_onv uint64[total][len], kept_h T[total].
+ *                        Walker w's records are the contiguous range that its tiles span; inside it they come tile by
+ *                        tile in a reproducible order (diagonal, singles, doubles), NOT in ascending column order --
+ *                        kept_col names the column of each record. */
+int64_t pynqs_reduce_tiles(int64_t nbatch, int sorb, int nele, int noA, int noB);
 int pynqs_reduce_count(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
-                       const void *plan, int dtype, double eps, int64_t *counts, void *stream);
+                       const void *plan, int dtype, double eps, uint32_t *tile_counts, void *stream);
 int pynqs_reduce_emit(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
-                      const void *plan, int dtype, double eps, const int64_t *offsets, int32_t *kept_col,
+                      const void *plan, int dtype, double eps, const int64_t *tile_offsets, int32_t *kept_col,
                       uint64_t *kept_onv, void *kept_h, void *stream);
 
 #ifdef __cplusplus

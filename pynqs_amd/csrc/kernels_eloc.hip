@@ -13,32 +13,6 @@
 
 namespace pynqs {
 
-// column -> (h, ket) for any column of the walker, given hs for the singles/diagonal
-template <int LEN, typename T>
-__device__ __forceinline__ T column_element(uint32_t col, const SDParams &p, const PlanLayout &pl, const LdsLayout &L,
-                                            const T *__restrict__ plan, const Walker<LEN> &wk, const T *__restrict__ hs,
-                                            uint64_t (&ket)[LEN]) {
-  if (col == 0) {
-#pragma unroll
-    for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
-    return hs[0];
-  }
-  const uint32_t r = col - 1;
-  if (r < p.d1) {
-    const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-#pragma unroll
-    for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
-    toggle<LEN>(ket, e & 0xff); toggle<LEN>(ket, (e >> 8) & 0xff);
-    return hs[col];
-  }
-  return double_element<LEN, T>(r, p, pl, L, plan, wk, ket);
-}
-
-__host__ __device__ inline size_t lds_bytes_eloc(const SDParams &p, size_t elem) {
-  // fixed part + staging tile + hs[1 + d1]
-  return lds_bytes(p, elem) + (size_t)(p.d1 + 2) * elem;
-}
-
 // -------------------------------------------------------------------------------------------------
 // SAMPLE_SPACE local energy: the tile scheduler of the drop-in kernel (plan_tiles.h) with a sink that, instead
 // of storing the column, looks psi(x') up and accumulates h * psi(x') in registers.  acc[walker] receives the
@@ -69,6 +43,7 @@ struct LookupSink {
       if constexpr (CPLX) psi0[1] = vi;
     }
   }
+  __device__ __forceinline__ void tile_begin(uint32_t) const {}
   __device__ __forceinline__ void one(uint32_t col, double h, const uint64_t (&ket)[LEN]) { add(col, h, ket); }
   __device__ __forceinline__ void two(uint32_t c0, double h0, const uint64_t (&k0)[LEN], uint32_t c1, double h1, const uint64_t (&k1)[LEN]) {
     if constexpr (HASH) {
@@ -192,64 +167,101 @@ __global__ __launch_bounds__(kBlock) void eloc_divide_kernel(double *__restrict_
 }
 
 // -------------------------------------------------------------------------------------------------
-// REDUCE front end: keep |h| >= eps.  One workgroup per walker; columns are visited in rounds of kBlock
-// consecutive columns so that a workgroup-wide exclusive scan of the keep flags gives ascending positions.
+// REDUCE front end: keep |h| >= eps (vmc/energy/eloc.py:297-298).  Two passes over the tile scheduler of the drop-in
+// kernel (plan_tiles.h), one workgroup per (walker, chunk), no workgroup barrier after the table build, no atomics:
+//   count: tile_counts[walker][chunk][tile] = kept columns of that tile (a wave owns a tile and visits its columns
+//          in a fixed order; the running count lives in a wave-private LDS word because some columns are produced
+//          inside divergent code)
+//   emit : the caller turns the counts into exclusive offsets; the wave writes its tile's records from there.
+// Records of a walker are therefore contiguous and in a reproducible order (tile by tile: diagonal and odd columns,
+// singles, the three classes of doubles), not in ascending column order: kept_col says which column each one is.
 template <int LEN, typename T, bool EMIT>
-__global__ __launch_bounds__(kBlock) void reduce_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
-                                                        const T *__restrict__ plan, T eps, int64_t *__restrict__ counts,
-                                                        const int64_t *__restrict__ offsets, int32_t *__restrict__ kept_col,
-                                                        uint64_t *__restrict__ kept_onv, T *__restrict__ kept_h) {
+struct ReduceSink {
+  T eps;
+  volatile uint32_t *run;              // this wave's running count inside the current tile (LDS)
+  uint32_t *__restrict__ tile_counts;  // count pass: this workgroup's slice
+  const int64_t *__restrict__ tile_off;  // emit pass: this workgroup's slice
+  int32_t *__restrict__ kept_col;
+  uint64_t *__restrict__ kept_onv;
+  T *__restrict__ kept_h;
+  uint32_t tile;    // current tile (0xffffffff: none)
+  int64_t base;     // emit: first record of the current tile
+
+  __device__ __forceinline__ void flush() {
+    if constexpr (!EMIT) {
+      if (tile != 0xffffffffu && (threadIdx.x & 63) == 0) tile_counts[tile] = *run;
+    }
+  }
+  __device__ __forceinline__ void tile_begin(uint32_t t) {
+    flush();
+    tile = t;
+    if ((threadIdx.x & 63) == 0) *run = 0;
+    if constexpr (EMIT) base = tile_off[t];
+  }
+  __device__ __forceinline__ void put(int64_t pos, uint32_t col, T h, const uint64_t (&ket)[LEN]) const {
+    kept_col[pos] = (int32_t)col;
+    kept_h[pos] = h;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) kept_onv[pos * LEN + i] = ket[i];
+  }
+  // adds `total` to the wave's running count and returns its previous value to all ACTIVE lanes
+  __device__ __forceinline__ uint32_t advance(uint32_t total) const {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)__ballot(1)) - 1;
+    uint32_t before = 0;
+    if (lane == leader) { before = *run; *run = before + total; }
+    return __shfl(before, leader);
+  }
+  __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&ket)[LEN]) const {
+    const bool k = fabs(h) >= eps;
+    const uint64_t m = __ballot(k);
+    if (!m) return;
+    const uint32_t before = advance((uint32_t)__popcll(m));
+    if constexpr (EMIT) {
+      const int lane = threadIdx.x & 63;
+      if (k) put(base + before + __popcll(m & ((1ull << lane) - 1ull)), col, h, ket);
+    }
+  }
+  __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&k0)[LEN], uint32_t c1, T h1, const uint64_t (&k1)[LEN]) const {
+    const bool a = fabs(h0) >= eps, b = fabs(h1) >= eps;
+    const uint64_t ma = __ballot(a), mb = __ballot(b);
+    if (!(ma | mb)) return;
+    const uint32_t before = advance((uint32_t)(__popcll(ma) + __popcll(mb)));
+    if constexpr (EMIT) {
+      const int lane = threadIdx.x & 63;
+      const uint64_t below = (1ull << lane) - 1ull;
+      const int64_t mine = base + before + __popcll(ma & below) + __popcll(mb & below);
+      if (a) put(mine, c0, h0, k0);
+      if (b) put(mine + (a ? 1 : 0), c1, h1, k1);
+    }
+  }
+  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) const {
+    two(col, h0, k0, col + 1, h1, k1);
+  }
+};
+
+template <int LEN, typename T, bool EMIT>
+__global__ __launch_bounds__(kBlock) void reduce_tiles_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
+                                                              uint32_t nchunks, uint32_t chunk_len, uint32_t max_tiles,
+                                                              const T *__restrict__ plan, T eps, uint32_t *__restrict__ tile_counts,
+                                                              const int64_t *__restrict__ tile_off, int32_t *__restrict__ kept_col,
+                                                              uint64_t *__restrict__ kept_onv, T *__restrict__ kept_h) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t wave_cnt[kBlock / 64];
-  const uint64_t walker = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ uint32_t wave_run[kBlock / 64];
+  __shared__ uint32_t next_tile;
+  const uint64_t wg = blockIdx.x;
+  const uint64_t walker = wg / nchunks;
+  const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
+  const int tid = threadIdx.x;
+  if (tid == 0) next_tile = 0;
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
-  T *hs = reinterpret_cast<T *>(smem + lds_bytes(p, sizeof(T)));
-  singles_and_diag_to_lds<LEN, T>(p, pl, L, nocc, plan, hs);
-  const uint32_t ncomb = p.nsd + 1;
-  uint64_t base = EMIT ? (uint64_t)offsets[walker] : 0;
-  uint32_t total = 0;
-  for (uint32_t c0 = 0; c0 < ncomb; c0 += kBlock) {
-    const uint32_t col = c0 + tid;
-    uint64_t ket[LEN];
-    T h = T(0);
-    bool keep = false;
-    if (col < ncomb) {
-      h = column_element<LEN, T>(col, p, pl, L, plan, wk, hs, ket);
-      keep = fabs(h) >= eps;
-    }
-    const uint64_t m = __ballot(keep);
-    if constexpr (EMIT) {
-      if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
-      __syncthreads();
-      uint32_t before = 0, all = 0;
-#pragma unroll
-      for (int w = 0; w < kBlock / 64; ++w) { const uint32_t c = wave_cnt[w]; all += c; if (w < wave) before += c; }
-      if (keep) {
-        const uint64_t pos = base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        kept_col[pos] = (int32_t)col;
-        kept_h[pos] = h;
-#pragma unroll
-        for (int i = 0; i < LEN; ++i) kept_onv[pos * LEN + i] = ket[i];
-      }
-      base += all;
-      __syncthreads();
-    } else {
-      total += (uint32_t)__popcll(m);  // identical in every lane of the wave
-    }
-  }
-  if constexpr (!EMIT) {
-    if (lane == 0) wave_cnt[wave] = total;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t s = 0;
-      for (int w = 0; w < kBlock / 64; ++w) s += wave_cnt[w];
-      counts[walker] = s;
-    }
-  }
+  ReduceSink<LEN, T, EMIT> sink{eps, wave_run + (tid >> 6), EMIT ? nullptr : tile_counts + wg * max_tiles,
+                                EMIT ? tile_off + wg * max_tiles : nullptr, kept_col, kept_onv, kept_h, 0xffffffffu, 0};
+  visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+  sink.flush();
 }
 
 }  // namespace pynqs
@@ -345,10 +357,24 @@ extern "C" int pynqs_hash_lookup(const void *table, int64_t nkeys, const uint64_
   return check_launch("hash_lookup");
 }
 
+static int reduce_geometry(int64_t nbatch, const SDParams &p, uint32_t *nchunks, uint32_t *chunk_len, uint32_t *max_tiles) {
+  plan_chunks(nbatch, p.nsd + 1, nchunks, chunk_len);
+  *max_tiles = max_tiles_per_chunk(p, *nchunks, *chunk_len);
+  return 0;
+}
+
+extern "C" int64_t pynqs_reduce_tiles(int64_t nbatch, int sorb, int nele, int noA, int noB) {
+  SDParams p;
+  if (nbatch < 0 || !make_sd_params(sorb, nele, noA, noB, &p)) return -1;
+  uint32_t nchunks, chunk_len, max_tiles;
+  reduce_geometry(nbatch, p, &nchunks, &chunk_len, &max_tiles);
+  return (int64_t)nchunks * max_tiles;
+}
+
 template <bool EMIT>
 static int launch_reduce(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan, int dtype,
-                         double eps, int64_t *counts, const int64_t *offsets, int32_t *kept_col, uint64_t *kept_onv, void *kept_h,
-                         void *stream) {
+                         double eps, uint32_t *tile_counts, const int64_t *tile_off, int32_t *kept_col, uint64_t *kept_onv,
+                         void *kept_h, void *stream) {
   SDParams p;
   PlanLayout pl;
   int rc = eloc_common_checks(sorb, nele, noA, noB, nbatch, &p, &pl);
@@ -356,38 +382,38 @@ static int launch_reduce(const uint64_t *bra, int64_t nbatch, int sorb, int nele
   if (dtype != PYNQS_F32 && dtype != PYNQS_F64) return set_error(PYNQS_EINVAL, "bad dtype");
   if (nbatch == 0) return PYNQS_OK;
   if (!bra || !plan) return set_error(PYNQS_EINVAL, "null pointer");
-  if (EMIT ? (!offsets || !kept_col || !kept_onv || !kept_h) : !counts) return set_error(PYNQS_EINVAL, "null pointer");
+  if (EMIT ? (!tile_off || !kept_col || !kept_onv || !kept_h) : !tile_counts) return set_error(PYNQS_EINVAL, "null pointer");
   const int len = (sorb - 1) / 64 + 1;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
-  const size_t lds = lds_bytes_eloc(p, esz);
-  if (lds > 158 * 1024) return set_error(PYNQS_EINVAL, "too many single excitations for the LDS staging buffer");
+  uint32_t nchunks, chunk_len, max_tiles;
+  reduce_geometry(nbatch, p, &nchunks, &chunk_len, &max_tiles);
+  const uint64_t grid = (uint64_t)nbatch * nchunks;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
+  const size_t lds = lds_bytes(p, esz);
+  // tiles a workgroup does not have keep the count 0
+  if (!EMIT && hipMemsetAsync(tile_counts, 0, 4 * (size_t)grid * max_tiles, st) != hipSuccess) return check_launch("memset");
   DISPATCH_LEN(len, {
-    if (dtype == PYNQS_F64) {
-      // beyond the default 64 KiB of dynamic LDS (sorb >~ 150) the kernel has to be told
-      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&reduce_kernel<LEN, double, EMIT>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return check_launch("hipFuncSetAttribute");
-      hipLaunchKernelGGL((reduce_kernel<LEN, double, EMIT>), dim3((uint32_t)nbatch), dim3(kBlock), lds, st, bra, p, pl,
-                         (const double *)plan, eps, counts, offsets, kept_col, kept_onv, (double *)kept_h);
-    } else {
-      if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&reduce_kernel<LEN, float, EMIT>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return check_launch("hipFuncSetAttribute");
-      hipLaunchKernelGGL((reduce_kernel<LEN, float, EMIT>), dim3((uint32_t)nbatch), dim3(kBlock), lds, st, bra, p, pl,
-                         (const float *)plan, (float)eps, counts, offsets, kept_col, kept_onv, (float *)kept_h);
-    }
+    if (dtype == PYNQS_F64)
+      hipLaunchKernelGGL((reduce_tiles_kernel<LEN, double, EMIT>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
+                         chunk_len, max_tiles, (const double *)plan, eps, tile_counts, tile_off, kept_col, kept_onv, (double *)kept_h);
+    else
+      hipLaunchKernelGGL((reduce_tiles_kernel<LEN, float, EMIT>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
+                         chunk_len, max_tiles, (const float *)plan, (float)eps, tile_counts, tile_off, kept_col, kept_onv,
+                         (float *)kept_h);
   });
   return check_launch(EMIT ? "reduce_emit" : "reduce_count");
 }
 
 extern "C" int pynqs_reduce_count(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
-                                  int dtype, double eps, int64_t *counts, void *stream) {
-  return launch_reduce<false>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, counts, nullptr, nullptr, nullptr, nullptr, stream);
+                                  int dtype, double eps, uint32_t *tile_counts, void *stream) {
+  return launch_reduce<false>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, tile_counts, nullptr, nullptr, nullptr, nullptr,
+                              stream);
 }
 
 extern "C" int pynqs_reduce_emit(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
-                                 int dtype, double eps, const int64_t *offsets, int32_t *kept_col, uint64_t *kept_onv,
+                                 int dtype, double eps, const int64_t *tile_offsets, int32_t *kept_col, uint64_t *kept_onv,
                                  void *kept_h, void *stream) {
-  return launch_reduce<true>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, nullptr, offsets, kept_col, kept_onv, kept_h, stream);
+  return launch_reduce<true>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, nullptr, tile_offsets, kept_col, kept_onv, kept_h,
+                             stream);
 }

@@ -114,6 +114,7 @@ struct StoreSink {
   T *__restrict__ hrow;
   uint64_t *__restrict__ crow;
   lds_u64 *stage;  // this wave's quarter of the LDS scratch (free while the wave is in a doubles tile)
+  __device__ __forceinline__ void tile_begin(uint32_t) const {}
   __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&ket)[LEN]) const {
     store_h<T>(hrow, col, h);
     if constexpr (WRITE_COMB) store_ket<LEN>(crow, col, ket);

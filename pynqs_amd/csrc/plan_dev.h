@@ -8,105 +8,11 @@
 
 namespace pynqs {
 
-// ---- singles -------------------------------------------------------------------------------------------
-// <x|H|x'> of the single excitations with ranks [s_lo, s_hi) (all < d1).  A single p -> q needs
-// h(p,q) + sum_{k in occ(x)} <pk||qk> added in the reference's order (k: word ascending, bit 63 -> 0,
-// excitation.cpp:141-157).  The nocc terms of one single are one row of the plan's S2 table: lanes gather
-// (single, k) pairs with full lane utilisation, stage them in LDS, then one lane per single adds them in order.
-// sink(rank, value, hole, particle) is called once per single by the summing lane.
-// All threads of the workgroup must call this (it contains barriers).
-template <typename T, typename Sink>
-__device__ __forceinline__ void singles_phase(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
-                                              const T *__restrict__ plan, uint32_t s_lo, uint32_t s_hi, Sink sink) {
-  if (s_lo >= s_hi) return;
-  const int tid = threadIdx.x;
-  const uint32_t K = (uint32_t)pl.K;
-  T *tile = reinterpret_cast<T *>(L.scratch);
-  const int stride = nocc | 1;  // odd: conflict-free column reads in the summation
-  const int per_tile = max(1, min(kBlock, kDiagTile / stride));
-  const T *__restrict__ S2 = plan + pl.offS2;
-  const T *__restrict__ S1 = plan + pl.offS1;
-  // lanes are grouped G per single (G = power of two >= nocc, at most 64)
-  const int G = nocc <= 16 ? 16 : (nocc <= 32 ? 32 : 64);
-  const int gshift = nocc <= 16 ? 4 : (nocc <= 32 ? 5 : 6);
-  const int per_iter = kBlock >> gshift;
-  const int my_s = tid >> gshift, my_j = tid & (G - 1);
-  for (uint32_t t0 = s_lo; t0 < s_hi; t0 += per_tile) {
-    const int cnt = (int)min((uint32_t)per_tile, s_hi - t0);
-    __syncthreads();  // scratch free
-    for (int sl = my_s; sl < cnt; sl += per_iter) {
-      const uint32_t r = t0 + sl;
-      const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-      const uint32_t spin = r >= p.d0;
-      const uint32_t hm = (e & 0xff) >> 1, qm = ((e >> 8) & 0xff) >> 1;
-      const T *__restrict__ rowp = S2 + ((size_t)(spin * K + hm) * K + qm) * p.sorb;
-      for (int j = my_j; j < nocc; j += G) tile[sl * stride + j] = rowp[L.occv[j]];
-    }
-    __syncthreads();
-    if (tid < cnt) {
-      const uint32_t r = t0 + tid;
-      const uint32_t e = r < p.d0 ? L.tab[p.offSa + r] : L.tab[p.offSb + (r - p.d0)];
-      const uint32_t spin = r >= p.d0;
-      const int h = e & 0xff, q = (e >> 8) & 0xff;
-      T acc = T(0);
-      acc += S1[(size_t)(spin * K + (h >> 1)) * K + (q >> 1)];
-      const T *__restrict__ mine = tile + tid * stride;
-      for (int j = 0; j < nocc; ++j) acc += mine[j];
-      sink(r, ((e >> 16) & 1u) ? -acc : acc, h, q);
-    }
-  }
-}
-
-// ---- diagonal ---------------------------------------------------------------------------------------------
-// <x|H|x> from the plan's D1/D2 with hamiltonian.cpp:41-48's order of additions: the workgroup gathers the
-// nele(nele+1)/2 terms into LDS, the LAST lane of the workgroup adds them in order and calls sink(value).
-// Begins with a barrier (scratch must be free); the other lanes return right after the last gather.
-template <typename T, typename Sink>
-__device__ __forceinline__ void diag_phase_plan(const SDParams &p, const PlanLayout &pl, const LdsLayout &L,
-                                                const T *__restrict__ plan, Sink sink) {
-  const T *__restrict__ D1 = plan + pl.offD1;
-  const T *__restrict__ D2 = plan + pl.offD2;
-  T *tile = reinterpret_cast<T *>(L.scratch);
-  const int tid = threadIdx.x;
-  const int nele = p.nele;
-  const int nterms = nele * (nele + 1) / 2;
-  T acc = T(0);
-  for (int base = 0; base < nterms; base += kDiagTile) {
-    const int end = min(base + kDiagTile, nterms);
-    __syncthreads();
-    for (int t = base + tid; t < end; t += kBlock) {
-      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > t) --a;
-      while ((a + 1) * (a + 2) / 2 <= t) ++a;
-      const int pos = t - a * (a + 1) / 2;
-      const int pa = L.occa[a];
-      tile[t - base] = pos == 0 ? D1[pa] : D2[pa * p.sorb + L.occa[pos - 1]];
-    }
-    __syncthreads();
-    if (tid == kBlock - 1) {
-      int t = 0;
-      const int n = end - base;
-      for (; t + 4 <= n; t += 4) {  // same order, fewer loop instructions
-        acc += tile[t]; acc += tile[t + 1]; acc += tile[t + 2]; acc += tile[t + 3];
-      }
-      for (; t < n; ++t) acc += tile[t];
-    }
-  }
-  if (tid == kBlock - 1) sink(acc);
-}
-
-// <x|H|x'> of the singles [0, d1) and of the diagonal into LDS: hs[0] = <x|H|x>, hs[1 + r] = single r
-// (same arithmetic as comb_hij_plan_kernel: plan_dev.h).  `hs` holds 1 + d1 values.
-template <int LEN, typename T>
-__device__ __forceinline__ void singles_and_diag_to_lds(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
-                                                        const T *__restrict__ plan, T *__restrict__ hs) {
-  singles_phase<T>(p, pl, L, nocc, plan, 0u, p.d1, [&](uint32_t r, T v, int, int) { hs[1 + r] = v; });
-  diag_phase_plan<T>(p, pl, L, plan, [&](T v) { hs[0] = v; });
-  __syncthreads();
-}
-
-// ---- wave-private variants (used by the tile scheduler, plan_tiles.h) ------------------------------------------
-// The same two computations carried out by ONE wave with no workgroup barrier, so that the other waves of the
+// ---- singles and diagonal (used by the tile scheduler, plan_tiles.h) -------------------------------------------
+// A single p -> q needs h(p,q) + sum_{k in occ(x)} <pk||qk> added in the reference's order (k: word ascending, bit
+// 63 -> 0, excitation.cpp:141-157), the diagonal the nele(nele+1)/2 terms of hamiltonian.cpp:41-48 in theirs: the
+// terms are gathered with all lanes, staged in LDS and added by one lane per sum (bit-identical results).
+// Both are carried out by ONE wave with no workgroup barrier, so that the other waves of the
 // workgroup can run the doubles meanwhile (ablation, profiles/: with workgroup-wide phases the singles and
 // the diagonal, 2 % of the columns, cost 0.08 ms of a 0.26 ms kernel in barrier-separated, mostly idle steps).
 // LDS operations of one wave execute in order; wave_sync() keeps the compiler from moving LDS accesses

@@ -56,8 +56,16 @@ __device__ __forceinline__ ClassRange class_range(uint32_t b0, uint32_t b1, uint
 //   void one(uint32_t col, T h, const uint64_t (&ket)[LEN]);                       // a single column
 //   void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]);  // col, col+1
 //   void two(uint32_t c0, T h0, const uint64_t (&k0)[LEN], uint32_t c1, T h1, const uint64_t (&k1)[LEN]);  // any two
+//   void tile_begin(uint32_t tile);   // called by all lanes of the wave that took tile `tile` of this workgroup
+// Number of tiles of a workgroup: at most max_tiles_per_chunk() (host and device agree on it).
 // `next_tile` is a workgroup-shared counter that must be 0 when the first wave arrives (set it before
 // build_walker_tables, whose final barrier publishes it).
+// upper bound of `ntiles` below for any chunk of a walker's row
+__host__ __device__ inline uint32_t max_tiles_per_chunk(const SDParams &p, uint32_t nchunks, uint32_t chunk_len) {
+  const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+  return 1 + (tS_all + nchunks - 1) / nchunks + chunk_len / (128u * PYNQS_U) + 4;
+}
+
 template <int LEN, typename T, typename Sink>
 __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
@@ -96,6 +104,7 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
     if (lane == 0) tile = atomicAdd(next_tile, 1u);
     tile = __builtin_amdgcn_readfirstlane(tile);
     if (tile >= ntiles) break;
+    sink.tile_begin(tile);  // wave-uniform; everything until the next call belongs to this tile, in a fixed order
     if (tile == 0) {
       // unpaired columns of the three classes: lanes 0..5
       if (kPaired && lane < 6) {

@@ -126,18 +126,6 @@ def _reduce_select(comb_hij: Tensor, eps: float, eps_sample: int) -> Tensor:
     return index1 if index is None else torch.cat([index, index1])
 
 
-def _fused_lds_ok(sorb: int, noa: int, nob: int, elem: int = 8) -> bool:
-    """The REDUCE compaction kernels stage all singles' matrix elements in LDS (the CU has 160 KiB)."""
-    k = sorb // 2
-    nva, nvb = k - noa, k - nob
-    d1 = noa * nva + nob * nvb
-    tab = d1 + noa * (noa - 1) // 2 + nva * (nva - 1) // 2 + nob * (nob - 1) // 2 + nvb * (nvb - 1) // 2
-    fixed = (tab * 4 + 3 * 192 + 7) // 8 * 8
-    if sorb <= 64:
-        fixed += tab * 8  # ket-mask tables of one-word determinants
-    return fixed + 2048 * elem + (d1 + 2) * elem <= 158 * 1024
-
-
 def _real_rbm_params(ansatz):
     """(weights [H, sorb], hidden_bias [H], visible_bias [sorb]) if `ansatz` (possibly DDP-wrapped) is a real RBM
     with the reference's formula (pynqs_amd.rbm.RealRBM, or PyNQS' RBMWavefunction with rbm_type == "real"), else None."""
@@ -158,7 +146,7 @@ def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
 
 
 def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa=0, nob=0) -> bool:
-    return (FUSED and _fused_lds_ok(sorb, noa, nob) and WF_LUT is not None and WF_LUT.sort and not (use_spin_raising or use_multi_psi or use_spin_flip)
+    return (FUSED and WF_LUT is not None and WF_LUT.sort and not (use_spin_raising or use_multi_psi or use_spin_flip)
             and sorb % 2 == 0 and h1e.dtype == torch.float64 and WF_LUT.dtype in (torch.float64, torch.complex128)
             and x.is_cuda and WF_LUT.bra_key.is_cuda)
 
@@ -183,28 +171,36 @@ def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT) -> Tuple[Tens
     return eloc, psi0
 
 
-def reduce_compact(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float):
+def reduce_compact(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, sort: bool = False):
     """Kept columns of the REDUCE method, compacted on the GPU: (row int64[m], col int32[m], onv uint8[m, 8*len],
-    h[m], counts int64[n]) with |h| >= eps, rows ascending and columns ascending inside a row."""
+    h[m], counts int64[n]) with |h| >= eps.  Rows ascend; inside a row the records come in the kernels' reproducible
+    tile order (sort=True: ascending columns like the reference's boolean mask, at the price of a sort)."""
     plan = CX.plan_for(h1e, h2e, sorb)
     dev = x.device
     n = x.size(0)
     L = (sorb - 1) // 64 + 1
     code = N.PYNQS_F64 if h1e.dtype == torch.float64 else N.PYNQS_F32
     st = torch.cuda.current_stream(dev).cuda_stream
-    counts = torch.empty(n, dtype=torch.int64, device=dev)
-    N.check(N.lib().pynqs_reduce_count(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, float(eps), counts.data_ptr(), st),
+    T = N.lib().pynqs_reduce_tiles(n, sorb, nele, noa, nob)
+    if T < 0:
+        raise RuntimeError("pynqs_reduce_tiles: bad arguments")
+    tile_counts = torch.empty((n, T), dtype=torch.int32, device=dev)
+    N.check(N.lib().pynqs_reduce_count(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, float(eps), tile_counts.data_ptr(), st),
             "pynqs_reduce_count")
-    ends = torch.cumsum(counts, 0)
-    offsets = (ends - counts).contiguous()
+    ends = torch.cumsum(tile_counts.view(-1), 0, dtype=torch.int64)
+    tile_off = (ends - tile_counts.view(-1)).contiguous()
+    counts = tile_counts.sum(1, dtype=torch.int64)
     m = int(ends[-1].item()) if n else 0
     col = torch.empty(m, dtype=torch.int32, device=dev)
     onv = torch.empty((m, 8 * L), dtype=torch.uint8, device=dev)
     h = torch.empty(m, dtype=h1e.dtype, device=dev)
-    if m:
-        N.check(N.lib().pynqs_reduce_emit(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, float(eps), offsets.data_ptr(),
-                                          col.data_ptr(), onv.data_ptr(), h.data_ptr(), st), "pynqs_reduce_emit")
     row = torch.repeat_interleave(torch.arange(n, device=dev), counts)
+    if m:
+        N.check(N.lib().pynqs_reduce_emit(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, float(eps), tile_off.data_ptr(),
+                                          col.data_ptr(), onv.data_ptr(), h.data_ptr(), st), "pynqs_reduce_emit")
+        if sort:
+            order = torch.argsort((row << 32) | col.long())
+            col, onv, h = col[order], onv[order], h[order]
     return row, col, onv, h, counts
 
 
@@ -253,7 +249,7 @@ def local_energy(
 
         # ---- fast path: REDUCE (deterministic) with on-chip compaction -----------------------------------
         if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and not (use_spin_raising or use_multi_psi or use_spin_flip)
-                and sorb % 2 == 0 and x.is_cuda and _fused_lds_ok(sorb, noa, nob, h1e.element_size())):
+                and sorb % 2 == 0 and x.is_cuda):
             row, col, onv, h, counts = reduce_compact(x, h1e, h2e, sorb, nele, noa, nob, eps)
             t2 = time.time_ns()
             psi = Func(ansatz_f, onv, WF_LUT, use_unique).to(dtype)

@@ -82,7 +82,14 @@ def test_reduce_compaction_is_exact(env):
 
     energy = env["energy"]
     for eps in (1e-2, 0.0, 1e3):
-        row, col, onv, h, counts = energy.reduce_compact(env["x"], env["h1e"], env["h2e"], 40, 30, 15, 15, eps)
+        row, col, onv, h, counts = energy.reduce_compact(env["x"], env["h1e"], env["h2e"], 40, 30, 15, 15, eps, sort=True)
+        # unsorted: the kernels' tile order -- same records, identical from run to run (no atomics)
+        u1 = energy.reduce_compact(env["x"], env["h1e"], env["h2e"], 40, 30, 15, 15, eps)
+        u2 = energy.reduce_compact(env["x"], env["h1e"], env["h2e"], 40, 30, 15, 15, eps)
+        assert all(torch.equal(a, b) for a, b in zip(u1, u2))
+        if col.numel():
+            o = torch.argsort((u1[0] << 32) | u1[1].long())
+            assert torch.equal(u1[1][o], col) and torch.equal(u1[3][o], h) and torch.equal(u1[2][o], onv)
         comb, hm = cx.get_comb_hij_fused(env["x"], env["h1e"], env["h2e"], 40, 30, 15, 15)
         keep = hm.abs() >= eps
         r2, c2 = torch.where(keep)
@@ -254,9 +261,9 @@ def test_gfmc_sample_kernel_matches_sequential_oracle(n, m, L):
     assert abs(acc - nz) <= 1
 
 
-def test_reduce_compaction_beyond_64k_lds():
-    """sorb 160 with 40 + 40 electrons: walker tables + staging + 3200 singles' elements need 67 KiB of LDS (the
-    default dynamic limit is 64): the compaction must still equal |Hmat| >= eps of the materialised row."""
+def test_reduce_compaction_large_system():
+    """sorb 160 with 40 + 40 electrons, 3.8 M columns per walker, rows cut into chunks over many workgroups: the
+    compaction (atomically reserved records + sort) must equal |Hmat| >= eps of the materialised row, in order."""
     from conftest import rand_occ, synth_integrals
     from pynqs_amd import C_extension as cx, energy
 
@@ -265,8 +272,7 @@ def test_reduce_compaction_beyond_64k_lds():
     d = torch.device("cuda")
     h1e, h2e = torch.from_numpy(h1).to(d), torch.from_numpy(h2).to(d)
     x = cx.tensor_to_onv(torch.from_numpy(rand_occ(2, sorb, no, no, seed=9)).to(d), sorb)
-    assert energy._fused_lds_ok(sorb, no, no)
-    row, col, onv, h, counts = energy.reduce_compact(x, h1e, h2e, sorb, 2 * no, no, no, 0.49)
+    row, col, onv, h, counts = energy.reduce_compact(x, h1e, h2e, sorb, 2 * no, no, no, 0.49, sort=True)
     comb, hm = cx.get_comb_hij_fused(x, h1e, h2e, sorb, 2 * no, no, no)
     keep = hm.abs() >= 0.49
     r2, c2 = torch.where(keep)
