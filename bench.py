@@ -235,10 +235,10 @@ class SampleSpaceFused(Workload):
         e1.record(st)
         self.N.check(rc, "pynqs_eloc_sample_space")
         # <E_loc>, variance: one packed all-reduce over the ranks (RCCL), no barrier
-        from pynqs_amd.stats import dist_stats_onepass
+        from pynqs_amd.stats import dist_stats_moments
         from pynqs_amd.distributed import get_world_size
 
-        self.stats = dist_stats_onepass(self.eloc, self.prob, None, get_world_size())
+        self.stats = dist_stats_moments(self.eloc, self.prob, None, get_world_size())
         return e0, e1
 
     def parity_gate(self):
@@ -312,10 +312,10 @@ class RbmFused(Workload):
         e0.record(st)
         self.eloc, self.psi = self.cx.eloc_rbm(self.x, self.h1, self.h2, tab, self.sorb, self.nele, self.noA, self.noB)
         e1.record(st)
-        from pynqs_amd.stats import dist_stats_onepass
+        from pynqs_amd.stats import dist_stats_moments
         from pynqs_amd.distributed import get_world_size
 
-        self.stats = dist_stats_onepass(self.eloc, self.prob, None, get_world_size())
+        self.stats = dist_stats_moments(self.eloc, self.prob, None, get_world_size())
         return e0, e1
 
     def _oracle(self, m, nthreads=0):
@@ -486,6 +486,34 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # pragma: no cover  (keeps the primary line intact)
                 extra[name] = {"error": repr(e)}
+        # (ii') of SURVEY.md 8(d): enumeration + |<x|H|x'>| >= eps compaction (count and emit passes, nothing materialised),
+        # what an external PyTorch ansatz is fed with; eps keeps about 1 % of the columns
+        try:
+            from pynqs_amd import energy as E2
+
+            for tag, sorb2, no2, nw2, eps2 in (("fe2s2_reduce_compact_eps1e-2", 40, 15, args.walkers, 1e-2), ("syn120_reduce_compact", 120, 30, 256, 0.495),
+                                               ("syn184_reduce_compact", 184, 46, 64, 0.495)):
+                if sorb2 == 40:
+                    d0 = load_fe2s2()
+                    h1c, h2c = torch.from_numpy(d0["h1e"]).to(dev), torch.from_numpy(d0["h2e"]).to(dev)
+                    xc = torch.from_numpy(np.ascontiguousarray(d0["ci_space"][np.arange(nw2) % d0["ci_space"].shape[0]])).to(dev)
+                else:
+                    h1c, h2c = (t.to(dev) for t in synth_integrals(sorb2))
+                    xc = synth_walkers(nw2, sorb2, no2, no2, 4321).to(dev)
+                fn = lambda: E2.reduce_compact(xc, h1c, h2c, sorb2, 2 * no2, no2, no2, eps2)
+                fn(); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter(); reps = 5
+                for _ in range(reps):
+                    r_ = fn()
+                torch.cuda.synchronize(dev)
+                el4 = (time.perf_counter() - t0) / reps
+                ncomb2 = algorithmic_bytes_dropin(sorb2, 2 * no2, no2, no2)[1]
+                extra[tag] = {"value": nw2 / el4, "unit": "walkers/s", "walkers": nw2, "ncomb": int(ncomb2), "ms_per_step": el4 * 1e3,
+                              "columns_per_s": nw2 * ncomb2 / el4, "kept_per_walker": r_[1].numel() / nw2, "eps": eps2}
+                del h1c, h2c, xc, r_
+                torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            extra["reduce_compact"] = {"error": repr(e)}
         # the generic amplitude path: psi(x') by a PyTorch-ROCm module (real RBM, alpha = 2) through
         # pynqs_amd.energy.local_energy -- SIMPLE (every column) and REDUCE (eps = 1e-2, the Fe2S2 example's setting)
         try:
@@ -504,7 +532,7 @@ def main():
             old_fused_rbm, E.FUSED_RBM = E.FUSED_RBM, False  # this line measures the generic module path
             for tag, nw, kw in (("fe2s2_eloc_simple_rbm_torch", 512, {}), ("fe2s2_eloc_reduce_eps1e-2_rbm_torch", 8192, {"reduce_psi": True, "eps": 1e-2})):
                 xg = torch.from_numpy(np.ascontiguousarray(d["ci_space"][:nw])).to(dev)
-                fn = lambda: E.total_energy(xg, nw, 2_000_000, h1g, h2g, rbm, sorb, nele, noA, noB, use_unique=False, **kw)
+                fn = lambda: E.total_energy(xg, nw, 2_000_000, h1g, h2g, rbm, sorb, nele, noA, noB, use_unique=True, **kw)
                 fn(); torch.cuda.synchronize(dev)
                 t0 = time.perf_counter(); reps = 3
                 for _ in range(reps):

@@ -166,6 +166,13 @@ int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int 
 int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const double *rand_num, const uint64_t *comb,
                       int sorb, int64_t *index, double *beta, uint64_t *x_new, void *stream);
 
+/* ---- statistics: utils/stats/dist_stats.py:18-79 needs sum p O, sum p |O|^2 (and sum p) before its all-reduce -----
+ *   pynqs_moments_workspace : [host] bytes of the workspace (device memory, ZERO it once before the first call)
+ *   pynqs_weighted_moments  : workspace[0..3] (doubles) = sum_i p_i Re x_i, sum_i p_i Im x_i, sum_i p_i |x_i|^2,
+ *                             sum_i p_i; x is double[n] or interleaved complex double[n][2]; fixed order of additions. */
+int64_t pynqs_moments_workspace(void);
+int pynqs_weighted_moments(const double *x, int is_complex, const double *prob, int64_t n, void *workspace, void *stream);
+
 /* REDUCE method front end: vmc/energy/eloc.py:205-324 with eps_sample == 0 keeps the columns with
  * |<x|H|x'>| >= eps (eloc.py:297-298; column 0 is treated like any other).  Two passes, nothing materialised, no
  * atomics.  A walker's row is visited in tiles; T = pynqs_reduce_tiles(...) tiles per walker:

@@ -119,3 +119,71 @@ extern "C" int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, 
                                        rand_num, comb, index, beta, x_new));
   return check_launch("gfmc_sample");
 }
+
+// -------------------------------------------------------------------------------------------------
+// Weighted moments of the local energies for the statistics all-reduce (utils/stats/dist_stats.py:18-79):
+//   out[0..3] = sum_i p_i Re x_i,  sum_i p_i Im x_i,  sum_i p_i |x_i|^2,  sum_i p_i
+// in one pass and a fixed order of additions (per-lane strided sums, wave butterfly, waves, then the blocks' partial
+// sums by the last block to finish): the ~10 small torch kernels this replaces cost 0.2 ms per step, a third of the
+// fused sample-space step.  out has room for 4 * (kMomentBlocks + 1) doubles (the partials follow the result) and
+// one counter word.
+namespace pynqs {
+
+constexpr int kMomentBlocks = 128;
+
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void moments_kernel(const double *__restrict__ x, const double *__restrict__ prob, int64_t n,
+                                                         double *__restrict__ out, unsigned int *__restrict__ done) {
+  __shared__ double red[4][kBlock / 64];
+  __shared__ bool last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + tid; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double p = prob[i];
+    const double re = CPLX ? x[2 * i] : x[i], im = CPLX ? x[2 * i + 1] : 0.0;
+    s[0] += p * re; s[1] += p * im; s[2] += p * (re * re + im * im); s[3] += p;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s[k] += __shfl_xor(s[k], d);
+    if (lane == 0) red[k][wave] = s[k];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) t += red[tid][w];
+    out[4 * (1 + blockIdx.x) + tid] = t;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) last = atomicAdd(done, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    if (tid < 4) {
+      double t = 0.0;
+      for (unsigned b = 0; b < gridDim.x; ++b) t += out[4 * (1 + b) + tid];  // block order: reproducible
+      out[tid] = t;
+    }
+    if (tid == 0) *done = 0;  // ready for the next call
+  }
+}
+
+}  // namespace pynqs
+
+extern "C" int64_t pynqs_moments_workspace(void) { return 8 * 4 * (pynqs::kMomentBlocks + 1) + 8; }
+
+extern "C" int pynqs_weighted_moments(const double *x, int is_complex, const double *prob, int64_t n, void *workspace, void *stream) {
+  if (n < 0) return set_error(PYNQS_EINVAL, "bad n");
+  if (!workspace || (n > 0 && (!x || !prob))) return set_error(PYNQS_EINVAL, "null pointer");
+  double *out = (double *)workspace;
+  unsigned int *done = (unsigned int *)(out + 4 * (kMomentBlocks + 1));
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > kMomentBlocks) blocks = kMomentBlocks;
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (is_complex) hipLaunchKernelGGL((moments_kernel<true>), dim3((uint32_t)blocks), dim3(kBlock), 0, st, x, prob, n, out, done);
+  else hipLaunchKernelGGL((moments_kernel<false>), dim3((uint32_t)blocks), dim3(kBlock), 0, st, x, prob, n, out, done);
+  return check_launch("weighted_moments");
+}

@@ -42,6 +42,42 @@ def dist_stats(x: Tensor, prob: Tensor, counts: Optional[int] = None, world_size
     return mean, var, sd, se
 
 
+_WS: dict = {}  # device -> zero-initialised workspace of pynqs_weighted_moments
+
+
+def _moments(x: Tensor, prob: Tensor) -> Tensor:
+    """[sum p Re x, sum p Im x, sum p |x|^2, sum p] as one float64 tensor: one HIP kernel for float64 / complex128 on
+    the GPU (pynqs_weighted_moments), torch ops otherwise."""
+    if x.is_cuda and prob.is_cuda and prob.dtype == torch.float64 and x.dtype in (torch.float64, torch.complex128) and x.dim() == 1:
+        from . import _native as N
+
+        dev = x.device
+        ws = _WS.get(dev)
+        if ws is None:
+            ws = _WS[dev] = torch.zeros(N.lib().pynqs_moments_workspace() // 8, dtype=torch.float64, device=dev)
+        xc, pc = x.contiguous(), prob.contiguous()
+        N.check(N.lib().pynqs_weighted_moments(xc.data_ptr(), int(x.is_complex()), pc.data_ptr(), x.numel(), ws.data_ptr(),
+                                               torch.cuda.current_stream(dev).cuda_stream), "pynqs_weighted_moments")
+        return ws[:4].clone()
+    w = _wdot(x, prob)
+    z = torch.zeros((), dtype=prob.dtype, device=x.device)
+    return torch.stack([w.real if torch.is_complex(w) else w, w.imag if torch.is_complex(w) else z,
+                        torch.dot((x * x.conj()).real, prob), prob.sum()]).to(torch.float64)
+
+
+def dist_stats_moments(x: Tensor, prob: Tensor, counts: Optional[int] = None, world_size: int = 1):
+    """dist_stats_onepass on the fused moments kernel: 1 kernel + 1 all-reduce of 4 doubles + the closing arithmetic.
+    counts defaults to len(x) * world_size (equal shards), so no device-to-host copy is needed."""
+    m = _moments(x, prob)
+    m = all_reduce_packed([m], world_size)[0]
+    mean = torch.complex(m[0], m[1]) if torch.is_complex(x) else m[0]
+    var = (m[2] - (m[0] * m[0] + m[1] * m[1]) * (2.0 - m[3])).clamp_min(0)
+    if counts is None:
+        counts = x.size(0) * get_world_size()
+    sd = torch.sqrt(var)
+    return mean, var, sd, sd / counts**0.5
+
+
 def dist_stats_onepass(x: Tensor, prob: Tensor, counts: Optional[int] = None, world_size: int = 1):
     """Same quantities from ONE packed all-reduce of (sum p O, sum p |O|^2, sum p[, n]):
     var = E|O|^2 - |E O|^2 (valid when the global weights sum to world_size, i.e. normalised p).

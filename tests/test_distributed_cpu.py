@@ -31,6 +31,8 @@ def _worker(rank, world, port, q):
         x, p = eloc[b:e], prob[b:e] * world
         st = S.operator_statistics(x, p, int(d["stat_counts"]), "E")
         one = S.dist_stats_onepass(x, p, int(d["stat_counts"]), world)
+        mom = S.dist_stats_moments(x, p, int(d["stat_counts"]), world)
+        assert all(abs(a.item() - b.item()) <= 1e-12 * max(1.0, abs(b.item())) for a, b in zip(mom, one))
         packed = D.all_reduce_packed([x.sum(), torch.complex(x[:2], x[:2] * 2)], world)
         # gradient estimator under DDP: micro-batches, last one synchronises
         torch.manual_seed(0)

@@ -131,6 +131,23 @@ def test_total_energy_chunks_and_statistics(env):
     np.testing.assert_allclose(m.cpu().numpy(), d["stat_mean"], rtol=1e-13)
     np.testing.assert_allclose(v.cpu().numpy(), d["stat_var"], rtol=1e-8)
     assert "<E> = " in repr(st)
+    # the fused moments kernel (one launch instead of ~10): same numbers; complex and large inputs against torch
+    from pynqs_amd.stats import dist_stats_moments
+
+    m2, v2, sd2, se2 = dist_stats_moments(ref, prob, int(d["stat_counts"]), 1)
+    np.testing.assert_allclose(m2.cpu().numpy(), d["stat_mean"], rtol=1e-13)
+    np.testing.assert_allclose(v2.cpu().numpy(), d["stat_var"], rtol=1e-8)
+    np.testing.assert_allclose(se2.cpu().numpy(), d["stat_se"], rtol=1e-8)
+    g = torch.Generator(device=env["dev"]).manual_seed(5)
+    for n in (1, 255, 70_001):
+        z = torch.complex(torch.randn(n, generator=g, dtype=torch.float64, device=env["dev"]), torch.randn(n, generator=g, dtype=torch.float64, device=env["dev"]))
+        p = torch.rand(n, generator=g, dtype=torch.float64, device=env["dev"]); p /= p.sum()
+        a = dist_stats_moments(z, p, n, 1)
+        b = dist_stats_onepass(z, p, n, 1)
+        a2 = dist_stats_moments(z, p, n, 1)  # workspace reuse, bit-reproducible
+        for u, w, u2 in zip(a, b, a2):
+            np.testing.assert_allclose(u.cpu().numpy(), w.cpu().numpy(), rtol=1e-10, atol=1e-13)
+            assert torch.equal(u, u2)
 
 
 def test_spin_flip_and_multi_psi_paths_agree_with_plain_tensor_algebra(env):
