@@ -10,6 +10,7 @@
 //  * consecutive lanes take consecutive excitation ranks, so Hmat/comb stores are fully coalesced;
 //  * all global indexing is 64-bit (the reference overflows int32 at cuda/kernel.cu:243-263).
 #pragma once
+#include <stdlib.h>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -198,18 +199,39 @@ __host__ __device__ inline uint64_t hash_capacity(int64_t nkeys) {
 
 __host__ __device__ constexpr int hash_slot_words(int len) { return len == 1 ? 2 : 4; }
 
-__host__ __device__ inline uint64_t hash_mix(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-  return z ^ (z >> 31);
-}
-
+// One 64-bit multiplication per key word (multiply-xorshift) instead of the two of the splitmix finaliser: the
+// fused sample-space kernel hashes every x' (64.5 M per launch on Fe2S2) and is close to VALU-bound, a 64-bit
+// multiplication is ~6 vector instructions.  The xor-shift brings the well-mixed high half of the product down to
+// the bits the table index is taken from.
 template <int LEN>
 __device__ __forceinline__ uint64_t hash_of(const uint64_t (&q)[LEN]) {
-  uint64_t h = 0x9e3779b97f4a7c15ull;
+  uint64_t h = q[0] * 0x9e3779b97f4a7c15ull;
 #pragma unroll
-  for (int w = 0; w < LEN; ++w) h = hash_mix(h ^ q[w]);
-  return h;
+  for (int w = 1; w < LEN; ++w) h = (h ^ (h >> 32) ^ q[w]) * 0xbf58476d1ce4e5b9ull;
+  return h ^ (h >> 29);
+}
+
+// Bloom prefilter of the same keys (2 bits per key out of one hash), appended to the table: the fused sample-space
+// kernel copies it into LDS and asks it before every probe.  Most x' are not in the sample table (85 % for the
+// Fe2S2 CI space), and a probe drags a whole cache line through the vector L1 for 16 useful bytes -- the kernel
+// was bound by exactly that (TA busy 82 %).  About 4 filter bits per key, at most kFilterMaxBits (16 KiB of LDS):
+// a larger filter costs more in LDS occupancy than its lower false-positive rate returns.
+constexpr uint32_t kFilterMaxBits = 1u << 17;
+
+inline uint32_t hash_filter_bits(int64_t nkeys) {  // host side
+  if (nkeys <= 0) return 0;
+  // largest power of two <= 4 bits per key, at most kFilterMaxBits: measured on Fe2S2 (18496 keys, 8192 walkers):
+  // no filter 0.447 ms, 32 Kbit 0.362, 64 Kbit 0.336, 128 Kbit 0.352, 256 Kbit 0.544 (LDS occupancy)
+  static const uint64_t maxbits = getenv("PYNQS_FILTER_BITS") ? strtoull(getenv("PYNQS_FILTER_BITS"), nullptr, 10) : kFilterMaxBits;
+  if (maxbits == 0) return 0;
+  uint64_t b = 1024;
+  while (2 * b <= 4ull * (uint64_t)nkeys && 2 * b <= maxbits) b <<= 1;
+  return b >= (uint64_t)nkeys ? (uint32_t)b : 0u;  // below one bit per key it rejects too little
+}
+
+__host__ __device__ inline void filter_positions(uint64_t h, uint32_t fbits, uint32_t &b0, uint32_t &b1) {
+  b0 = (uint32_t)(h >> 20) & (fbits - 1u);
+  b1 = (uint32_t)(h >> 41) & (fbits - 1u);
 }
 
 // First probe only: the slot content (to let a caller issue several independent first probes back to back).
@@ -218,6 +240,17 @@ struct HashProbe {
   uint64_t w[hash_slot_words(LEN)];
   uint64_t s;
 };
+
+template <int LEN>
+__device__ __forceinline__ HashProbe<LEN> hash_probe_first_h(const uint64_t *__restrict__ table, uint64_t cap, uint64_t h) {
+  constexpr int W = hash_slot_words(LEN);
+  HashProbe<LEN> pr;
+  pr.s = h & (cap - 1);
+  const hash_u64x2 *slot = reinterpret_cast<const hash_u64x2 *>(table + pr.s * W);
+#pragma unroll
+  for (int i = 0; i < W / 2; ++i) { const hash_u64x2 v = slot[i]; pr.w[2 * i] = v[0]; pr.w[2 * i + 1] = v[1]; }
+  return pr;
+}
 
 template <int LEN>
 __device__ __forceinline__ HashProbe<LEN> hash_probe_first(const uint64_t *__restrict__ table, uint64_t cap,

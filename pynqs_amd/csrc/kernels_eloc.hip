@@ -26,8 +26,31 @@ struct LookupSink {
   const double *__restrict__ wf;
   double *__restrict__ psi0;  // this walker's psi(x) slot
   double re, im;
+  uint32_t filt;   // LDS address of the Bloom filter words (HASH only)
+  uint32_t fbits;  // its size in bits, 0 = no filter
+  // false: the key is certainly not in the table
+  __device__ __forceinline__ bool maybe(uint64_t h) const {
+    if (!fbits) return true;
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    uint32_t b0, b1;
+    filter_positions(h, fbits, b0, b1);
+    const uint32_t w0 = *reinterpret_cast<lds_cu32 *>(filt + 4u * (b0 >> 5)), w1 = *reinterpret_cast<lds_cu32 *>(filt + 4u * (b1 >> 5));
+    return ((w0 >> (b0 & 31u)) & (w1 >> (b1 & 31u)) & 1u) != 0u;
+  }
+  // the two look-ups of a sink call: filter, then both first probes in flight together
+  __device__ __forceinline__ void lookup2(uint32_t c0, double h0, const uint64_t (&k0)[LEN], uint32_t c1, double h1, const uint64_t (&k1)[LEN]) {
+    const uint64_t g0 = hash_of<LEN>(k0), g1 = hash_of<LEN>(k1);
+    const bool m0 = maybe(g0), m1 = maybe(g1);
+    HashProbe<LEN> p0, p1;
+    if (m0) p0 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, g0);
+    if (m1) p1 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, g1);
+    accumulate(c0, h0, m0 ? hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0) : -1);
+    accumulate(c1, h1, m1 ? hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1) : -1);
+  }
   __device__ __forceinline__ void add(uint32_t col, double h, const uint64_t (&ket)[LEN]) {
-    const int64_t pos = HASH ? hash_find<LEN>(keys, (uint64_t)nkeys, ket) : lut_find<LEN>(keys, nkeys, ket);
+    int64_t pos;
+    if constexpr (HASH) pos = maybe(hash_of<LEN>(ket)) ? hash_find<LEN>(keys, (uint64_t)nkeys, ket) : -1;
+    else pos = lut_find<LEN>(keys, nkeys, ket);
     accumulate(col, h, pos);
   }
   __device__ __forceinline__ void accumulate(uint32_t col, double h, int64_t pos) {
@@ -46,23 +69,15 @@ struct LookupSink {
   __device__ __forceinline__ void tile_begin(uint32_t) const {}
   __device__ __forceinline__ void one(uint32_t col, double h, const uint64_t (&ket)[LEN]) { add(col, h, ket); }
   __device__ __forceinline__ void two(uint32_t c0, double h0, const uint64_t (&k0)[LEN], uint32_t c1, double h1, const uint64_t (&k1)[LEN]) {
-    if constexpr (HASH) {
-      const HashProbe<LEN> p0 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k0);
-      const HashProbe<LEN> p1 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k1);
-      accumulate(c0, h0, hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0));
-      accumulate(c1, h1, hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1));
-    } else {
+    if constexpr (HASH) lookup2(c0, h0, k0, c1, h1, k1);
+    else {
       add(c0, h0, k0);
       add(c1, h1, k1);
     }
   }
   __device__ __forceinline__ void pair(uint32_t col, double h0, double h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) {
-    if constexpr (HASH) {  // both first probes in flight together
-      const HashProbe<LEN> p0 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k0);
-      const HashProbe<LEN> p1 = hash_probe_first<LEN>(keys, (uint64_t)nkeys, k1);
-      accumulate(col, h0, hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0));
-      accumulate(col + 1, h1, hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1));
-    } else {
+    if constexpr (HASH) lookup2(col, h0, k0, col + 1, h1, k1);
+    else {
       add(col, h0, k0);
       add(col + 1, h1, k1);
     }
@@ -75,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
                                                                    const double *__restrict__ plan,
                                                                    const uint64_t *__restrict__ keys, int64_t nkeys,
                                                                    const double *__restrict__ wf, double *__restrict__ acc,
-                                                                   double *__restrict__ psi0) {
+                                                                   double *__restrict__ psi0, uint32_t fbits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double red[2][kBlock / 64];
   __shared__ uint32_t next_tile;
@@ -87,8 +102,16 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
-  const int nocc = build_walker_tables<LEN>(wk, p, L);
-  LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0};
+  // the table's Bloom filter follows its slots in memory; its LDS copy follows the staging scratch
+  const uint32_t filt_off = (uint32_t)lds_bytes(p, sizeof(double));
+  if (HASH && fbits) {
+    const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(keys + (uint64_t)nkeys * hash_slot_words(LEN));
+    uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
+    for (uint32_t i = tid; i < fbits / 32; i += kBlock) lf[i] = gf[i];
+  }
+  const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier: the filter copy is visible
+  LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0,
+                                   __builtin_amdgcn_groupstaticsize() + filt_off, HASH ? fbits : 0u};
   visit_tiles<LEN, double>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
   double re = sink.re, im = sink.im;
   // fixed-order reduction: lanes (xor butterfly), then waves.  (Which tile a wave gets is dynamic, so the
@@ -117,20 +140,28 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
 // (lookups only start after the build kernel has finished).
 template <int LEN>
 __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__restrict__ keys, int64_t nkeys, uint64_t cap,
-                                                            uint64_t *__restrict__ table) {
+                                                            uint64_t *__restrict__ table, uint32_t fbits) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nkeys) return;
   uint64_t q[LEN];
 #pragma unroll
   for (int w = 0; w < LEN; ++w) q[w] = keys[i * LEN + w];
   constexpr int W = hash_slot_words(LEN);
-  uint64_t s = hash_of<LEN>(q) & (cap - 1);
+  const uint64_t hq = hash_of<LEN>(q);
+  uint64_t s = hq & (cap - 1);
   for (uint64_t probes = 0; probes < cap; ++probes) {
     unsigned long long *idxp = reinterpret_cast<unsigned long long *>(table + s * W + (W - 1));
     const unsigned long long old = atomicCAS(idxp, ~0ull, (unsigned long long)i);
     if (old == ~0ull) {
 #pragma unroll
       for (int w = 0; w < LEN; ++w) table[s * W + w] = q[w];
+      if (fbits) {
+        uint32_t b0, b1;
+        filter_positions(hq, fbits, b0, b1);
+        uint32_t *filter = reinterpret_cast<uint32_t *>(table + cap * W);
+        atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
+        atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
+      }
       return;
     }
     s = (s + 1) & (cap - 1);
@@ -289,7 +320,8 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   hipStream_t st = (hipStream_t)stream;
   uint32_t nchunks, chunk_len;
   plan_chunks(nbatch, p.nsd + 1, &nchunks, &chunk_len);
-  const size_t lds = lds_bytes(p, sizeof(double));
+  const uint32_t fbits = hash ? hash_filter_bits(nkeys) : 0u;
+  const size_t lds = lds_bytes(p, sizeof(double)) + fbits / 8;
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;
@@ -298,7 +330,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
 #define PYNQS_SS_LAUNCH(C, H)                                                                                              \
   hipLaunchKernelGGL((eloc_sample_space_kernel<LEN, C, H>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, \
-                     chunk_len, pd, keys, size_arg, wf, eloc, psi0)
+                     chunk_len, pd, keys, size_arg, wf, eloc, psi0, fbits)
   DISPATCH_LEN(len, {
     if (wf_is_complex) { if (hash) PYNQS_SS_LAUNCH(true, true); else PYNQS_SS_LAUNCH(true, false); }
     else { if (hash) PYNQS_SS_LAUNCH(false, true); else PYNQS_SS_LAUNCH(false, false); }
@@ -326,7 +358,7 @@ extern "C" int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch,
 extern "C" int64_t pynqs_hash_bytes(int64_t nkeys, int sorb) {
   if (nkeys < 0 || sorb < 1 || sorb > kMaxSorb) return -1;
   const int len = (sorb - 1) / 64 + 1;
-  return (int64_t)(hash_capacity(nkeys) * (uint64_t)hash_slot_words(len) * 8);
+  return (int64_t)(hash_capacity(nkeys) * (uint64_t)hash_slot_words(len) * 8 + hash_filter_bits(nkeys) / 8);
 }
 
 extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, void *table, void *stream) {
@@ -336,10 +368,13 @@ extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, v
   const uint64_t cap = hash_capacity(nkeys);
   hipStream_t st = (hipStream_t)stream;
   if ((uintptr_t)table & 15u) return set_error(PYNQS_EINVAL, "table must be 16-byte aligned");
-  if (hipMemsetAsync(table, 0xFF, cap * (size_t)hash_slot_words(len) * 8, st) != hipSuccess) return check_launch("hash memset");
+  const size_t slot_bytes = cap * (size_t)hash_slot_words(len) * 8;
+  const uint32_t fbits = hash_filter_bits(nkeys);
+  if (hipMemsetAsync(table, 0xFF, slot_bytes, st) != hipSuccess) return check_launch("hash memset");
+  if (fbits && hipMemsetAsync((char *)table + slot_bytes, 0, fbits / 8, st) != hipSuccess) return check_launch("filter memset");
   if (nkeys == 0) return PYNQS_OK;
   const uint32_t grid = (uint32_t)((nkeys + kBlock - 1) / kBlock);
-  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table));
+  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table, fbits));
   return check_launch("hash_build");
 }
 
