@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *_
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a workgroup barrier
   const uint32_t ncomb = p.nsd + 1;
-  static_assert((kDiagTile / 4) * sizeof(T) >= 192 * 8, "a wave's scratch quarter must hold 64 three-word kets");
+  static_assert(LEN != 3 || (kDiagTile / 4) * sizeof(T) >= 192 * 8, "a wave's scratch quarter must hold 64 three-word kets");
   StoreSink<LEN, T, WRITE_COMB> sink{hmat + (size_t)walker * ncomb, comb + (size_t)walker * ncomb * LEN,
                                      (lds_u64 *)(reinterpret_cast<T *>(L.scratch) + (threadIdx.x >> 6) * (kDiagTile / 4))};
   const uint32_t odd_base = (uint32_t)((walker * (uint64_t)ncomb) & 1u);  // 16-byte alignment of the pair stores
