@@ -86,7 +86,7 @@ struct LookupSink {
 
 template <int LEN, bool CPLX, bool HASH>
 __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
-                                                                   uint32_t nchunks, uint32_t chunk_len,
+                                                                   uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
                                                                    const double *__restrict__ plan,
                                                                    const uint64_t *__restrict__ keys, int64_t nkeys,
                                                                    const double *__restrict__ wf, double *__restrict__ acc,
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double red[2][kBlock / 64];
   __shared__ uint32_t next_tile;
-  const uint64_t wg = blockIdx.x;
-  const uint64_t walker = wg / nchunks;
-  const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
+  uint64_t walker;
+  uint32_t chunk;
+  map_workgroup(nchunks, xcd_map, walker, chunk);
   const int tid = threadIdx.x;
   if (tid == 0) next_tile = 0;
   Walker<LEN> wk;
@@ -273,24 +273,25 @@ struct ReduceSink {
 
 template <int LEN, typename T, bool EMIT>
 __global__ __launch_bounds__(kBlock) void reduce_tiles_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
-                                                              uint32_t nchunks, uint32_t chunk_len, uint32_t max_tiles,
+                                                              uint32_t nchunks, uint32_t chunk_len, uint32_t max_tiles, bool xcd_map,
                                                               const T *__restrict__ plan, T eps, uint32_t *__restrict__ tile_counts,
                                                               const int64_t *__restrict__ tile_off, int32_t *__restrict__ kept_col,
                                                               uint64_t *__restrict__ kept_onv, T *__restrict__ kept_h) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t wave_run[kBlock / 64];
   __shared__ uint32_t next_tile;
-  const uint64_t wg = blockIdx.x;
-  const uint64_t walker = wg / nchunks;
-  const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
+  uint64_t walker;
+  uint32_t chunk;
+  map_workgroup(nchunks, xcd_map, walker, chunk);
+  const uint64_t slot = walker * nchunks + chunk;  // position of this (walker, chunk) in the per-tile arrays
   const int tid = threadIdx.x;
   if (tid == 0) next_tile = 0;
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
-  ReduceSink<LEN, T, EMIT> sink{eps, wave_run + (tid >> 6), EMIT ? nullptr : tile_counts + wg * max_tiles,
-                                EMIT ? tile_off + wg * max_tiles : nullptr, kept_col, kept_onv, kept_h, 0xffffffffu, 0};
+  ReduceSink<LEN, T, EMIT> sink{eps, wave_run + (tid >> 6), EMIT ? nullptr : tile_counts + slot * max_tiles,
+                                EMIT ? tile_off + slot * max_tiles : nullptr, kept_col, kept_onv, kept_h, 0xffffffffu, 0};
   visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
   sink.flush();
 }
@@ -330,7 +331,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
 #define PYNQS_SS_LAUNCH(C, H)                                                                                              \
   hipLaunchKernelGGL((eloc_sample_space_kernel<LEN, C, H>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, \
-                     chunk_len, pd, keys, size_arg, wf, eloc, psi0, fbits)
+                     chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0, fbits)
   DISPATCH_LEN(len, {
     if (wf_is_complex) { if (hash) PYNQS_SS_LAUNCH(true, true); else PYNQS_SS_LAUNCH(true, false); }
     else { if (hash) PYNQS_SS_LAUNCH(false, true); else PYNQS_SS_LAUNCH(false, false); }
@@ -431,11 +432,12 @@ static int launch_reduce(const uint64_t *bra, int64_t nbatch, int sorb, int nele
   DISPATCH_LEN(len, {
     if (dtype == PYNQS_F64)
       hipLaunchKernelGGL((reduce_tiles_kernel<LEN, double, EMIT>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                         chunk_len, max_tiles, (const double *)plan, eps, tile_counts, tile_off, kept_col, kept_onv, (double *)kept_h);
+                         chunk_len, max_tiles, xcd_mapping(nchunks), (const double *)plan, eps, tile_counts, tile_off, kept_col, kept_onv,
+                         (double *)kept_h);
     else
       hipLaunchKernelGGL((reduce_tiles_kernel<LEN, float, EMIT>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                         chunk_len, max_tiles, (const float *)plan, (float)eps, tile_counts, tile_off, kept_col, kept_onv,
-                         (float *)kept_h);
+                         chunk_len, max_tiles, xcd_mapping(nchunks), (const float *)plan, (float)eps, tile_counts, tile_off, kept_col,
+                         kept_onv, (float *)kept_h);
   });
   return check_launch(EMIT ? "reduce_emit" : "reduce_count");
 }

@@ -154,14 +154,14 @@ struct StoreSink {
 
 template <int LEN, typename T, bool WRITE_COMB>
 __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
-                                                               uint32_t nchunks, uint32_t chunk_len,
+                                                               uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
                                                                const T *__restrict__ plan, uint64_t *__restrict__ comb,
                                                                T *__restrict__ hmat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t next_tile;
-  const uint64_t wg = blockIdx.x;
-  const uint64_t walker = wg / nchunks;
-  const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
+  uint64_t walker;
+  uint32_t chunk;
+  map_workgroup(nchunks, xcd_map, walker, chunk);
   if (threadIdx.x == 0) next_tile = 0;
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
@@ -213,10 +213,10 @@ static int launch_plan(const uint64_t *bra, int64_t nbatch, const SDParams &p, c
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large: nbatch*nchunks > 2^31-1");
   if (comb)
     hipLaunchKernelGGL((comb_hij_plan_kernel<LEN, T, true>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                       chunk_len, plan, comb, hmat);
+                       chunk_len, xcd_mapping(nchunks), plan, comb, hmat);
   else
     hipLaunchKernelGGL((comb_hij_plan_kernel<LEN, T, false>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                       chunk_len, plan, comb, hmat);
+                       chunk_len, xcd_mapping(nchunks), plan, comb, hmat);
   return check_launch("comb_hij_plan");
 }
 

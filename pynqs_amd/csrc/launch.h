@@ -43,6 +43,15 @@ inline void plan_chunks(int64_t nbatch, uint32_t ncomb, uint32_t *nchunks, uint3
   *nchunks = (ncomb + len - 1) / len;
 }
 
+// whether map_workgroup's XCD-aware order applies (plan_tiles.h): at least 8 chunks per walker, a multiple of 8.
+// OFF unless PYNQS_XCD_MAP=1: measured neutral to 8 % slower (sorb 120: 64 walkers 0.575 -> 0.620 ms, 512 walkers
+// 4.376 -> 4.366 ms; sorb 184: 1.075 -> 1.072 ms) -- these kernels sit at the HBM ceiling for mixed traffic
+// (4.5-5.8 TB/s moved; a device copy reaches 4.55), not on L2 misses of the plan.
+inline bool xcd_mapping(uint32_t nchunks) {
+  static const bool on = getenv("PYNQS_XCD_MAP") && atoi(getenv("PYNQS_XCD_MAP")) == 1;
+  return on && nchunks >= 8 && nchunks % 8 == 0;
+}
+
 }  // namespace pynqs
 
 // run-time dispatch of the ONV word count (the reference compiles one build per MAX_SORB_LEN)

@@ -60,6 +60,24 @@ __device__ __forceinline__ ClassRange class_range(uint32_t b0, uint32_t b1, uint
 // Number of tiles of a workgroup: at most max_tiles_per_chunk() (host and device agree on it).
 // `next_tile` is a workgroup-shared counter that must be 0 when the first wave arrives (set it before
 // build_walker_tables, whose final barrier publishes it).
+// blockIdx -> (walker, chunk).  A chunk of columns reads its own part of the plan (the alpha-beta doubles of a chunk
+// use a few [pb][pj] sub-matrices of Vab).  Workgroups are dealt round-robin over the 8 XCDs, each with its own 4 MiB
+// L2 (blocks b and b + 8 share one; observed, not promised -- only speed depends on it): with xcd_map, XCD slot
+// b % 8 gets an eighth of the chunk indices and runs through them chunk by chunk over all walkers, so that the
+// blocks resident on one XCD re-use the same plan lines instead of all eight L2s streaming the whole plan.
+__device__ __forceinline__ void map_workgroup(uint32_t nchunks, bool xcd_map, uint64_t &walker, uint32_t &chunk) {
+  const uint32_t wg = blockIdx.x;
+  if (xcd_map) {  // host guarantees nchunks % 8 == 0
+    const uint32_t nbatch = gridDim.x / nchunks, cpx = nchunks >> 3;
+    const uint32_t q = wg >> 3, cl = q / nbatch;
+    walker = q - cl * nbatch;
+    chunk = (wg & 7u) * cpx + cl;
+  } else {
+    walker = wg / nchunks;
+    chunk = wg - (uint32_t)walker * nchunks;
+  }
+}
+
 // upper bound of `ntiles` below for any chunk of a walker's row
 __host__ __device__ inline uint32_t max_tiles_per_chunk(const SDParams &p, uint32_t nchunks, uint32_t chunk_len) {
   const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
