@@ -72,30 +72,35 @@ __global__ __launch_bounds__(kBlock) void plan_build_kernel(const T *__restrict_
 // a row is < 2^32 bytes (ncomb < 2^24, <= 24 B per ket).
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
-template <typename T>
+// NT: non-temporal stores.  The outputs are written once and never read by the kernel.  When the plan does not fit
+// the L2 (large systems) keeping the output stream out of the caches leaves them to the gathers: sorb 120 0.637 ->
+// 0.517 ms.  When it does fit (Fe2S2, 2 MiB) ordinary stores are faster (0.252 vs 0.285 ms): the host picks.
+#define PYNQS_STORE(ptr, val) do { if constexpr (NT) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
+
+template <bool NT, typename T>
 __device__ __forceinline__ void store_h(T *__restrict__ hrow, uint32_t col, T v) {
-  *reinterpret_cast<T *>(reinterpret_cast<char *>(hrow) + (size_t)(col * (uint32_t)sizeof(T))) = v;
+  PYNQS_STORE(reinterpret_cast<T *>(reinterpret_cast<char *>(hrow) + (size_t)(col * (uint32_t)sizeof(T))), v);
 }
-template <typename T>
+template <bool NT, typename T>
 __device__ __forceinline__ void store_h2(T *__restrict__ hrow, uint32_t col, T v0, T v1) {
   typedef T T2 __attribute__((ext_vector_type(2)));
   T2 v = {v0, v1};
-  *reinterpret_cast<T2 *>(reinterpret_cast<char *>(hrow) + (size_t)(col * (uint32_t)sizeof(T))) = v;
+  PYNQS_STORE(reinterpret_cast<T2 *>(reinterpret_cast<char *>(hrow) + (size_t)(col * (uint32_t)sizeof(T))), v);
 }
-template <int LEN>
+template <bool NT, int LEN>
 __device__ __forceinline__ void store_ket(uint64_t *__restrict__ crow, uint32_t col, const uint64_t (&ket)[LEN]) {
   char *dst = reinterpret_cast<char *>(crow) + (size_t)(col * (uint32_t)(8 * LEN));
   if constexpr (LEN == 2) {  // one 16-byte store (rows of two-word kets are 16-byte aligned)
     u64x2 v = {ket[0], ket[1]};
-    *reinterpret_cast<u64x2 *>(dst) = v;
+    PYNQS_STORE(reinterpret_cast<u64x2 *>(dst), v);
   } else {
 #pragma unroll
-    for (int i = 0; i < LEN; ++i) reinterpret_cast<uint64_t *>(dst)[i] = ket[i];
+    for (int i = 0; i < LEN; ++i) PYNQS_STORE(reinterpret_cast<uint64_t *>(dst) + i, ket[i]);
   }
 }
 // two consecutive kets = 2*LEN words = LEN 16-byte stores; (row base + col) is even, so the address is
 // 16-byte aligned for every LEN
-template <int LEN>
+template <bool NT, int LEN>
 __device__ __forceinline__ void store_ket2(uint64_t *__restrict__ crow, uint32_t col, const uint64_t (&k0)[LEN],
                                            const uint64_t (&k1)[LEN]) {
   u64x2 *dst = reinterpret_cast<u64x2 *>(reinterpret_cast<char *>(crow) + (size_t)(col * (uint32_t)(8 * LEN)));
@@ -103,30 +108,30 @@ __device__ __forceinline__ void store_ket2(uint64_t *__restrict__ crow, uint32_t
 #pragma unroll
   for (int i = 0; i < LEN; ++i) { w[i] = k0[i]; w[LEN + i] = k1[i]; }
 #pragma unroll
-  for (int i = 0; i < LEN; ++i) { u64x2 v = {w[2 * i], w[2 * i + 1]}; dst[i] = v; }
+  for (int i = 0; i < LEN; ++i) { u64x2 v = {w[2 * i], w[2 * i + 1]}; PYNQS_STORE(dst + i, v); }
 }
 
 // The drop-in kernel: every column of the walker's range goes to HBM (comb and Hmat in the reference layout).
 typedef __attribute__((address_space(3))) uint64_t lds_u64;
 
-template <int LEN, typename T, bool WRITE_COMB>
+template <int LEN, typename T, bool WRITE_COMB, bool NT>
 struct StoreSink {
   T *__restrict__ hrow;
   uint64_t *__restrict__ crow;
   lds_u64 *stage;  // this wave's quarter of the LDS scratch (free while the wave is in a doubles tile)
   __device__ __forceinline__ void tile_begin(uint32_t) const {}
   __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&ket)[LEN]) const {
-    store_h<T>(hrow, col, h);
-    if constexpr (WRITE_COMB) store_ket<LEN>(crow, col, ket);
+    store_h<NT, T>(hrow, col, h);
+    if constexpr (WRITE_COMB) store_ket<NT, LEN>(crow, col, ket);
   }
   __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) const {
-    store_h2<T>(hrow, col, h0, h1);
-    if constexpr (WRITE_COMB) store_ket2<LEN>(crow, col, k0, k1);
+    store_h2<NT, T>(hrow, col, h0, h1);
+    if constexpr (WRITE_COMB) store_ket2<NT, LEN>(crow, col, k0, k1);
   }
   // columns c0 = b + lane and c1 = b + 64 + lane of every lane of the wave (plan_tiles.h)
   __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&k0)[LEN], uint32_t c1, T h1, const uint64_t (&k1)[LEN]) const {
-    store_h<T>(hrow, c0, h0);
-    store_h<T>(hrow, c1, h1);
+    store_h<NT, T>(hrow, c0, h0);
+    store_h<NT, T>(hrow, c1, h1);
     if constexpr (WRITE_COMB) {
       if constexpr (LEN == 3) {
         // 24-byte kets: a lane storing its own ket covers a third of each line per instruction.  64 kets of the
@@ -141,18 +146,18 @@ struct StoreSink {
           __builtin_amdgcn_wave_barrier();
           uint64_t *dst = crow + (size_t)((half ? c1 : c0) - lane) * 3;
 #pragma unroll
-          for (int k = 0; k < 3; ++k) dst[lane + 64 * k] = st[lane + 64 * k];
+          for (int k = 0; k < 3; ++k) PYNQS_STORE(dst + lane + 64 * k, (uint64_t)st[lane + 64 * k]);
           __builtin_amdgcn_wave_barrier();
         }
       } else {
-        store_ket<LEN>(crow, c0, k0);
-        store_ket<LEN>(crow, c1, k1);
+        store_ket<NT, LEN>(crow, c0, k0);
+        store_ket<NT, LEN>(crow, c1, k1);
       }
     }
   }
 };
 
-template <int LEN, typename T, bool WRITE_COMB>
+template <int LEN, typename T, bool WRITE_COMB, bool NT>
 __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
                                                                uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
                                                                const T *__restrict__ plan, uint64_t *__restrict__ comb,
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void comb_hij_plan_kernel(const uint64_t *_
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a workgroup barrier
   const uint32_t ncomb = p.nsd + 1;
   static_assert(LEN != 3 || (kDiagTile / 4) * sizeof(T) >= 192 * 8, "a wave's scratch quarter must hold 64 three-word kets");
-  StoreSink<LEN, T, WRITE_COMB> sink{hmat + (size_t)walker * ncomb, comb + (size_t)walker * ncomb * LEN,
+  StoreSink<LEN, T, WRITE_COMB, NT> sink{hmat + (size_t)walker * ncomb, comb + (size_t)walker * ncomb * LEN,
                                      (lds_u64 *)(reinterpret_cast<T *>(L.scratch) + (threadIdx.x >> 6) * (kDiagTile / 4))};
   const uint32_t odd_base = (uint32_t)((walker * (uint64_t)ncomb) & 1u);  // 16-byte alignment of the pair stores
   visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, odd_base, &next_tile, sink);
@@ -211,12 +216,15 @@ static int launch_plan(const uint64_t *bra, int64_t nbatch, const SDParams &p, c
   const size_t lds = lds_bytes(p, sizeof(T));
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large: nbatch*nchunks > 2^31-1");
-  if (comb)
-    hipLaunchKernelGGL((comb_hij_plan_kernel<LEN, T, true>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                       chunk_len, xcd_mapping(nchunks), plan, comb, hmat);
-  else
-    hipLaunchKernelGGL((comb_hij_plan_kernel<LEN, T, false>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
-                       chunk_len, xcd_mapping(nchunks), plan, comb, hmat);
+  // non-temporal output stores once the plan is larger than one XCD's L2 (4 MiB); PYNQS_NT=0/1 overrides
+  static const int nt_env = getenv("PYNQS_NT") ? atoi(getenv("PYNQS_NT")) : -1;
+  const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)pl.total * sizeof(T) > ((size_t)4 << 20);
+#define PYNQS_PLAN_LAUNCH(WC, NTV)                                                                                          \
+  hipLaunchKernelGGL((comb_hij_plan_kernel<LEN, T, WC, NTV>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, \
+                     chunk_len, xcd_mapping(nchunks), plan, comb, hmat)
+  if (comb) { if (nt) PYNQS_PLAN_LAUNCH(true, true); else PYNQS_PLAN_LAUNCH(true, false); }
+  else { if (nt) PYNQS_PLAN_LAUNCH(false, true); else PYNQS_PLAN_LAUNCH(false, false); }
+#undef PYNQS_PLAN_LAUNCH
   return check_launch("comb_hij_plan");
 }
 
