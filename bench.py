@@ -181,8 +181,25 @@ class DropinFused(Workload):
             if time.perf_counter() - t0 > budget_s * 0.8 or reps >= 50:
                 break
         el = time.perf_counter() - t0
-        return {"value": done / el, "unit": "local energies/s", "cores": cores, "kind": kind,
-                "sample": f"{reps} x get_comb_hij_fused on the first {sample} walkers of the same batch ({el:.1f} s)"}
+        out = {"value": done / el, "unit": "local energies/s", "cores": cores, "kind": kind,
+               "sample": f"{reps} x get_comb_hij_fused on the first {sample} walkers of the same batch ({el:.1f} s)"}
+        # the reference's production setting is OMP_NUM_THREADS=1 per GPU process (run.sh:3): the same call on one thread
+        try:
+            if kind == "reference":
+                torch.set_num_threads(1)
+                one = fn
+            else:
+                one = lambda xs: O.comb_hij_fused(xs.numpy(), h1n, h2n, self.sorb, self.nele, self.noA, self.noB, nthreads=1)
+            m1 = max(1, min(self.n, 512))
+            t0 = time.perf_counter(); r1 = 0
+            while time.perf_counter() - t0 < 2.0:
+                one(x[:m1].contiguous()); r1 += 1
+            out["one_thread"] = {"value": m1 * r1 / (time.perf_counter() - t0), "unit": "local energies/s", "cores": 1,
+                                 "sample": f"{r1} x the same call on the first {m1} walkers"}
+        finally:
+            if kind == "reference":
+                torch.set_num_threads(cores)
+        return out
 
 
 class SampleSpaceFused(Workload):

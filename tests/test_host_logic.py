@@ -126,3 +126,20 @@ def test_unique_onv_matches_torch_unique():
         assert torch.equal(torch.unique(u, dim=0), ref)
     u, inv = unique_onv(torch.empty((0, 16), dtype=torch.uint8))
     assert u.shape == (0, 16) and inv.numel() == 0
+
+
+def test_header_is_valid_c99(tmp_path):
+    """include/pynqs_amd.h is the C ABI: it must compile as plain C (no C++-isms), and a C translation unit that
+    takes the address of every declared entry point must type-check."""
+    import re
+    import subprocess
+
+    from pynqs_amd import _native
+
+    hdr = os.path.join(ROOT, "include", "pynqs_amd.h")
+    src = tmp_path / "abi.c"
+    names = sorted(_native.SIGNATURES)
+    src.write_text('#include "pynqs_amd.h"\nvoid *table[] = {\n' + "".join(f"  (void *){n},\n" for n in names) + "};\n")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-Wno-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr), str(src)])
+    declared = set(re.findall(r"\b(pynqs_[a-z0-9_]+)\s*\(", open(hdr).read()))
+    assert declared == set(names)
