@@ -66,9 +66,9 @@ static inline RbmBlocks make_rbm_blocks(const SDParams &p) {
 }
 
 // LDS after the walker tables (16-byte aligned): [q / staging][mn][sh][Cq][hs]
-//   q   [sorb + 1][Hq]  row r(o) = o/2 for alpha, sorb/2 + o/2 for beta orbitals (a wave mostly reads rows of one
-//                       spin: consecutive rows -> different 16-byte slots); row `sorb` is all ones (the partner
-//                       of a single); aliases the scratch the singles / diagonal are staged in
+//   q   [sorb + 1][hw+1] row r(o) = o/2 for alpha, sorb/2 + o/2 for beta orbitals (a wave mostly reads rows of one
+//                       spin: consecutive rows -> different bank pairs); row `sorb` belongs to the dummy orbital
+//                       (the partner of a single); hw hidden units at a time (all of them in the fast kernel)
 //   mn  [2][Hq]         m_h, then (m_h rho_h)^(1/4) (1, 0 in the padding)
 //   sh  [Hq]            s_h
 //   Cq  [sorb + 2]      C(o) by orbital, 1 for the dummy orbital `sorb`
@@ -83,14 +83,15 @@ struct RbmLds {
 
 __host__ __device__ inline size_t rbm_q_offset(const SDParams &p) { return (lds_fixed_bytes(p) + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t rbm_region_bytes(const SDParams &p, const RbmLayout &rl) {
-  const size_t a = (size_t)kDiagTile * 8 + 16, b = (size_t)(p.sorb + 1) * rl.Hq * 8;
-  return ((a > b ? a : b) + 15) & ~(size_t)15;
+// `hw` = hidden units resident in LDS at a time: rl.Hloop (all of them, the fast kernel) or a multiple of 8 (the
+// windowed kernel for sorb x num_hidden beyond the LDS); row stride hw + 1 doubles (odd: see rbm.h)
+__host__ __device__ inline size_t rbm_region_bytes(const SDParams &p, uint32_t hw) {
+  return (((size_t)(p.sorb + 1) * (hw + 1) * 8) + 15) & ~(size_t)15;
 }
 
-__host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayout &rl) {
-  return rbm_q_offset(p) + rbm_region_bytes(p, rl) +
-         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 48;  // + red, tile counter
+__host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayout &rl, uint32_t hw) {
+  return rbm_q_offset(p) + rbm_region_bytes(p, hw) +
+         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 48;  // + red, counters
 }
 
 __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o >> 1) + ((o & 1u) ? K : 0u); }
@@ -129,15 +130,19 @@ __device__ __forceinline__ void rbm_singles(uint32_t r, const SDParams &p, const
   hs[1 + r] = ((e >> 16) & 1u) ? -acc : acc;
 }
 
-template <int LEN>
+// WINDOWED = false: all hidden units of q' live in LDS, waves pull tiles from a counter (the fast kernel).
+// WINDOWED = true : sorb x num_hidden does not fit: the workgroup streams q' through LDS `hw` hidden units at a time;
+//                   in every round each wave holds the 16 x 64 running products of ONE tile in registers across the
+//                   windows (two barriers per window).
+template <int LEN, bool WINDOWED>
 __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
-                                                          RbmBlocks B, uint32_t nchunks, const double *__restrict__ plan,
+                                                          RbmBlocks B, uint32_t nchunks, uint32_t hw, const double *__restrict__ plan,
                                                           const double *__restrict__ rbm, double *__restrict__ eloc,
                                                           double *__restrict__ psi) {
   // no static __shared__ here: with the dynamic region at LDS address 0 the row offsets below are the addresses and
   // the ds_read immediates carry the rest (a static in front costs one v_add per read)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *red = reinterpret_cast<double *>(smem + lds_bytes_rbm(p, rl) - 48);  // [kBlock / 64]
+  double *red = reinterpret_cast<double *>(smem + lds_bytes_rbm(p, rl, hw) - 48);  // [kBlock / 64]
   uint32_t *next_tile_p = reinterpret_cast<uint32_t *>(red + kBlock / 64);
   uint32_t *next_single_p = next_tile_p + 1;
 #define next_tile (*next_tile_p)
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
     // (plain offsets from the LDS array: a pointer that went through an integer cast is no longer known to be LDS
     // and its loads become flat_load with full waits)
     R.q = reinterpret_cast<double *>(smem + rbm_q_offset(p));
-    R.mn = reinterpret_cast<double *>(smem + rbm_q_offset(p) + rbm_region_bytes(p, rl));
+    R.mn = reinterpret_cast<double *>(smem + rbm_q_offset(p) + rbm_region_bytes(p, hw));
     R.sh = R.mn + 2 * Hq;
     R.Cq = R.sh + Hq;
     R.hs = R.Cq + (sorb + 2);
@@ -216,68 +221,87 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   if (tid == 0) eloc[walker] = R.hs[0];
   return;
 #endif
-  // ---- phase B: q[o][h] = exp(4 s_h x_o W[h][o]) and C(o) = exp(-2 x_o (a_o + sum_h s_h W[h][o])), a wave per row --
-  // (kRowBatch rows x 2 columns per lane are requested together: an un-batched loop pays one L2 round trip per row)
+  // ---- phase B: q'[o][h] = (m_h rho_h)^(1/4) exp(4 s_h x_o W[h][o]) for the hidden units [h0, h0 + hw) into LDS, a wave
+  // per row, and (with_sum) sum_h s_h W[h][o] -> Cq[o].  kRowBatch rows x 2 columns per lane are requested together:
+  // an un-batched loop pays one L2 round trip per row.
   constexpr int kRowBatch = 4;
-  const int kWaves = nwaves;
   const double *__restrict__ E4 = rbm + rl.offE4p;
-  const uint32_t dE4 = (uint32_t)(rl.offE4m - rl.offE4p), uHq = (uint32_t)Hq;
-  bool pos[2];   // s_h > 0 for this lane's two columns
-  double fq[2];  // (m_h rho_h)^(1/4), 0 in the padding
-  double sgn[2];
+  const uint32_t dE4 = (uint32_t)(rl.offE4m - rl.offE4p), uHq = (uint32_t)Hq, stride = hw + 1;
+  auto build_window = [&](uint32_t h0, bool with_sum) {
+    bool pos[2];   // s_h > 0 for this lane's two columns
+    double fq[2];  // (m_h rho_h)^(1/4), 0 in the padding
+    double sgn[2];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const int h = lane + 64 * c;
-    sgn[c] = h < H ? R.sh[h] : 0.0;
-    pos[c] = sgn[c] > 0.0;
-    fq[c] = h < H ? R.mn[Hq + h] : 0.0;
-  }
-  for (int o0 = wave; o0 <= sorb; o0 += kWaves * kRowBatch) {
-    double e4[kRowBatch][2], wv[kRowBatch][2];
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t j = lane + 64 * c, h = h0 + j;
+      const bool in = j < hw && h < (uint32_t)H;
+      sgn[c] = in ? R.sh[h] : 0.0;
+      pos[c] = sgn[c] > 0.0;
+      fq[c] = in ? R.mn[Hq + h] : 0.0;
+    }
+    for (int o0 = wave; o0 <= sorb; o0 += nwaves * kRowBatch) {
+      double e4[kRowBatch][2], wv[kRowBatch][2];
 #pragma unroll
-    for (int b = 0; b < kRowBatch; ++b) {
-      const int o = o0 + b * kWaves;
-      const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
+      for (int b = 0; b < kRowBatch; ++b) {
+        const int o = o0 + b * nwaves;
+        const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const uint32_t h = lane + 64 * c, idx = (uint32_t)o * uHq + h;
-        e4[b][c] = 1.0; wv[b][c] = 0.0;
-        if (o < sorb && h < (uint32_t)H) {
-          e4[b][c] = E4[idx + (pos[c] == occ ? 0u : dE4)];
-          wv[b][c] = Wt[idx];
+        for (int c = 0; c < 2; ++c) {
+          const uint32_t j = lane + 64 * c, h = h0 + j, idx = (uint32_t)o * uHq + h;
+          e4[b][c] = 1.0; wv[b][c] = 0.0;
+          if (o < sorb && j < hw && h < (uint32_t)H) {
+            e4[b][c] = E4[idx + (pos[c] == occ ? 0u : dE4)];
+            if (with_sum) wv[b][c] = Wt[idx];
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < kRowBatch; ++b) {
+        const int o = o0 + b * nwaves;
+        if (o > sorb) break;  // wave-uniform
+        const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
+        const uint32_t rowq = (o < sorb ? rbm_row(o, K) : (uint32_t)sorb) * stride;
+        double S = sgn[0] * wv[b][0] + sgn[1] * wv[b][1];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (lane + 64 * c < stride) R.q[rowq + lane + 64 * c] = e4[b][c] * fq[c];
+        for (uint32_t j = lane + 128; j < stride; j += 64) {  // windows wider than 128 hidden units: the rest of the row
+          const uint32_t h = h0 + j;
+          double v = 0.0;
+          if (j < hw && h < (uint32_t)H) {
+            const double s2 = R.sh[h];
+            v = R.mn[Hq + h];
+            if (o < sorb) {
+              const uint32_t idx = (uint32_t)o * uHq + h;
+              v *= E4[idx + ((s2 > 0.0) == occ ? 0u : dE4)];
+              if (with_sum) S += s2 * Wt[idx];
+            }
+          }
+          R.q[rowq + j] = v;
+        }
+        if (with_sum) {
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) S += __shfl_xor(S, d);
+          if (lane == 0) R.Cq[o] = S;  // sum_h s_h W[h][o]; turned into C(o) below, all orbitals at once
         }
       }
     }
-#pragma unroll
-    for (int b = 0; b < kRowBatch; ++b) {
-      const int o = o0 + b * kWaves;
-      if (o > sorb) break;  // wave-uniform
-      const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
-      const uint32_t rowq = (o < sorb ? rbm_row(o, K) : (uint32_t)sorb) * uHq;
-      double S = sgn[0] * wv[b][0] + sgn[1] * wv[b][1];
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-        if (lane + 64 * c < Hq) R.q[rowq + lane + 64 * c] = e4[b][c] * fq[c];
-      for (int h = lane + 128; h < Hq; h += 64) {  // more than 128 hidden units: the rest of the row
-        double v = 0.0;
-        if (h < H) {
-          const double s2 = R.sh[h];
-          v = R.mn[Hq + h];
-          if (o < sorb) {
-            const uint32_t idx = (uint32_t)o * uHq + h;
-            v *= E4[idx + ((s2 > 0.0) == occ ? 0u : dE4)];
-            S += s2 * Wt[idx];
-          }
-        }
-        R.q[rowq + h] = v;
-      }
+  };
+  if constexpr (!WINDOWED) {
+    build_window(0u, true);
+  } else {
+    // sum_h s_h W[h][o] over ALL hidden units, a wave per orbital (the windows are built inside the rounds below)
+    for (int o = wave; o <= sorb; o += nwaves) {
+      double S = 0.0;
+      if (o < sorb)
+        for (int h = lane; h < H; h += 64) S += R.sh[h] * Wt[(uint32_t)o * uHq + h];
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) S += __shfl_xor(S, d);
-      if (lane == 0) R.Cq[o] = S;  // sum_h s_h W[h][o]; turned into C(o) below, all orbitals at once
+      if (lane == 0) R.Cq[o] = S;
     }
   }
   __syncthreads();
-  const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)rbm_q_offset(p), rowB = (uint32_t)Hq * 8u;
+  const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)rbm_q_offset(p), rowB = stride * 8u;
   for (int o = tid; o <= sorb; o += nthreads) {
     R.rowaddr[o] = qbase + (o < sorb ? rbm_row(o, K) : (uint32_t)sorb) * rowB;
     double c = 1.0;
@@ -294,17 +318,23 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   return;
 #endif
 
-  // ---- tiles of 64 blocks, pulled by the waves from an LDS counter --------------------------------------------
+  // ---- tiles of 64 blocks: pulled by the waves from an LDS counter, or (WINDOWED) one per wave and round ------------
   const double *__restrict__ Vss = plan + pl.offVss;
   const double *__restrict__ Vab = plan + pl.offVab;
   const uint32_t my_tiles = B.ntiles > chunk ? (B.ntiles - chunk + nchunks - 1) / nchunks : 0;
+  const uint32_t nrounds = (my_tiles + nwaves - 1) / nwaves;  // WINDOWED only
   double esum = 0.0;
-  for (;;) {
+  for (uint32_t round = 0;; ++round) {
     uint32_t lt = 0;
-    if (lane == 0) lt = atomicAdd(&next_tile, 1u);
-    lt = __builtin_amdgcn_readfirstlane(lt);
-    if (lt >= my_tiles) break;
-    const uint32_t id = (chunk + lt * nchunks) * 64u + (uint32_t)lane;
+    if constexpr (WINDOWED) {
+      if (round >= nrounds) break;       // workgroup-uniform: the windows below contain barriers
+      lt = round * nwaves + wave;        // >= my_tiles: a wave without a tile still helps to build the windows
+    } else {
+      if (lane == 0) lt = atomicAdd(&next_tile, 1u);
+      lt = __builtin_amdgcn_readfirstlane(lt);
+      if (lt >= my_tiles) break;
+    }
+    const uint32_t id = lt < my_tiles ? (chunk + lt * nchunks) * 64u + (uint32_t)lane : 0xffffffffu;
     // class and block of this lane
     int cls = 4;
     uint32_t bid = 0, nbf = 1, offF = 0, offS = 0, nF = 1, nS = 1;
@@ -314,20 +344,16 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
     else if (id < B.b[2]) { cls = 2; bid = id - B.b[1]; nbf = B.nbf[2]; dv = B.dv[2]; offF = p.offHPb; offS = p.offPPb; nF = p.noBB; nS = p.nvBB; }
     else if (id < B.b[3]) { cls = 3; bid = id - B.b[2]; nbf = B.nbf[3]; dv = B.dv[3]; offF = p.offSa; offS = p.offSb; nF = p.nSa; nS = p.nSb; }
     const uint32_t bs = mdiv(bid, dv), bf = bid - bs * nbf;
-    uint32_t ef[4], es[4];
-    // the q rows of the 8 entries' orbitals as 32-bit LDS addresses (the dynamic region starts at the static size;
-    // an array of generic pointers loses the address space and its loads become flat_load)
-    uint32_t rb[16];
     const bool real_fast = cls < 4, real_slow = cls >= 1 && cls < 4;
+    // the 4 + 4 table entries of this lane's block; re-read where needed rather than kept in registers over the
+    // hidden-unit loop (the kernel sits at the 128-VGPR line)
+    auto entries = [&](uint32_t (&ef)[4], uint32_t (&es)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ef[i] = real_fast ? L.tab[offF + min(4 * bf + i, nF - 1)] : 0u;
-      es[i] = real_slow ? L.tab[offS + min(4 * bs + i, nS - 1)] : 0u;
-      rb[2 * i] = R.rowaddr[real_fast ? (ef[i] & 0xff) : (uint32_t)sorb];
-      rb[2 * i + 1] = R.rowaddr[real_fast ? ((ef[i] >> 8) & 0xff) : (uint32_t)sorb];
-      rb[8 + 2 * i] = R.rowaddr[real_slow ? (es[i] & 0xff) : (uint32_t)sorb];
-      rb[8 + 2 * i + 1] = R.rowaddr[real_slow ? ((es[i] >> 8) & 0xff) : (uint32_t)sorb];
-    }
+      for (int i = 0; i < 4; ++i) {
+        ef[i] = real_fast ? L.tab[offF + min(4 * bf + i, nF - 1)] : 0u;
+        es[i] = real_slow ? L.tab[offS + min(4 * bs + i, nS - 1)] : 0u;
+      }
+    };
     double acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 1.0;
@@ -336,30 +362,58 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
     // Eight sub-steps share one update of the row addresses (immediate offsets); the empty asm keeps the compiler
     // from fusing the loads of neighbouring hidden units into ds_read2_b64 (half the LDS rate) or into 16-byte
     // loads (twice the registers: the kernel must stay below 128 VGPRs for 4 waves per SIMD).
-    for (int h = 0; h < rl.Hloop; h += 8) {
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<lds_cdouble *>(rb[k] + 8 * c);
-        const double m = R.mn[h + c];
-        double gf[4], gs[4];
+    auto hidden_units = [&](uint32_t h0, uint32_t count) {
+      // the q' rows of the 8 entries' orbitals as 32-bit LDS addresses (the dynamic region starts at the static
+      // size; an array of generic pointers loses the address space and its loads become flat_load)
+      uint32_t rb[16];
+      {
+        uint32_t ef[4], es[4];
+        entries(ef, es);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          gf[i] = v[2 * i] * v[2 * i + 1];
-          gs[i] = v[8 + 2 * i] * v[8 + 2 * i + 1];
+          rb[2 * i] = R.rowaddr[real_fast ? (ef[i] & 0xff) : (uint32_t)sorb];
+          rb[2 * i + 1] = R.rowaddr[real_fast ? ((ef[i] >> 8) & 0xff) : (uint32_t)sorb];
+          rb[8 + 2 * i] = R.rowaddr[real_slow ? (es[i] & 0xff) : (uint32_t)sorb];
+          rb[8 + 2 * i + 1] = R.rowaddr[real_slow ? ((es[i] >> 8) & 0xff) : (uint32_t)sorb];
+        }
+      }
+      for (uint32_t h = 0; h < count; h += 8) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          double v[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<lds_cdouble *>(rb[k] + 8 * c);
+          const double m = R.mn[h0 + h + c];
+          double gf[4], gs[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            gf[i] = v[2 * i] * v[2 * i + 1];
+            gs[i] = v[8 + 2 * i] * v[8 + 2 * i + 1];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * i + j] *= fma(gf[i], gs[j], m);
+          asm volatile("" ::: "memory");
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[4 * i + j] *= fma(gf[i], gs[j], m);
-        asm volatile("" ::: "memory");
+        for (int k = 0; k < 16; ++k) rb[k] += 64;
       }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) rb[k] += 64;
+    };
+    if constexpr (WINDOWED) {
+      for (uint32_t h0 = 0; h0 < (uint32_t)rl.Hloop; h0 += hw) {
+        __syncthreads();  // the previous window has been consumed by every wave
+        build_window(h0, false);
+        __syncthreads();
+        hidden_units(h0, min(hw, (uint32_t)rl.Hloop - h0));
+      }
+    } else {
+      hidden_units(0u, (uint32_t)rl.Hloop);
     }
     // matrix elements, prefactors, sum
     if (cls < 4) {
+      uint32_t ef[4], es[4];
+      entries(ef, es);
       double cf[4], cs[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -430,6 +484,17 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
 using namespace pynqs;
 
 static constexpr size_t kRbmMaxLds = 158 * 1024;  // of the CU's 160 KiB
+static constexpr size_t kRbmWindowLds = 64 * 1024;  // LDS target of the windowed kernel (2 workgroups per CU)
+
+// hidden units resident in LDS: all of them (rl.Hloop) when that fits, else the largest multiple of 8 that keeps the
+// workgroup within kRbmWindowLds (at least 8); 0 if not even that fits
+static uint32_t rbm_window(const SDParams &p, const RbmLayout &rl) {
+  if (lds_bytes_rbm(p, rl, (uint32_t)rl.Hloop) <= kRbmMaxLds) return (uint32_t)rl.Hloop;
+  const size_t other = lds_bytes_rbm(p, rl, 0u) - rbm_region_bytes(p, 0u);
+  for (uint32_t hw = 256; hw >= 8; hw -= 8)
+    if (other + rbm_region_bytes(p, hw) <= (hw > 8 ? kRbmWindowLds : kRbmMaxLds)) return hw;
+  return 0;
+}
 
 extern "C" int64_t pynqs_rbm_table_bytes(int sorb, int nhidden) {
   RbmLayout rl;
@@ -442,7 +507,7 @@ extern "C" int pynqs_eloc_rbm_supported(int sorb, int nele, int noA, int noB, in
   PlanLayout pl;
   RbmLayout rl;
   if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl) || !make_rbm_layout(sorb, nhidden, &rl)) return 0;
-  return lds_bytes_rbm(p, rl) <= kRbmMaxLds ? 1 : 0;
+  return rbm_window(p, rl) > 0 ? 1 : 0;
 }
 
 extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb,
@@ -468,8 +533,10 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   if (nbatch < 0 || nbatch > 0x7fffffffll) return set_error(PYNQS_EINVAL, "bad nbatch");
   if (nbatch == 0) return PYNQS_OK;
   if (!bra || !plan || !rbm_table || !eloc) return set_error(PYNQS_EINVAL, "null pointer");
-  const size_t lds = lds_bytes_rbm(p, rl);
-  if (lds > kRbmMaxLds) return set_error(PYNQS_EINVAL, "RBM table of this sorb x nhidden does not fit the 160 KB LDS");
+  const uint32_t hw = rbm_window(p, rl);
+  if (hw == 0) return set_error(PYNQS_EINVAL, "the walker tables of this system leave no LDS for the RBM rows");
+  const bool windowed = hw < (uint32_t)rl.Hloop;
+  const size_t lds = lds_bytes_rbm(p, rl, hw);
   const RbmBlocks B = make_rbm_blocks(p);
   // few walkers: cut a walker's tiles over several workgroups (each repeats the per-walker set-up)
   uint32_t nchunks = 1;
@@ -486,13 +553,18 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   // (3-wave workgroups divide Fe2S2's 9 tiles evenly but leave only 12 waves per CU -- LDS allows 4 workgroups --
   // and were 8 % slower at 80 hidden units; the kernel itself runs with any multiple of 64 threads >= 128)
   const uint32_t threads = kBlock;
+#define PYNQS_RBM_LAUNCH(W)                                                                                                     \
+  do {                                                                                                                          \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN, W>),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)            \
+      return check_launch("hipFuncSetAttribute");                                                                               \
+    hipLaunchKernelGGL((eloc_rbm_kernel<LEN, W>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, rl, B, nchunks, hw, \
+                       (const double *)plan, (const double *)rbm_table, eloc, psi);                                            \
+  } while (0)
   DISPATCH_LEN(len, {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return check_launch("hipFuncSetAttribute");
-    hipLaunchKernelGGL((eloc_rbm_kernel<LEN>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, rl, B, nchunks,
-                       (const double *)plan, (const double *)rbm_table, eloc, psi);
+    if (windowed) PYNQS_RBM_LAUNCH(true);
+    else PYNQS_RBM_LAUNCH(false);
   });
+#undef PYNQS_RBM_LAUNCH
   return check_launch("eloc_rbm");
 }

@@ -94,3 +94,39 @@ def test_empty_and_errors(cx, fe2s2):
         cx.RBMTable(_dev(d["W"]).float(), _dev(d["hb"]).float(), None)
     with pytest.raises(RuntimeError):
         cx.RBMTable(_dev(d["W"]), _dev(d["hb"][:-1]), None)
+
+
+@pytest.mark.parametrize("sorb,noA,noB,H,n", [(128, 3, 2, 400, 5), (184, 2, 2, 368, 3), (66, 5, 5, 700, 4), (40, 15, 15, 1200, 2)])
+def test_windowed_kernel_against_oracle(cx, sorb, noA, noB, H, n):
+    """sorb x num_hidden beyond the LDS: the windowed kernel (hidden units streamed through LDS in windows, one tile
+    per wave and round) against the oracle's materialise-and-forward result."""
+    from oracle import oracle
+    from pynqs_amd import _native as N
+
+    h1, h2 = synth_integrals(sorb)
+    occ = rand_occ(n, sorb, noA, noB, seed=sorb + H)
+    bra_cpu = oracle.pm01_to_onv(occ, sorb)
+    g = np.random.default_rng(sorb * 7 + H)
+    W = 0.05 * (g.random((H, sorb)) - 0.5)
+    hb = 2.0 * (g.random(H) - 0.5)
+    vb = 0.2 * (g.random(sorb) - 0.5)
+    assert N.lib().pynqs_eloc_rbm_supported(sorb, noA + noB, noA, noB, H) == 1
+    # reference in the log domain: with > 1000 hidden units psi = prod 2cosh(theta) itself overflows float64 (the
+    # oracle, like the reference's rbm.py, then returns inf / nan) while the ratios stay finite
+    comb, hm = oracle.comb_hij_fused(bra_cpu, h1, h2, sorb, noA + noB, noA, noB)
+    xs = oracle.onv_to_pm1(comb.reshape(-1, comb.shape[-1]), sorb)
+    th = xs @ W.T + hb
+    lnpsi = (xs @ vb + (np.abs(th) + np.log1p(np.exp(-2.0 * np.abs(th)))).sum(1)).reshape(n, -1)
+    e_ref = (hm * np.exp(lnpsi - lnpsi[:, :1])).sum(1)
+    tab = cx.RBMTable(_dev(W), _dev(hb), _dev(vb))
+    e, p = cx.eloc_rbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
+    with np.errstate(over="ignore"):
+        p_ref = np.exp(lnpsi[:, 0])
+    if np.isfinite(p_ref).all():
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref, rtol=1e-10)
+        e_orc, _ = oracle.eloc_simple_rbm(bra_cpu, h1, h2, sorb, noA + noB, noA, noB, W, hb, vb)
+        np.testing.assert_allclose(e_orc, e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
+    else:
+        assert torch.isinf(p).all()
+    scale = max(1.0, float(np.abs(e_ref).max()))
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
