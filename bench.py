@@ -547,7 +547,8 @@ def main():
             old_default = torch.get_default_dtype()
             torch.set_default_dtype(torch.float64)
             old_fused_rbm, E.FUSED_RBM = E.FUSED_RBM, False  # this line measures the generic module path
-            for tag, nw, kw in (("fe2s2_eloc_simple_rbm_torch", 512, {}), ("fe2s2_eloc_reduce_eps1e-2_rbm_torch", 8192, {"reduce_psi": True, "eps": 1e-2})):
+            for tag, nw, kw in (("fe2s2_eloc_simple_rbm_torch", 512, {}), ("fe2s2_eloc_reduce_eps1e-2_rbm_torch", 8192, {"reduce_psi": True, "eps": 1e-2}),
+                                ("fe2s2_eloc_reduce_eps1e-2_sample1000_rbm_torch", 8192, {"reduce_psi": True, "eps": 1e-2, "eps_sample": 1000})):
                 xg = torch.from_numpy(np.ascontiguousarray(d["ci_space"][:nw])).to(dev)
                 fn = lambda: E.total_energy(xg, nw, 2_000_000, h1g, h2g, rbm, sorb, nele, noA, noB, use_unique=True, **kw)
                 fn(); torch.cuda.synchronize(dev)

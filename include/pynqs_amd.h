@@ -190,6 +190,26 @@ int pynqs_reduce_emit(const uint64_t *bra, int64_t nbatch, int sorb, int nele, i
                       const void *plan, int dtype, double eps, const int64_t *tile_offsets, int32_t *kept_col,
                       uint64_t *kept_onv, void *kept_h, void *stream);
 
+/* Semi-stochastic REDUCE (eloc.py:257-296, eps_sample > 0; the Fe2S2 example uses eps = 1e-2, eps_sample = 1000):
+ * columns with |H| >= eps are kept (the three calls above); from the others N columns are drawn with replacement,
+ * p_m = |H_m| / S, and a column drawn c times carries the weight (c / N) sign(H_m) S.  The multinomial is drawn
+ * hierarchically -- over the tiles on the host, inside a tile on the GPU -- which is the same distribution:
+ *   pynqs_reduce_count_sums : like pynqs_reduce_count, plus tile_sums double[nbatch][T] = sum of the sub-eps |H| per
+ *                             tile (eps = +inf: nothing is kept, every column can be drawn)
+ *   pynqs_reduce_sample     : tile_draws int32[nbatch][T] = draws per tile (host: multinomial over tile_sums),
+ *                             sample_offsets int64[nbatch][T] = exclusive prefix of tile_draws over the flattened
+ *                             array, walker_scale double[nbatch] = S / N, seed for the counter-based generator.
+ *                             Tile t writes one record per DISTINCT drawn column into s_col / s_onv / s_h starting at
+ *                             sample_offsets[t] (at most tile_draws[t] of them; pre-fill s_col with -1 to tell the
+ *                             unused slots): s_h = sign(H) * hits * walker_scale. */
+int pynqs_reduce_count_sums(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                            const void *plan, int dtype, double eps, uint32_t *tile_counts, double *tile_sums,
+                            void *stream);
+int pynqs_reduce_sample(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                        int dtype, double eps, const int32_t *tile_draws, const int64_t *sample_offsets,
+                        const double *walker_scale, uint64_t seed, int32_t *s_col, uint64_t *s_onv, void *s_h,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

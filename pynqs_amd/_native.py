@@ -48,6 +48,8 @@ SIGNATURES = {
     "pynqs_weighted_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "pynqs_reduce_tiles": (_i64, [_i64, _int, _int, _int, _int]),
     "pynqs_reduce_count": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp]),
+    "pynqs_reduce_count_sums": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp, _vp]),
+    "pynqs_reduce_sample": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "pynqs_reduce_emit": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -34,6 +34,7 @@ from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, che
                               spin_flip_onv, spin_flip_sign, split_batch_idx, unique_onv)
 
 FUSED = True  # use the fused sample-space / reduce kernels when the configuration allows it
+FUSED_SAMPLED = True  # REDUCE with eps_sample > 0: select and draw on chip (reduce_compact_sampled) instead of torch.multinomial on the matrix
 FUSED_RBM = True  # SIMPLE method: evaluate a real RBM ansatz inside the kernel (pynqs_eloc_rbm) instead of calling the module
 
 
@@ -204,6 +205,71 @@ def reduce_compact(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, no
     return row, col, onv, h, counts
 
 
+def reduce_compact_sampled(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int,
+                           seed: Optional[int] = None):
+    """The semi-stochastic selection of vmc/energy/eloc.py:257-296 without the [n, ncomb] matrices.
+    Returns (kept, sampled): kept = (row, col, onv, h, counts) of the columns with |h| >= eps (empty when eps <= 0:
+    the reference then draws from all columns), sampled = (row, col, onv, w, counts) with one record per distinct
+    drawn column and w = (hits / eps_sample) * sign(h) * S_row, S_row = sum of the sub-eps |h| of the row.
+    The draws over the tiles of a row come from torch.multinomial, the ones inside a tile from a counter-based
+    generator in the kernel seeded with `seed` (default: drawn from torch's generator)."""
+    plan = CX.plan_for(h1e, h2e, sorb)
+    dev = x.device
+    n = x.size(0)
+    L = (sorb - 1) // 64 + 1
+    code = N.PYNQS_F64 if h1e.dtype == torch.float64 else N.PYNQS_F32
+    st = torch.cuda.current_stream(dev).cuda_stream
+    lib = N.lib()
+    T = lib.pynqs_reduce_tiles(n, sorb, nele, noa, nob)
+    if T < 0:
+        raise RuntimeError("pynqs_reduce_tiles: bad arguments")
+    eps_eff = float(eps) if eps > 0.0 else float("inf")
+    tile_counts = torch.empty((n, T), dtype=torch.int32, device=dev)
+    tile_sums = torch.empty((n, T), dtype=torch.float64, device=dev)
+    N.check(lib.pynqs_reduce_count_sums(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, eps_eff, tile_counts.data_ptr(),
+                                        tile_sums.data_ptr(), st), "pynqs_reduce_count_sums")
+    # kept part (same records as reduce_compact)
+    ends = torch.cumsum(tile_counts.view(-1), 0, dtype=torch.int64)
+    counts = tile_counts.sum(1, dtype=torch.int64)
+    m = int(ends[-1].item()) if n else 0
+    col = torch.empty(m, dtype=torch.int32, device=dev)
+    onv = torch.empty((m, 8 * L), dtype=torch.uint8, device=dev)
+    h = torch.empty(m, dtype=h1e.dtype, device=dev)
+    row = torch.repeat_interleave(torch.arange(n, device=dev), counts)
+    if m:
+        tile_off = (ends - tile_counts.view(-1)).contiguous()
+        N.check(lib.pynqs_reduce_emit(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, eps_eff, tile_off.data_ptr(),
+                                      col.data_ptr(), onv.data_ptr(), h.data_ptr(), st), "pynqs_reduce_emit")
+    # draws over the tiles, then inside the tiles
+    S = tile_sums.sum(1)
+    live = S > 0
+    probs = torch.where(live.unsqueeze(1), tile_sums, torch.ones_like(tile_sums))
+    ids = torch.multinomial(probs, eps_sample, replacement=True)
+    flat_ids = (ids + torch.arange(n, device=dev).unsqueeze(1) * T).view(-1)
+    tile_draws = torch.bincount(flat_ids, minlength=n * T).view(n, T).to(torch.int32)  # (scatter_add_ here: 0.6 ms of atomics)
+    tile_draws = (tile_draws * live.unsqueeze(1).to(torch.int32)).contiguous()
+    d_ends = torch.cumsum(tile_draws.view(-1), 0, dtype=torch.int64)
+    sample_off = (d_ends - tile_draws.view(-1)).contiguous()
+    total = n * eps_sample  # upper bound; rows with S == 0 leave their slots unused
+    s_col = torch.full((total,), -1, dtype=torch.int32, device=dev)
+    s_onv = torch.empty((total, 8 * L), dtype=torch.uint8, device=dev)
+    s_h = torch.empty(total, dtype=h1e.dtype, device=dev)
+    scale = (S / eps_sample).contiguous()
+    if seed is None:
+        seed = int(torch.randint(0, 2**62, (1,)).item())
+    N.check(lib.pynqs_reduce_sample(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, eps_eff, tile_draws.data_ptr(),
+                                    sample_off.data_ptr(), scale.data_ptr(), seed, s_col.data_ptr(), s_onv.data_ptr(), s_h.data_ptr(), st),
+            "pynqs_reduce_sample")
+    # slot k belongs to the walker whose draws cover it
+    draws_per_row = tile_draws.sum(1, dtype=torch.int64)
+    slot_row = torch.repeat_interleave(torch.arange(n, device=dev), draws_per_row)
+    used = int(d_ends[-1].item()) if n else 0
+    valid = s_col[:used] >= 0
+    s_row = slot_row[valid]
+    s_counts = torch.zeros(n, dtype=torch.int64, device=dev).scatter_add_(0, s_row, torch.ones_like(s_row))
+    return (row, col, onv, h, counts), (s_row, s_col[:used][valid], s_onv[:used][valid], s_h[:used][valid], s_counts)
+
+
 def local_energy(
     x: Tensor, h1e: Tensor, h2e: Tensor, ansatz, ansatz_batch: Callable[..., Tensor], sorb: int, nele: int, noa: int, nob: int,
     dtype=torch.double, use_spin_raising: bool = False, h1e_spin: Optional[Tensor] = None, h2e_spin: Optional[Tensor] = None,
@@ -263,6 +329,32 @@ def local_energy(
                 eloc = torch.view_as_complex(torch.segment_reduce(torch.view_as_real(w).contiguous(), "sum", lengths=counts, unsafe=True))
             else:
                 eloc = torch.segment_reduce(w, "sum", lengths=counts, unsafe=True)
+            t3 = time.time_ns()
+            return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi_x, ((t2 - t0) / 1e6, 0.0, (t3 - t2) / 1e6)
+
+        # ---- fast path: semi-stochastic REDUCE (eps_sample > 0) with the selection done on chip ------------------------
+        if (FUSED and FUSED_SAMPLED and reduce_psi and not use_sample_space and eps_sample > 0
+                and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0 and x.is_cuda):
+            (row, col, onv, h, counts), (s_row, s_col, s_onv, s_w, s_counts) = reduce_compact_sampled(
+                x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample))
+            t2 = time.time_ns()
+            psi_all = Func(ansatz_f, torch.cat([onv, s_onv]), WF_LUT, use_unique).to(dtype)
+            psi, psi_s = psi_all[: onv.size(0)], psi_all[onv.size(0):]
+            # psi(x): column 0 among the kept records (every row keeps it unless |H_00| < eps, where the reference divides by 0 too),
+            # else among the drawn ones
+            psi_x = torch.zeros(batch, dtype=dtype, device=x.device)
+            first_s = s_col == 0
+            psi_x[s_row[first_s]] = psi_s[first_s]
+            first = col == 0
+            psi_x[row[first]] = psi[first]
+            rdt = _real_dtype(dtype)
+
+            def seg(wv, cnt):
+                if wv.is_complex():
+                    return torch.view_as_complex(torch.segment_reduce(torch.view_as_real(wv).contiguous(), "sum", lengths=cnt, unsafe=True))
+                return torch.segment_reduce(wv, "sum", lengths=cnt, unsafe=True)
+
+            eloc = seg((psi / psi_x[row]) * h.to(rdt), counts) + seg((psi_s / psi_x[s_row]) * s_w.to(rdt), s_counts)
             t3 = time.time_ns()
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi_x, ((t2 - t0) / 1e6, 0.0, (t3 - t2) / 1e6)
 

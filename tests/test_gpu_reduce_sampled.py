@@ -1,0 +1,108 @@
+"""Semi-stochastic REDUCE on chip (pynqs_reduce_count_sums / pynqs_reduce_sample, energy.reduce_compact_sampled) against
+the definition in vmc/energy/eloc.py:257-296: keep |H| >= eps; draw eps_sample columns from the rest with
+p_m = |H_m| / S; weight (hits / eps_sample) * sign(H_m) * S.  Structural checks are exact; the distribution is checked
+against the multinomial expectation with a 6-sigma bound (fixed seeds: deterministic test)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rand_occ, synth_integrals
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _setup(sorb, noA, noB, n, seed):
+    from pynqs_amd import C_extension as cx
+
+    h1, h2 = synth_integrals(sorb)
+    h1e, h2e = _dev(h1), _dev(h2)
+    x = cx.tensor_to_onv(_dev(rand_occ(n, sorb, noA, noB, seed=seed)), sorb)
+    comb, hm = cx.get_comb_hij_fused(x, h1e, h2e, sorb, noA + noB, noA, noB)
+    return x, h1e, h2e, comb, hm
+
+
+@pytest.mark.parametrize("sorb,noA,noB,eps", [(12, 3, 2, 0.2), (16, 4, 4, 0.35), (66, 3, 3, 0.3), (130, 2, 2, 0.25), (12, 3, 3, 0.0)])
+def test_records_follow_the_definition(sorb, noA, noB, eps):
+    from pynqs_amd import energy
+
+    n, N = 24, 4000
+    x, h1e, h2e, comb, hm = _setup(sorb, noA, noB, n, seed=sorb)
+    torch.manual_seed(1)
+    (row, col, onv, h, counts), (s_row, s_col, s_onv, s_w, s_counts) = energy.reduce_compact_sampled(
+        x, h1e, h2e, sorb, noA + noB, noA, noB, eps, N, seed=77)
+    keep = hm.abs() >= eps if eps > 0 else torch.zeros_like(hm, dtype=torch.bool)
+    # kept part: exactly the |H| >= eps set
+    got = torch.zeros_like(keep)
+    got[row, col.long()] = True
+    assert torch.equal(got, keep) and torch.equal(h, hm[row, col.long()]) and torch.equal(onv, comb[row, col.long()])
+    assert torch.equal(counts, keep.sum(1))
+    # drawn part: distinct sub-eps columns, right kets, right signs, hits add up to N per row
+    assert not keep[s_row, s_col.long()].any()
+    flat = s_row * hm.size(1) + s_col.long()
+    assert flat.unique().numel() == flat.numel()
+    assert torch.equal(s_onv, comb[s_row, s_col.long()])
+    S = torch.where(keep, torch.zeros_like(hm), hm.abs()).sum(1)
+    hits = (s_w.abs() * N / S[s_row])
+    assert torch.allclose(hits, hits.round(), atol=1e-6) and (hits.round() >= 1).all()
+    assert torch.equal(torch.sign(s_w), torch.sign(hm[s_row, s_col.long()]))
+    tot = torch.zeros(n, dtype=torch.float64, device=x.device).index_add_(0, s_row, hits.round())
+    assert torch.equal(tot, torch.full_like(tot, float(N)))
+    assert torch.equal(s_counts, torch.bincount(s_row, minlength=n))
+    # distribution: hits ~ Binomial(N, p_m) per column; pooled z-scores stay within 6 sigma
+    p = torch.where(keep, torch.zeros_like(hm), hm.abs()) / S[:, None]
+    emp = torch.zeros_like(hm)
+    emp[s_row, s_col.long()] = hits.round()
+    z = (emp - N * p) / torch.sqrt(N * p * (1 - p) + 1e-12)
+    sel = p > 5.0 / N
+    if bool(sel.any()):
+        assert float(z[sel].abs().max()) < 6.0
+        assert abs(float(z[sel].mean())) < 6.0 / np.sqrt(float(sel.sum()))
+    # pooled over blocks of 64 columns (also covers rows whose single columns are all rare)
+    nb = hm.size(1) // 64
+    if nb:
+        eb = emp[:, : nb * 64].reshape(n, nb, 64).sum(-1)
+        pb = p[:, : nb * 64].reshape(n, nb, 64).sum(-1)
+        zb = (eb - N * pb) / torch.sqrt(N * pb * (1 - pb) + 1e-12)
+        selb = pb > 5.0 / N
+        if bool(selb.any()):
+            assert float(zb[selb].abs().max()) < 6.0
+    # same seeds -> same records
+    torch.manual_seed(1)
+    again = energy.reduce_compact_sampled(x, h1e, h2e, sorb, noA + noB, noA, noB, eps, N, seed=77)
+    assert all(torch.equal(a, b) for a, b in zip(again[1], (s_row, s_col, s_onv, s_w, s_counts)))
+
+
+def test_local_energy_estimator_is_unbiased(fe2s2):
+    """local_energy(reduce_psi, eps = 1e-2, eps_sample = 1000) with the on-chip selection: the mean over repeated
+    draws approaches the exact (SIMPLE) local energy, and its spread matches the generic torch.multinomial path."""
+    from pynqs_amd import energy, public_function as pf
+    from pynqs_amd.rbm import RealRBM
+
+    d = golden("eloc_e2e_fe2s2.npz")
+    dev = torch.device("cuda")
+    torch.set_default_dtype(torch.float64)
+    try:
+        h1e, h2e = _dev(fe2s2["h1e"]), _dev(fe2s2["h2e"])
+        x = _dev(d["x"][:16])
+        rbm = RealRBM(torch.from_numpy(d["W"]), torch.from_numpy(d["hb"]), torch.from_numpy(d["vb"])).to(dev).double()
+        ab = lambda xx, func: pf.ansatz_batch(func, xx, 1_000_000, 40, dev, torch.double)
+        exact = torch.from_numpy(d["eloc_simple"][:16]).to(dev)
+        torch.manual_seed(5)
+        R = 60
+        runs = {}
+        for fused in (True, False):
+            energy.FUSED_SAMPLED = fused
+            runs[fused] = torch.stack([energy.local_energy(x, h1e, h2e, rbm, ab, 40, 30, 15, 15, reduce_psi=True, eps=1e-2, eps_sample=1000)[0]
+                                       for _ in range(R)])
+        energy.FUSED_SAMPLED = True
+        for fused in (True, False):
+            m, s = runs[fused].mean(0), runs[fused].std(0)
+            assert float(((m - exact).abs() / (s / np.sqrt(R) + 1e-12)).max()) < 5.0, fused
+        ratio = runs[True].std(0) / runs[False].std(0)
+        assert 0.6 < float(ratio.mean()) < 1.6
+    finally:
+        torch.set_default_dtype(torch.float32)
