@@ -284,6 +284,12 @@ static int launch_rs(const uint64_t *bra, int64_t nbatch, int sorb, int nele, in
     if (hipMemsetAsync(tile_sums, 0, 8 * (size_t)grid * max_tiles, st) != hipSuccess) return check_launch("memset");
   }
   DISPATCH_LEN(len, {
+    if (lds > 64 * 1024) {  // beyond the default dynamic LDS limit (large tables, sorb >~ 150)
+      const void *fn = dtype == PYNQS_F64 ? reinterpret_cast<const void *>(&reduce_sample_kernel<LEN, double, SAMPLE>)
+                                          : reinterpret_cast<const void *>(&reduce_sample_kernel<LEN, float, SAMPLE>);
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("hipFuncSetAttribute");
+    }
     if (dtype == PYNQS_F64)
       hipLaunchKernelGGL((reduce_sample_kernel<LEN, double, SAMPLE>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks,
                          chunk_len, max_tiles, (const double *)plan, eps, tile_counts, tile_sums, tile_draws, sample_off, walker_scale,

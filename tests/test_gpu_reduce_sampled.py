@@ -76,6 +76,25 @@ def test_records_follow_the_definition(sorb, noA, noB, eps):
     assert all(torch.equal(a, b) for a, b in zip(again[1], (s_row, s_col, s_onv, s_w, s_counts)))
 
 
+def test_large_tables_three_words():
+    """sorb 184 with 46 + 46 electrons: the walker tables alone take 50 KiB of LDS, with the draw buffers > 64 KiB
+    (needs the raised dynamic-LDS limit); 6.6 M columns per row cut into chunks over many workgroups."""
+    from pynqs_amd import energy
+
+    n, N, eps = 2, 3000, 0.4
+    x, h1e, h2e, comb, hm = _setup(184, 46, 46, n, seed=3)
+    torch.manual_seed(2)
+    (row, col, onv, h, counts), (s_row, s_col, s_onv, s_w, s_counts) = energy.reduce_compact_sampled(x, h1e, h2e, 184, 92, 46, 46, eps, N, seed=5)
+    keep = hm.abs() >= eps
+    assert torch.equal(counts, keep.sum(1))
+    assert not keep[s_row, s_col.long()].any() and torch.equal(s_onv, comb[s_row, s_col.long()])
+    S = torch.where(keep, torch.zeros_like(hm), hm.abs()).sum(1)
+    hits = (s_w.abs() * N / S[s_row]).round()
+    tot = torch.zeros(n, dtype=torch.float64, device=x.device).index_add_(0, s_row, hits)
+    assert torch.equal(tot, torch.full_like(tot, float(N)))
+    assert torch.equal(torch.sign(s_w), torch.sign(hm[s_row, s_col.long()]))
+
+
 def test_local_energy_estimator_is_unbiased(fe2s2):
     """local_energy(reduce_psi, eps = 1e-2, eps_sample = 1000) with the on-chip selection: the mean over repeated
     draws approaches the exact (SIMPLE) local energy, and its spread matches the generic torch.multinomial path."""
