@@ -10,12 +10,15 @@
 // (no overflow for any theta; the reference's psi(x')/psi(x) of two products over-/underflows first), so
 //   psi(x')/psi(x) = prod_{o in F} C(o) * prod_h (m_h + n_h prod_{o in F} q_h(o)),
 //   C(o) = exp(-2 x_o (a_o + sum_h s_h W[h][o])),  n_h = m_h rho_h.
-// Per walker the workgroup builds q[o][h] in LDS (one read of exp(+-4W) per element, no transcendental in the
+// Every excitation multiplies four rows (a single: its two orbitals and a dummy row twice), so the rows kept in
+// LDS are q'_h(o) = (m_h rho_h)^(1/4) q_h(o) and a factor is m_h + prod_{o in F} q'_h(o).
+// Per walker the workgroup builds q'[o][h] in LDS (one read of exp(+-4W) per element, no transcendental in the
 // inner loop) and C(o); then every lane owns a 4 x 4 block of excitations -- 4 entries of a class's "fast"
 // excitation table x 4 entries of its "slow" table (hole pairs x particle pairs, alpha singles x beta singles:
 // detcore.h) -- and runs over the hidden units with 16 running products in registers:
-//   per hidden unit and lane: 16 LDS reads, 12 multiplications for the 8 pair products, 16 x (fma + mul).
-// The kernel is bound by the f64 vector rate and the LDS read rate, not by HBM.
+//   per hidden unit and lane: 16 LDS reads, 8 multiplications for the 8 pair products, 16 x (fma + mul).
+// The kernel is bound by the f64 vector rate (84 % busy), not by HBM.  When sorb x
+// num_hidden does not fit the LDS the WINDOWED variant streams q' through it (see eloc_rbm_kernel).
 // Matrix elements come from the integral plan exactly as in kernels_plan.hip.
 #include "detcore.h"
 #include "launch.h"
@@ -73,7 +76,6 @@ static inline RbmBlocks make_rbm_blocks(const SDParams &p) {
 //   sh  [Hq]            s_h
 //   Cq  [sorb + 2]      C(o) by orbital, 1 for the dummy orbital `sorb`
 //   hs  [d1 + 2]        <x|H|x>, then the singles
-typedef double rbm_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const double lds_cdouble;  // read through a 32-bit LDS address
 
 struct RbmLds {
