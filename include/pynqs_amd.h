@@ -171,6 +171,9 @@ int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const doubl
  *   pynqs_weighted_moments  : workspace[0..3] (doubles) = sum_i p_i Re x_i, sum_i p_i Im x_i, sum_i p_i |x_i|^2,
  *                             sum_i p_i; x is double[n] or interleaved complex double[n][2]; fixed order of additions. */
 int64_t pynqs_moments_workspace(void);
+/* closing arithmetic of dist_stats.py:59-79 on the summed moments of all ranks (moments[0..3] as above, SUMMED over
+ * the ranks; inv_world = 1 / world_size as in comm.py:62-67): out5 = mean_re, mean_im, var, sd, se = sd / sqrt(counts). */
+int pynqs_stats_finish(const double *moments, double inv_world, double counts, double *out5, void *stream);
 int pynqs_weighted_moments(const double *x, int is_complex, const double *prob, int64_t n, void *workspace, void *stream);
 
 /* REDUCE method front end: vmc/energy/eloc.py:205-324 with eps_sample == 0 keeps the columns with

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pynqs_eloc_rbm": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp]),
     "pynqs_gfmc_sample": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "pynqs_moments_workspace": (_i64, []),
+    "pynqs_stats_finish": (_int, [_vp, _dbl, _dbl, _vp, _vp]),
     "pynqs_weighted_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),
     "pynqs_reduce_tiles": (_i64, [_i64, _int, _int, _int, _int]),
     "pynqs_reduce_count": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _vp, _vp]),

@@ -172,6 +172,23 @@ __global__ __launch_bounds__(kBlock) void moments_kernel(const double *__restric
 
 }  // namespace pynqs
 
+namespace pynqs {
+// mean, var = E|O|^2 - |E O|^2 (2 - sum p), sd, se from the (all-reduced) moments: one thread instead of ten torch launches
+__global__ void stats_finish_kernel(const double *__restrict__ m, double inv_world, double counts, double *__restrict__ out) {
+  const double re = m[0] * inv_world, im = m[1] * inv_world, m2 = m[2] * inv_world, ps = m[3] * inv_world;
+  double var = m2 - (re * re + im * im) * (2.0 - ps);
+  var = var > 0.0 ? var : 0.0;
+  const double sd = sqrt(var);
+  out[0] = re; out[1] = im; out[2] = var; out[3] = sd; out[4] = sd / sqrt(counts);
+}
+}  // namespace pynqs
+
+extern "C" int pynqs_stats_finish(const double *moments, double inv_world, double counts, double *out5, void *stream) {
+  if (!moments || !out5 || !(counts > 0.0)) return set_error(PYNQS_EINVAL, "bad arguments");
+  hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, moments, inv_world, counts, out5);
+  return check_launch("stats_finish");
+}
+
 extern "C" int64_t pynqs_moments_workspace(void) { return 8 * 4 * (pynqs::kMomentBlocks + 1) + 8; }
 
 extern "C" int pynqs_weighted_moments(const double *x, int is_complex, const double *prob, int64_t n, void *workspace, void *stream) {

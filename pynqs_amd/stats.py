@@ -69,6 +69,21 @@ def dist_stats_moments(x: Tensor, prob: Tensor, counts: Optional[int] = None, wo
     """dist_stats_onepass on the fused moments kernel: 1 kernel + 1 all-reduce of 4 doubles + the closing arithmetic.
     counts defaults to len(x) * world_size (equal shards), so no device-to-host copy is needed."""
     m = _moments(x, prob)
+    if counts is None:
+        counts = x.size(0) * get_world_size()
+    if m.is_cuda:
+        # sum over the ranks (no division here: the finishing kernel applies 1 / world_size), then ONE launch
+        import torch.distributed as dist
+
+        from . import _native as N
+
+        if get_world_size() > 1:
+            dist.all_reduce(m, dist.ReduceOp.SUM)
+        out = torch.empty(6, dtype=torch.float64, device=m.device)
+        N.check(N.lib().pynqs_stats_finish(m.data_ptr(), 1.0 / world_size, float(counts), out.data_ptr(),
+                                           torch.cuda.current_stream(m.device).cuda_stream), "pynqs_stats_finish")
+        mean = torch.view_as_complex(out[0:2]).reshape(()) if torch.is_complex(x) else out[0]
+        return mean, out[2], out[3], out[4]
     m = all_reduce_packed([m], world_size)[0]
     mean = torch.complex(m[0], m[1]) if torch.is_complex(x) else m[0]
     var = (m[2] - (m[0] * m[0] + m[1] * m[1]) * (2.0 - m[3])).clamp_min(0)
