@@ -130,3 +130,22 @@ def test_windowed_kernel_against_oracle(cx, sorb, noA, noB, H, n):
         assert torch.isinf(p).all()
     scale = max(1.0, float(np.abs(e_ref).max()))
     np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
+
+
+def test_end_to_end_vmc_lowers_the_energy():
+    """examples/vmc_rbm_exact_sampling.py: fused E_loc -> statistics kernel -> gradient -> Adam on a sorb-8 problem
+    with exact sampling: the variational energy must go down and stay above the exact ground state."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vmc_example", os.path.join(root, "examples", "vmc_rbm_exact_sampling.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        hist, e0 = mod.run(steps=80, log=lambda *_: None)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert hist[-1] < hist[0] - 0.05
+    assert min(hist) >= e0 - 1e-9
+    assert hist[-1] - e0 < 0.6 * (hist[0] - e0)
