@@ -214,18 +214,20 @@ __device__ __forceinline__ uint64_t hash_of(const uint64_t (&q)[LEN]) {
 // Bloom prefilter of the same keys (2 bits per key out of one hash), appended to the table: the fused sample-space
 // kernel copies it into LDS and asks it before every probe.  Most x' are not in the sample table (85 % for the
 // Fe2S2 CI space), and a probe drags a whole cache line through the vector L1 for 16 useful bytes -- the kernel
-// was bound by exactly that (TA busy 82 %).  About 4 filter bits per key, at most kFilterMaxBits (16 KiB of LDS):
+// was bound by exactly that (TA busy 82 %).  About 8 filter bits per key, at most kFilterMaxBits (16 KiB of LDS):
 // a larger filter costs more in LDS occupancy than its lower false-positive rate returns.
 constexpr uint32_t kFilterMaxBits = 1u << 17;
 
 inline uint32_t hash_filter_bits(int64_t nkeys) {  // host side
   if (nkeys <= 0) return 0;
-  // largest power of two <= 4 bits per key, at most kFilterMaxBits: measured on Fe2S2 (18496 keys, 8192 walkers):
-  // no filter 0.447 ms, 32 Kbit 0.362, 64 Kbit 0.336, 128 Kbit 0.352, 256 Kbit 0.544 (LDS occupancy)
+  // largest power of two <= 8 bits per key, at most kFilterMaxBits.  Measured on Fe2S2 (18496 keys, 8192 walkers) with
+  // the kernel's order-free singles/diagonal (no staging scratch in LDS): 2 / 4 / 8 / 16 bits per key -> 0.345 / 0.298 /
+  // 0.271 / 0.294 ms (false positives vs LDS occupancy); no filter 0.447 ms
   static const uint64_t maxbits = getenv("PYNQS_FILTER_BITS") ? strtoull(getenv("PYNQS_FILTER_BITS"), nullptr, 10) : kFilterMaxBits;
   if (maxbits == 0) return 0;
   uint64_t b = 1024;
-  while (2 * b <= 4ull * (uint64_t)nkeys && 2 * b <= maxbits) b <<= 1;
+  static const uint64_t per_key = getenv("PYNQS_FILTER_PER_KEY") ? strtoull(getenv("PYNQS_FILTER_PER_KEY"), nullptr, 10) : 8;
+  while (2 * b <= per_key * (uint64_t)nkeys && 2 * b <= maxbits) b <<= 1;
   return b >= (uint64_t)nkeys ? (uint32_t)b : 0u;  // below one bit per key it rejects too little
 }
 

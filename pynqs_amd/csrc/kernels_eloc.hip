@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   // the table's Bloom filter follows its slots in memory; its LDS copy follows the staging scratch
-  const uint32_t filt_off = (uint32_t)lds_bytes(p, sizeof(double));
+  const uint32_t filt_off = (uint32_t)((lds_bytes(p, 0) + 15) & ~(size_t)15);  // no staging scratch: order-free singles / diagonal
   if (HASH && fbits) {
     const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(keys + (uint64_t)nkeys * hash_slot_words(LEN));
     uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier: the filter copy is visible
   LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0,
                                    __builtin_amdgcn_groupstaticsize() + filt_off, HASH ? fbits : 0u};
-  visit_tiles<LEN, double>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+  visit_tiles<LEN, double, LookupSink<LEN, CPLX, HASH>, false>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
   double re = sink.re, im = sink.im;
   // fixed-order reduction: lanes (xor butterfly), then waves.  (Which tile a wave gets is dynamic, so the
   // order of the additions inside a lane, and with it the last bits of the sum, can vary from run to run.)
@@ -322,7 +322,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   uint32_t nchunks, chunk_len;
   plan_chunks(nbatch, p.nsd + 1, &nchunks, &chunk_len);
   const uint32_t fbits = hash ? hash_filter_bits(nkeys) : 0u;
-  const size_t lds = lds_bytes(p, sizeof(double)) + fbits / 8;
+  const size_t lds = ((lds_bytes(p, 0) + 15) & ~(size_t)15) + fbits / 8;
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;

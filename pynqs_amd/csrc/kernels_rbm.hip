@@ -98,40 +98,6 @@ __host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayo
 
 __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o >> 1) + ((o & 1u) ? K : 0u); }
 
-// <x|H|x> and the singles' matrix elements for THIS kernel.  The drop-in kernels add these terms in the reference's
-// order, one lane per sum and staged through LDS, to be bit-identical (plan_dev.h); here E_loc is a sum of ~ncomb
-// rounded products anyway (tolerance 1e-8 Ha), so the terms are added in whatever order is cheapest:
-//   diagonal: lane a adds h(p_a,p_a) + sum_{b<a} <p_a p_b||p_a p_b>, then a butterfly over the wave;
-//   singles : one lane per single walks its S2 row over the occupied orbitals (its 2-3 cache lines stay in L1).
-__device__ __forceinline__ double rbm_diag(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, const double *__restrict__ plan) {
-  const int lane = threadIdx.x & 63;
-  const double *__restrict__ D1 = plan + pl.offD1;
-  const double *__restrict__ D2 = plan + pl.offD2;
-  double acc = 0.0;
-  for (int a = lane; a < p.nele; a += 64) {
-    const uint32_t pa = L.occa[a];
-    acc += D1[pa];
-    const double *__restrict__ row = D2 + pa * (uint32_t)p.sorb;
-#pragma unroll 4
-    for (int b = 0; b < a; ++b) acc += row[L.occa[b]];
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
-  return acc;
-}
-
-__device__ __forceinline__ void rbm_singles(uint32_t r, const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
-                                            const double *__restrict__ plan, double *__restrict__ hs) {
-  if (r >= p.d1) return;
-  const uint32_t e = L.tab[p.offSa + r], K = (uint32_t)pl.K;
-  const uint32_t pq = ((r >= p.d0 ? K : 0u) + ((e & 0xff) >> 1)) * K + (((e >> 8) & 0xff) >> 1);
-  const double *__restrict__ row = plan + pl.offS2 + (size_t)pq * p.sorb;
-  double acc = plan[pl.offS1 + pq];
-#pragma unroll 8
-  for (int j = 0; j < nocc; ++j) acc += row[L.occv[j]];
-  hs[1 + r] = ((e >> 16) & 1u) ? -acc : acc;
-}
-
 // WINDOWED = false: all hidden units of q' live in LDS, waves pull tiles from a counter (the fast kernel).
 // WINDOWED = true : sorb x num_hidden does not fit: the workgroup streams q' through LDS `hw` hidden units at a time;
 //                   in every round each wave holds the 16 x 64 running products of ONE tile in registers across the
@@ -186,7 +152,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   const int kThetaThreads = nthreads - 64;
   if (wave == nwaves - 1) {
     if (need_hs) {
-      const double hii = rbm_diag(p, pl, L, plan);
+      const double hii = fast_diag<double>(p, pl, L, plan);
       if (lane == 0) R.hs[0] = hii;
     }
   } else {
@@ -215,7 +181,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
       if (lane == 0) t = atomicAdd(next_single_p, 1u);
       t = __builtin_amdgcn_readfirstlane(t);
       if (t >= nst) break;
-      rbm_singles(t * 64 + lane, p, pl, L, nocc, plan, R.hs);
+      if (t * 64 + lane < p.d1) R.hs[1 + t * 64 + lane] = fast_single<double>(t * 64 + lane, p, pl, L, nocc, plan);
     }
   }
   __syncthreads();

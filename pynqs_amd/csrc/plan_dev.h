@@ -162,6 +162,42 @@ __device__ __forceinline__ void singles_tile(uint32_t r0, uint32_t r_end, const 
   }
 }
 
+// ---- order-free variants -----------------------------------------------------------------------------------
+// For kernels whose result is a rounded sum over all columns anyway (fused local energies, tolerance 1e-8 Ha): the
+// terms of <x|H|x> and of a single are added in whatever order is cheapest, no LDS staging:
+//   fast_diag  : lane a adds h(p_a,p_a) + sum_{b<a} <p_a p_b||p_a p_b>, then a butterfly over the wave (all lanes get it);
+//   fast_single: one lane walks the single's S2 row over the occupied orbitals (its 2-3 cache lines stay in L1).
+template <typename T>
+__device__ __forceinline__ T fast_diag(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, const T *__restrict__ plan) {
+  const int lane = threadIdx.x & 63;
+  const T *__restrict__ D1 = plan + pl.offD1;
+  const T *__restrict__ D2 = plan + pl.offD2;
+  T acc = T(0);
+  for (int a = lane; a < p.nele; a += 64) {
+    const uint32_t pa = L.occa[a];
+    acc += D1[pa];
+    const T *__restrict__ row = D2 + pa * (uint32_t)p.sorb;
+#pragma unroll 4
+    for (int b = 0; b < a; ++b) acc += row[L.occa[b]];
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  return acc;
+}
+
+// single excitation rank r < d1 (signed matrix element)
+template <typename T>
+__device__ __forceinline__ T fast_single(uint32_t r, const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
+                                         const T *__restrict__ plan) {
+  const uint32_t e = L.tab[p.offSa + r], K = (uint32_t)pl.K;
+  const uint32_t pq = ((r >= p.d0 ? K : 0u) + ((e & 0xff) >> 1)) * K + (((e >> 8) & 0xff) >> 1);
+  const T *__restrict__ row = plan + pl.offS2 + (size_t)pq * p.sorb;
+  T acc = plan[pl.offS1 + pq];
+#pragma unroll 8
+  for (int j = 0; j < nocc; ++j) acc += row[L.occv[j]];
+  return ((e >> 16) & 1u) ? -acc : acc;
+}
+
 // ---- doubles ----------------------------------------------------------------------------------------------
 // A double excitation whose table element has been requested: the two LDS table entries and the value.
 // For single-word ONVs (LEN == 1) the ket comes from the LDS mask tables (detcore.h: msk): k0 ^ k1.

@@ -84,7 +84,13 @@ __host__ __device__ inline uint32_t max_tiles_per_chunk(const SDParams &p, uint3
   return 1 + (tS_all + nchunks - 1) / nchunks + chunk_len / (128u * PYNQS_U) + 4;
 }
 
-template <int LEN, typename T, typename Sink>
+// EXACT = true : <x|H|x> and the singles are summed in the reference's order (bit-identical values; needs the LDS
+//                staging scratch of lds_bytes(p, sizeof(T))).
+// EXACT = false: order-free sums (plan_dev.h: fast_diag / fast_single), no scratch (lds_bytes(p, 0)), 64 singles per
+//                tile: for sinks that only accumulate a rounded sum over all columns (fused local energies).
+constexpr int kSinglesPerFastTile = 64;
+
+template <int LEN, typename T, typename Sink, bool EXACT = true>
 __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
                                             uint32_t chunk_len, uint32_t odd_base, uint32_t *next_tile, Sink &sink) {
@@ -104,7 +110,8 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
   const uint32_t tA = (gA.npairs + kSlots - 1) / kSlots, tB = (gB.npairs + kSlots - 1) / kSlots, tO = (gO.npairs + kSlots - 1) / kSlots;
   // The singles tiles of the walker are dealt round-robin to its workgroups (they cost far more per column
   // than doubles; left to the first chunk they would make it the straggler when rows are cut into many chunks).
-  const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+  constexpr uint32_t kSPT = EXACT ? kSinglesPerTile : kSinglesPerFastTile;
+  const uint32_t tS_all = (p.d1 + kSPT - 1) / kSPT;
   const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
   const uint32_t ntiles = 1 + tS + tA + tB + tO;
   const T *__restrict__ Vss = plan + pl.offVss;
@@ -140,25 +147,49 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
         }
       }
       if (lo == 0) {
-        diag_wave<T>(p, pl, L, plan, [&](T v) {
-          uint64_t ket[LEN];
+        if constexpr (EXACT) {
+          diag_wave<T>(p, pl, L, plan, [&](T v) {
+            uint64_t ket[LEN];
 #pragma unroll
-          for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
-          sink.one(0u, v, ket);
-        });
+            for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+            sink.one(0u, v, ket);
+          });
+        } else {
+          const T v = fast_diag<T>(p, pl, L, plan);
+          if (lane == 0) {
+            uint64_t ket[LEN];
+#pragma unroll
+            for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+            sink.one(0u, v, ket);
+          }
+        }
       }
       continue;
     }
     if (tile <= tS) {
-      const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSinglesPerTile;
-      singles_tile<T>(r0, min(r0 + kSinglesPerTile, p.d1), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
-        uint64_t ket[LEN];
+      const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSPT;
+      if constexpr (EXACT) {
+        singles_tile<T>(r0, min(r0 + kSPT, p.d1), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
+          uint64_t ket[LEN];
 #pragma unroll
-        for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
-        toggle<LEN>(ket, e & 0xff);
-        toggle<LEN>(ket, (e >> 8) & 0xff);
-        sink.one(r + 1, v, ket);
-      });
+          for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+          toggle<LEN>(ket, e & 0xff);
+          toggle<LEN>(ket, (e >> 8) & 0xff);
+          sink.one(r + 1, v, ket);
+        });
+      } else {
+        const uint32_t r = r0 + lane;
+        if (r < p.d1) {
+          const T v = fast_single<T>(r, p, pl, L, nocc, plan);
+          const uint32_t e = L.tab[p.offSa + r];
+          uint64_t ket[LEN];
+#pragma unroll
+          for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+          toggle<LEN>(ket, e & 0xff);
+          toggle<LEN>(ket, (e >> 8) & 0xff);
+          sink.one(r + 1, v, ket);
+        }
+      }
       continue;
     }
     tile -= 1 + tS;
