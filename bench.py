@@ -14,6 +14,12 @@ Workloads (config.workload):
   fe2s2_dropin   get_comb_hij_fused on the shipped Fe2S2 problem (sorb 40, 15a15b, ncomb 7876):
                  comb + Hmat materialised exactly like the reference API (HBM-write bound).
   syn<sorb>_dropin  same on synthetic dense integrals, sorb in {56, 120, 184}.
+  fe2s2_eloc_sample_space   complete SAMPLE_SPACE local energies in one kernel (hash-table psi) + statistics
+                 kernel + packed all-reduce.
+  fe2s2_eloc_rbm / syn<sorb>_eloc_rbm   complete SIMPLE local energies with a real RBM (alpha = 2) evaluated inside the
+                 kernel; the RBM table is rebuilt every step (parameters change every optimisation step).
+With the default workload and N = 1 the line also carries `extra`: the fused workloads above, the larger systems, the
+REDUCE compaction throughput and the generic PyTorch-module paths, each measured in the same run.
 Inputs are resident in HBM before the timed region.  Nothing here reads /root/reference.
 """
 from __future__ import annotations
