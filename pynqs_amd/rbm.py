@@ -17,6 +17,9 @@ class RealRBM(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         x = x.to(self.weights.dtype)
-        ax = torch.mv(x, self.visible_bias).exp()
-        amp = (2 * (torch.mm(x, self.weights.T) + self.hidden_bias).cosh()).prod(-1)
-        return ax * amp
+        # one GEMM for theta and a.x (the reference calls mv + mm, rbm.py:186-211; rocBLAS' gemv on [M, sorb] costs a
+        # third of this forward for M ~ 1e6 rows)
+        wext = torch.cat([self.weights, self.visible_bias.unsqueeze(0)], 0)
+        bext = torch.cat([self.hidden_bias, self.hidden_bias.new_zeros(1)])
+        z = torch.addmm(bext, x, wext.T)
+        return z[:, -1].exp() * (2 * z[:, :-1].cosh()).prod(-1)
