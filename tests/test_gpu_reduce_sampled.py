@@ -125,3 +125,28 @@ def test_local_energy_estimator_is_unbiased(fe2s2):
         assert 0.6 < float(ratio.mean()) < 1.6
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_float32_integrals():
+    """The reference dispatches on the integral dtype (cpu_tensor.cpp:249): float32 integrals give float32 matrix
+    elements; the compaction and the draws must follow the float32 values."""
+    from pynqs_amd import C_extension as cx, energy
+
+    sorb, noA, noB, n, N, eps = 16, 4, 3, 12, 2000, 0.3
+    h1, h2 = synth_integrals(sorb)
+    h1e, h2e = _dev(h1.astype(np.float32)), _dev(h2.astype(np.float32))
+    x = cx.tensor_to_onv(_dev(rand_occ(n, sorb, noA, noB, seed=21)), sorb)
+    comb, hm = cx.get_comb_hij_fused(x, h1e, h2e, sorb, noA + noB, noA, noB)
+    assert hm.dtype == torch.float32
+    row, col, onv, h, counts = energy.reduce_compact(x, h1e, h2e, sorb, noA + noB, noA, noB, eps, sort=True)
+    keep = hm.abs() >= eps
+    r2, c2 = torch.where(keep)
+    assert torch.equal(row, r2) and torch.equal(col.long(), c2) and torch.equal(h, hm[keep]) and h.dtype == torch.float32
+    torch.manual_seed(4)
+    _, (s_row, s_col, s_onv, s_w, s_counts) = energy.reduce_compact_sampled(x, h1e, h2e, sorb, noA + noB, noA, noB, eps, N, seed=9)
+    assert s_w.dtype == torch.float32 and not keep[s_row, s_col.long()].any()
+    S = torch.where(keep, torch.zeros_like(hm), hm.abs()).double().sum(1)
+    hits = (s_w.double().abs() * N / S[s_row]).round()
+    tot = torch.zeros(n, dtype=torch.float64, device=x.device).index_add_(0, s_row, hits)
+    assert torch.equal(tot, torch.full_like(tot, float(N)))
+    assert torch.equal(torch.sign(s_w), torch.sign(hm[s_row, s_col.long()]))
