@@ -401,8 +401,10 @@ def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    # a step of the headline workload takes 0.2-0.25 ms: 2000 steps = half a second of measurement.  (With 50 steps the GPU
+    # is still ramping up: 0.243 ms per step against 0.208 ms sustained.)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="fe2s2_dropin")
     ap.add_argument("--walkers", type=int, default=8192, help="walkers per GPU")
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
@@ -461,8 +463,13 @@ def main():
         pmc = os.path.join(ROOT, "profiles", f"pmc_{w.name}.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        return {"bound": "hbm", "kernel": w.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": w.bytes_per_walker * w.n}
+        out = {"bound": "hbm", "kernel": w.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+               "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": w.bytes_per_walker * w.n}
+        if traffic:
+            # the algorithmic bytes count every integral gather once; for Fe2S2 they are served by the L2, so the
+            # fraction can pass 1.  What actually crossed the HBM interface, against the same 8 TB/s:
+            out["hbm_traffic_frac"] = traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        return out
 
     el, kern_ms = timed(wl, args.warmup, args.steps)
 
@@ -494,11 +501,11 @@ def main():
     # secondary measurements (same run, N = 1 only): the complete fused local energy and the larger word counts
     if world == 1 and not args.no_extra and args.workload == "fe2s2_dropin":
         extra = {}
-        for name, nw, steps in (("fe2s2_eloc_sample_space", args.walkers, 20), ("fe2s2_eloc_rbm", args.walkers, 20),
-                                ("syn56_eloc_rbm", 4096, 10), ("syn120_dropin", 64, 10), ("syn184_dropin", 16, 5)):
+        for name, nw, steps in (("fe2s2_eloc_sample_space", args.walkers, 1000), ("fe2s2_eloc_rbm", args.walkers, 500),
+                                ("syn56_eloc_rbm", 4096, 200), ("syn120_dropin", 64, 500), ("syn184_dropin", 16, 200)):
             try:
                 w2 = make_workload(name, nw, rank, dev, args.path)
-                el2, k2 = timed(w2, 2, steps)
+                el2, k2 = timed(w2, max(2, steps // 10), steps)
                 ok2, d2 = w2.parity_gate()
                 extra[w2.name] = {"value": w2.n * steps / el2, "unit": "local energies/s", "walkers": w2.n, "ncomb": w2.ncomb,
                                   "ms_per_step": el2 / steps * 1e3, "roofline": roofline(w2, k2),
