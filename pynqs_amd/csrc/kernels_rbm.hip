@@ -113,13 +113,12 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   double *red = reinterpret_cast<double *>(smem + lds_bytes_rbm(p, rl, hw) - 48);  // [kBlock / 64]
   uint32_t *next_tile_p = reinterpret_cast<uint32_t *>(red + kBlock / 64);
   uint32_t *next_single_p = next_tile_p + 1;
-#define next_tile (*next_tile_p)
   const uint64_t wg = blockIdx.x;
   const uint64_t walker = wg / nchunks;
   const uint32_t chunk = (uint32_t)(wg - walker * nchunks);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthreads = blockDim.x, nwaves = nthreads >> 6;  // 3 or 4 waves: whichever divides the walker's tiles better
-  if (tid == 0) { next_tile = 0; *next_single_p = 0; }
+  if (tid == 0) { *next_tile_p = 0; *next_single_p = 0; }
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
       if (round >= nrounds) break;       // workgroup-uniform: the windows below contain barriers
       lt = round * nwaves + wave;        // >= my_tiles: a wave without a tile still helps to build the windows
     } else {
-      if (lane == 0) lt = atomicAdd(&next_tile, 1u);
+      if (lane == 0) lt = atomicAdd(next_tile_p, 1u);
       lt = __builtin_amdgcn_readfirstlane(lt);
       if (lt >= my_tiles) break;
     }
@@ -445,7 +444,6 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
   }
 }
 
-#undef next_tile
 }  // namespace pynqs
 
 // =================================================================================================
