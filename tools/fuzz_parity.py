@@ -1,0 +1,75 @@
+"""Randomised differential test of the HIP kernels against the CPU oracle: random (sorb, noA, noB, batch, dtype) for the
+drop-in kernel (bit-exact), the fused sample-space and RBM local energies (1e-8 Ha scaled) and the REDUCE compaction.
+usage: python tools/fuzz_parity.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O
+from pynqs_amd import C_extension as cx, energy, public_function as pf
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = torch.device("cuda")
+G = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def integrals(sorb):
+    h1 = rng.random((sorb, sorb)) - 0.5
+    h1 = (h1 + h1.T).reshape(-1)
+    pair = sorb * (sorb - 1) // 2
+    return h1, rng.random(pair * (pair + 1) // 2) - 0.5
+
+
+def walkers(n, sorb, noA, noB):
+    occ = np.zeros((n, sorb), dtype=np.uint8)
+    for i in range(n):
+        occ[i, 2 * rng.permutation(sorb // 2)[:noA]] = 1
+        occ[i, 2 * rng.permutation(sorb // 2)[:noB] + 1] = 1
+    return O.pm01_to_onv(occ, sorb)
+
+
+t0, cases = time.time(), 0
+while time.time() - t0 < budget:
+    sorb = int(rng.choice([4, 6, 8, 10, 12, 14, 16, 20, 24, 30, 36, 40, 66, 70, 130]))
+    K = sorb // 2
+    big = sorb > 40
+    noA = int(rng.integers(0, min(K, 4 if big else K) + 1)); noB = int(rng.integers(0, min(K, 4 if big else K) + 1))
+    if noA + noB == 0:
+        continue
+    n = int(rng.choice([1, 2, 3, 7, 33, 100])) if not big else int(rng.choice([1, 2, 5]))
+    h1, h2 = integrals(sorb)
+    x = walkers(n, sorb, noA, noB)
+    nele = noA + noB
+    for dt in (np.float32, np.float64):  # float64 last: ho / hm are reused below
+        co, ho = O.comb_hij_fused(x, h1.astype(dt), h2.astype(dt), sorb, nele, noA, noB)
+        comb, hm = cx.get_comb_hij_fused(G(x), G(h1.astype(dt)), G(h2.astype(dt)), sorb, nele, noA, noB)
+        assert np.array_equal(comb.cpu().numpy(), co) and np.array_equal(hm.cpu().numpy(), ho), ("dropin", sorb, noA, noB, n, dt)
+    h1e, h2e = G(h1), G(h2)
+    scale = max(1.0, float(np.abs(ho).sum(1).max()))
+    # REDUCE compaction == thresholded materialised row
+    eps = float(rng.choice([0.0, 0.1, 0.3, 0.6]))
+    row, col, onv, h, counts = energy.reduce_compact(G(x), h1e, h2e, sorb, nele, noA, noB, eps, sort=True)
+    keep = torch.from_numpy(np.abs(ho) >= eps).to(dev)
+    r2, c2 = torch.where(keep)
+    assert torch.equal(row, r2) and torch.equal(col.long(), c2) and torch.equal(h, hm[keep]), ("reduce", sorb, noA, noB, n, eps)
+    # fused RBM local energy
+    H = int(rng.choice([1, 3, 8, 17, 40]))
+    W = 0.2 * (rng.random((H, sorb)) - 0.5); hb = 2.0 * (rng.random(H) - 0.5); vb = 0.3 * (rng.random(sorb) - 0.5)
+    e_ref, p_ref = O.eloc_simple_rbm(x, h1, h2, sorb, nele, noA, noB, W, hb, vb)
+    e, p = cx.eloc_rbm(G(x), h1e, h2e, cx.RBMTable(G(W), G(hb), G(vb)), sorb, nele, noA, noB)
+    assert np.allclose(p.cpu().numpy(), p_ref, rtol=1e-10, atol=0), ("rbm psi", sorb, noA, noB, n, H)
+    assert np.abs(e.cpu().numpy() - e_ref).max() <= 1e-8 * max(1.0, np.abs(e_ref).max(), scale), ("rbm eloc", sorb, noA, noB, n, H)
+    # fused sample-space local energy: table = a random half of the connected determinants of walker 0 plus all walkers
+    flat = np.unique(np.concatenate([co[0][rng.random(co.shape[1]) < 0.5], x]), axis=0)
+    order = O.sort_keys(flat, sorb) if hasattr(O, "sort_keys") else None
+    keys = flat[order] if order is not None else flat
+    wf = rng.random(keys.shape[0]) + 0.1
+    lut = pf.WavefunctionLUT(G(keys), G(wf), sorb, device=dev)
+    el, _, psi0, _ = energy.local_energy(G(x), h1e, h2e, None, None, sorb, nele, noA, noB, WF_LUT=lut, use_sample_space=True)
+    ks = lut.bra_key.cpu().numpy(); ws = lut.wf_value.cpu().numpy()
+    e2, p2 = O.eloc_sample_space(x, h1, h2, sorb, nele, noA, noB, ks, ws)
+    assert np.array_equal(psi0.cpu().numpy(), p2), ("ss psi0", sorb, noA, noB, n)
+    assert np.abs(el.cpu().numpy() - e2).max() <= 1e-8 * max(1.0, np.abs(e2).max(), scale), ("ss eloc", sorb, noA, noB, n)
+    cases += 1
+print(f"fuzz ok: {cases} random systems in {time.time() - t0:.0f} s")
