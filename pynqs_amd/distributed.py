@@ -78,3 +78,21 @@ def shard_bounds(n: int, world_size: int, rank: int):
     k, res = divmod(n, world_size)
     begin = rank * k + min(rank, res)
     return begin, begin + k + (1 if rank < res else 0)
+
+
+def all_gather_varlen(t: Tensor) -> Tensor:
+    """Concatenation over the ranks (rank order) of tensors whose first dimension may differ from rank to rank
+    (walker shards differ by at most one, shard_bounds): sizes first, then one padded all-gather.  The reference
+    gathers to rank 0 and scatters back (comm.py:76-131); every rank keeping the whole array removes that round trip."""
+    ws = get_world_size()
+    if ws == 1:
+        return t
+    n = torch.tensor([t.size(0)], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(ws)]
+    dist.all_gather(sizes, n)
+    sizes = [int(v.item()) for v in sizes]
+    m = max(sizes)
+    pad = t if t.size(0) == m else torch.cat([t, t.new_zeros((m - t.size(0),) + tuple(t.shape[1:]))])
+    parts = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(parts, pad.contiguous())
+    return torch.cat([q[:k] for q, k in zip(parts, sizes)])

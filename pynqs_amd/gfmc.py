@@ -14,6 +14,7 @@ import torch
 from torch import Tensor
 
 from .C_extension import get_comb_hij_fused
+from .distributed import all_gather_varlen, get_rank, get_world_size
 from .energy import Func
 from .public_function import WavefunctionLUT
 
@@ -80,3 +81,30 @@ def sample_update(x: Tensor, weight: Tensor, comb_x: Tensor, green_kernel: Tenso
     weight_new = weight * beta.squeeze()
     accept_nums = index.nonzero().size(0)
     return x_new, weight_new, beta, accept_nums
+
+
+def branching(x: Tensor, weight: Tensor, xi: Optional[Tensor] = None) -> Tensor:
+    """gfmc/walker.py:340-408: stochastic reconfiguration (comb resampling) of the walkers of ALL ranks by weight.
+    Output slot k (global numbering, this rank owns `x.size(0)` consecutive ones) takes the walker whose interval of
+    the global cumulative weight contains (k + xi_k) / N_total.  Same arithmetic as the reference (per-rank cumsum +
+    offset of the previous ranks, clamped at 1); instead of gathering everything on rank 0 and scattering the
+    result, every rank all-gathers the cumulative weights and the walkers (N_total * (8 + 8 * len) bytes) and picks
+    its own slots -- one exchange step, no rank-0 serialisation.  xi: uniforms for this rank's slots (default torch.rand)."""
+    ws, rank = get_world_size(), get_rank()
+    dev = x.device
+    batch = x.size(0)
+    w_sums = all_gather_varlen(weight.sum(0, keepdim=True)).cumsum(0)  # cumulative weight of ranks 0..r
+    sizes = all_gather_varlen(torch.tensor([batch], dtype=torch.int64, device=dev)).cumsum(0)
+    # walkers on the ranks in front.  (The reference writes x_size_all[rank] - x_size_all[0], walker.py:369, which is the
+    # same number only when all shards have the same size; with shards that differ by one it repeats / drops a slot.)
+    offset = sizes[rank] - batch
+    if xi is None:
+        xi = torch.rand(batch, device=dev)
+    rand_prob = (torch.arange(batch, device=dev) + offset + xi) / sizes[-1]
+    pre = 0 if rank == 0 else w_sums[rank - 1]
+    cum_prob = (weight / w_sums[-1]).cumsum(0) + pre / w_sums[-1]
+    cum_prob.clamp_(max=1.0)
+    x_all = all_gather_varlen(x)
+    cum_all = all_gather_varlen(cum_prob)
+    index = torch.searchsorted(cum_all, rand_prob.to(cum_all.dtype), right=False).reshape(-1).clamp_(max=x_all.size(0) - 1)
+    return x_all[index]

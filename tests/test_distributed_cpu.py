@@ -103,3 +103,73 @@ def test_shard_bounds():
     parts = [shard_bounds(11, 3, r) for r in range(3)]
     assert parts == [(0, 4), (4, 8), (8, 11)]  # first n % ws ranks get one more (comm.py:108-111)
     assert [shard_bounds(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def _branch_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pynqs_amd import distributed as D, gfmc
+
+        g = torch.Generator().manual_seed(42)
+        n = 11  # uneven shards: 6 + 5
+        x_all = torch.randint(0, 256, (n, 16), generator=g, dtype=torch.uint8)
+        w_all = torch.rand(n, generator=g, dtype=torch.float64) + 0.05
+        xi_all = torch.rand(n, generator=g, dtype=torch.float64)
+        b, e = D.shard_bounds(n, world, rank)
+        x_new = gfmc.branching(x_all[b:e].contiguous(), w_all[b:e].contiguous(), xi_all[b:e].contiguous())
+        gathered = D.all_gather_varlen(torch.arange(b, e))
+        q.put((rank, x_new.numpy(), gathered.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gfmc_branching_world_size_two():
+    """gfmc/walker.py:340-408 (comb resampling over all ranks): the all-gather form on 2 ranks with uneven shards must pick
+    the walkers the reference's gather -> rank 0 -> scatter form picks (emulated here in one process)."""
+    world, n = 2, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_branch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _q
+
+    out = []
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=5))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: see its traceback above"
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    g = torch.Generator().manual_seed(42)
+    x_all = torch.randint(0, 256, (n, 16), generator=g, dtype=torch.uint8)
+    w_all = torch.rand(n, generator=g, dtype=torch.float64) + 0.05
+    xi_all = torch.rand(n, generator=g, dtype=torch.float64)
+    # the reference's arithmetic: per-rank cumsum + offset of the previous ranks, clamped; then one searchsorted
+    from pynqs_amd.distributed import shard_bounds
+
+    cums, tot, pre = [], w_all.sum(), 0.0
+    w_rank = []
+    for r in range(world):
+        b, e = shard_bounds(n, world, r)
+        w_rank.append(w_all[b:e].sum())
+    w_cum = torch.stack(w_rank).cumsum(0)
+    for r in range(world):
+        b, e = shard_bounds(n, world, r)
+        pre = 0 if r == 0 else w_cum[r - 1]
+        cums.append(((w_all[b:e] / w_cum[-1]).cumsum(0) + pre / w_cum[-1]).clamp(max=1.0))
+    cum = torch.cat(cums)
+    rand_prob = (torch.arange(n) + xi_all) / n
+    idx = torch.searchsorted(cum, rand_prob, right=False).clamp(max=n - 1)
+    want = x_all[idx].numpy()
+    got = np.concatenate([o[1] for o in out])
+    assert np.array_equal(got, want)
+    for o in out:
+        assert np.array_equal(o[2], np.arange(n))  # all_gather_varlen keeps the rank order with uneven shards
