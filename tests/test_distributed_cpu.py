@@ -173,3 +173,79 @@ def test_gfmc_branching_world_size_two():
     assert np.array_equal(got, want)
     for o in out:
         assert np.array_equal(o[2], np.arange(n))  # all_gather_varlen keeps the rank order with uneven shards
+
+
+def _merge_worker(rank, world, port, q, same_tree):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pynqs_amd import sample_comm
+
+        onv, cnt, wf = _merge_inputs(rank, same_tree)
+        u, _, p, lut, mc = sample_comm.gather_scatter_sample(onv, cnt, wf, 40, use_LUT=True, use_same_tree=same_tree, is_onv=True)
+        q.put((rank, u.numpy(), p.numpy(), lut.bra_key.numpy(), lut.wf_value.numpy(), mc.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _merge_inputs(rank, same_tree):
+    g = torch.Generator().manual_seed(5)
+    pool = torch.randint(0, 256, (9, 8), generator=g, dtype=torch.uint8)
+    pool[:, 5:] = 0  # 40 orbitals
+    psi = torch.rand(9, generator=g, dtype=torch.float64) + 0.1
+    sel = ([0, 1, 2, 3, 4], [5, 6, 7, 8]) if same_tree else ([0, 1, 2, 3, 4], [3, 4, 5, 6])  # second case: two shared determinants
+    cnt = (torch.arange(1, 6), torch.arange(10, 14)) if same_tree else (torch.arange(1, 6), torch.tensor([7, 8, 9, 10]))
+    i = sel[rank]
+    return pool[i].contiguous(), cnt[rank].to(torch.int64), psi[i].contiguous()
+
+
+@pytest.mark.parametrize("same_tree", [True, False])
+def test_sampler_merge_world_size_two(same_tree):
+    """Sampler.gather_scatter_sample (vmc/sample.py:627-772) as all-gather + local merge on 2 ranks: the shards, the
+    probabilities (x world_size) and the look-up table must be those of the reference's gather -> merge on rank 0 ->
+    scatter protocol (emulated in one process)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q, same_tree)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _q
+
+    out = []
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=5))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: see its traceback above"
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    ins = [_merge_inputs(r, same_tree) for r in range(world)]
+    onv_all, cnt_all, wf_all = (torch.cat([t[k] for t in ins]) for k in range(3))
+    if same_tree:
+        mu, mc, wfu = onv_all, cnt_all, wf_all
+    else:
+        mu, inv, cts = torch.unique(onv_all, dim=0, sorted=True, return_inverse=True, return_counts=True)
+        first = inv.argsort(stable=True)[torch.cat((cts.new_zeros(1), cts.cumsum(0)))[:-1]]
+        wfu = wf_all[first]
+        mc = torch.zeros(mu.size(0), dtype=torch.int64).index_add_(0, inv, cnt_all)
+    prob = mc / mc.sum()
+    k, res = divmod(mu.size(0), world)
+    start = 0
+    for r in range(world):
+        size = k + (1 if r < res else 0)
+        assert np.array_equal(out[r][1], mu[start:start + size].numpy())
+        np.testing.assert_allclose(out[r][2], (prob[start:start + size] * world).numpy(), rtol=1e-15)
+        assert np.array_equal(out[r][5], mc.numpy())
+        start += size
+        # the table holds all merged determinants with their amplitudes (sorted inside WavefunctionLUT)
+        keys = out[r][3]; vals = out[r][4]
+        lookup = {bytes(kk): float(v) for kk, v in zip(keys, vals)}
+        assert len(lookup) == mu.size(0)
+        for kk, v in zip(mu.numpy(), wfu.numpy()):
+            assert lookup[bytes(kk)] == float(v)
