@@ -4,7 +4,6 @@ sit on the path: SURVEY.md 8a rows a3, a16).  Same names and argument meaning as
 """
 from __future__ import annotations
 
-from functools import partial
 from typing import Callable, List, Optional, Tuple
 
 import numpy as np
@@ -20,53 +19,53 @@ USE_HASH = True  # WavefunctionLUT keeps a GPU hash table next to the sorted key
 
 def check_para(bra: Tensor) -> None:
     """utils/public_function.py: onv tensors must be uint8."""
-    if bra.dtype != torch.uint8:
+    if bra.dtype is not torch.uint8:
         raise Exception(f"The type of bra {bra.dtype} must be torch.uint8")
 
 
 def split_batch_idx(dim: int, min_batch: int) -> List[int]:
     """utils/public_function.py:695-717: cumulative ends of chunks of `min_batch` (last one shorter)."""
-    length = int(np.ceil(dim / min_batch))
-    ends = [min(dim, (i + 1) * min_batch) for i in range(length)]
-    return ends
+    nchunks = -(-dim // min_batch)  # ceil
+    return [min((c + 1) * min_batch, dim) for c in range(nchunks)]
 
 
 def split_length_idx(dim: int, length: int) -> List[int]:
     """utils/public_function.py:720-746: `length` nearly equal parts, the first dim % length one longer."""
-    k, res = divmod(dim, length)
-    out, acc = [], 0
-    for i in range(length):
-        acc += k + (1 if i < res else 0)
-        out.append(acc)
-    return out
+    base, extra = divmod(dim, length)
+    ends, stop = [], 0
+    for part in range(length):
+        stop += base + (part < extra)
+        ends.append(stop)
+    return ends
 
 
 def torch_lexsort(keys: List[Tensor], dim: int = -1) -> Tensor:
-    """utils/public_function.py:615-648 (np.lexsort semantics: last key is the primary one)."""
+    """utils/public_function.py:615-648 (np.lexsort semantics: last key is the primary one): stable sorts from the
+    least significant key upwards, each applied to the order found so far."""
     if len(keys) < 2:
         raise ValueError(f"keys must be at least 2 sequences, but {len(keys)=}.")
-    idx = keys[0].argsort(dim=dim, stable=True)
-    for k in keys[1:]:
-        idx = idx.gather(dim, k.gather(dim, idx).argsort(dim=dim, stable=True))
-    return idx
+    order = torch.argsort(keys[0], dim=dim, stable=True)
+    for key in keys[1:]:
+        step = torch.argsort(torch.gather(key, dim, order), dim=dim, stable=True)
+        order = torch.gather(order, dim, step)
+    return order
 
 
 def torch_sort_onv(bra: Tensor, little_endian: bool = True) -> Tensor:
     """utils/public_function.py:651-692: argsort of onv rows as little-endian big integers.
     The reference lexsorts byte columns; sorting the 64-bit words (most significant last) is the same order
     and 8x fewer passes."""
-    assert bra.dim() == 2
+    if bra.dim() != 2:
+        raise AssertionError("onv batch must be 2-D")
     if not little_endian:
         raise NotImplementedError("Little_endian has not been implemented")
     words = bra.contiguous().view(torch.int64)  # [n, len]; compare as unsigned
-    n, L = words.shape
-    idx = torch.arange(n, device=bra.device)
-    for w in range(L):  # least significant word first, stable sorts
-        col = words[idx, w]
-        # unsigned order of int64: flip the sign bit
-        key = col ^ torch.iinfo(torch.int64).min
-        idx = idx[key.argsort(stable=True)]
-    return idx
+    perm = torch.arange(words.size(0), device=bra.device)
+    sign = torch.iinfo(torch.int64).min
+    for w in range(words.size(1)):  # least significant word first, stable sorts
+        key = words[perm, w] ^ sign  # unsigned order of int64: flip the sign bit
+        perm = perm[torch.argsort(key, stable=True)]
+    return perm
 
 
 def unique_onv(x: Tensor) -> Tuple[Tensor, Tensor]:
@@ -91,76 +90,63 @@ def unique_onv(x: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 class WavefunctionLUT:
-    """utils/public_function.py:749-868: sorted (onv -> psi) table with binary-search lookup.
-    Lookup runs on the GPU through pynqs_amd.C_extension.wavefunction_lut."""
+    """utils/public_function.py:749-868: (onv -> psi) table over sorted keys.  Same public surface as the reference's
+    class (bra_key, wf_value, dtype, memory, lookup, index_value, rank_begin / rank_end ...); look-ups run on the GPU
+    through the hash table built next to the keys (USE_HASH) or the binary search of pynqs_amd.C_extension."""
 
     def __init__(self, bra_key: Tensor, wf_value: Tensor, sorb: int, device=None, sort: bool = True) -> None:
         check_para(bra_key)
-        assert bra_key.size(0) == wf_value.size(0)
-        self.sort = sort
+        if bra_key.size(0) != wf_value.size(0):
+            raise AssertionError("one amplitude per key")
+        self.sort, self.sorb = sort, sorb
+        keys, vals = bra_key, wf_value
         if sort:
-            idx = torch_sort_onv(bra_key)
-            self._bra_key = bra_key[idx].to(device).contiguous()
-            self._wf_value = wf_value[idx].to(device)
-            self.idx_sorted = torch.argsort(idx, stable=True)
-        else:
-            self._bra_key = bra_key.to(device).contiguous()
-            self._wf_value = wf_value.to(device)
-        self.sorb = sorb
+            order = torch_sort_onv(bra_key)
+            keys, vals = bra_key[order], wf_value[order]
+            self.idx_sorted = torch.argsort(order, stable=True)  # position of the i-th input key in the sorted table
+        self._bra_key = keys.to(device).contiguous()
+        self._wf_value = vals.to(device)
         self.hashtable = None
-        if USE_HASH and self._bra_key.is_cuda and self._bra_key.size(0) > 0:
-            self.hashtable = CX.hash_build(self._bra_key, sorb)  # values = positions in the sorted key array
-        self.rank = get_rank()
-        self.world_size = get_world_size()
-        rank_idx = [0] + split_length_idx(bra_key.size(0), self.world_size)
-        self.rank_idx = rank_idx
-        self.rank_begin = rank_idx[self.rank]
-        self.rank_end = rank_idx[self.rank + 1]
+        self._rebuild_hash()
+        # the contiguous shard of the (unsorted) keys that belongs to this rank
+        self.rank, self.world_size = get_rank(), get_world_size()
+        self.rank_idx = [0] + split_length_idx(bra_key.size(0), self.world_size)
+        self.rank_begin, self.rank_end = self.rank_idx[self.rank], self.rank_idx[self.rank + 1]
 
-    @property
-    def bra_key(self) -> Tensor:
-        return self._bra_key
+    def _rebuild_hash(self) -> None:
+        ok = USE_HASH and self._bra_key.is_cuda and self._bra_key.size(0) > 0
+        self.hashtable = CX.hash_build(self._bra_key, self.sorb) if ok else None  # values = positions in the sorted keys
 
-    @property
-    def wf_value(self) -> Tensor:
-        return self._wf_value
-
-    @property
-    def dtype(self):
-        return self._wf_value.dtype
+    bra_key = property(lambda self: self._bra_key)
+    wf_value = property(lambda self: self._wf_value)
+    dtype = property(lambda self: self._wf_value.dtype)
+    memory = property(lambda self: self._bra_key.numel() / 2**20)
 
     def to(self, device) -> None:
-        self._bra_key = self._bra_key.to(device=device)
-        self._wf_value = self._wf_value.to(device=device)
-        self.hashtable = CX.hash_build(self._bra_key, self.sorb) if (USE_HASH and self._bra_key.is_cuda) else None
-
-    @property
-    def memory(self) -> float:
-        return self.bra_key.numel() / 2**20
+        self._bra_key, self._wf_value = self._bra_key.to(device=device), self._wf_value.to(device=device)
+        self._rebuild_hash()
 
     def lookup(self, onv: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         """(indices of onv found, indices not found, psi of the found ones) -- public_function.py:817-838."""
-        nbatch = onv.size(0)
-        baseline = torch.arange(nbatch, device=onv.device, dtype=torch.int64)
         if self.hashtable is not None and onv.is_cuda:
-            idx_array, mask = CX.hash_lookup(self.hashtable, onv)
+            pos, found = CX.hash_lookup(self.hashtable, onv)
         else:
-            idx_array, mask = wavefunction_lut(self._bra_key, onv, self.sorb)
-        idx_array, mask = idx_array.to(onv.device), mask.to(onv.device)
-        onv_idx = baseline[mask]
-        onv_not_idx = baseline[torch.logical_not(mask)]
-        value = self._wf_value[idx_array.masked_select(mask)]
-        return onv_idx, onv_not_idx, value
+            pos, found = wavefunction_lut(self._bra_key, onv, self.sorb)
+        pos, found = pos.to(onv.device), found.to(onv.device)
+        every = torch.arange(onv.size(0), device=onv.device, dtype=torch.int64)
+        return every[found], every[~found], self._wf_value[pos[found]]
 
     def index_value(self, begin: int, end: int) -> Tensor:
-        assert self.sort, "not-sorted does not support index-value"
-        begin = self.rank_begin + begin
-        end = self.rank_begin + end
-        assert self.rank_end >= end, "Index date must be in the same rank"
-        return self.wf_value[self.idx_sorted[begin:end]]
+        if not self.sort:
+            raise AssertionError("not-sorted does not support index-value")
+        lo, hi = self.rank_begin + begin, self.rank_begin + end
+        if hi > self.rank_end:
+            raise AssertionError("Index date must be in the same rank")
+        return self._wf_value[self.idx_sorted[lo:hi]]
 
     def clean_memory(self) -> None:
-        del self._bra_key, self._wf_value
+        self._bra_key = self._wf_value = None
+        self.hashtable = None
 
     def __repr__(self) -> str:
         return (f"{type(self).__name__}(\n    bra-key shape: {tuple(self.bra_key.size())}\n"
@@ -169,18 +155,19 @@ class WavefunctionLUT:
 
 def ansatz_batch(func: Callable[[Tensor], Tensor], x: Tensor, batch: int, sorb: int, device, dtype) -> Tensor:
     """utils/public_function.py:934-960: uint8 onv -> +-1 -> func, in chunks of `batch` rows."""
-    if x.dtype == torch.uint8:
-        convert = partial(onv_to_tensor, sorb=sorb)
-    else:
-        assert x.size(1) == sorb
-        convert = lambda t: t  # noqa: E731
-    if batch == -1 or x.size(0) == 0 or batch >= x.size(0):
-        return func(convert(x)).to(dtype)
-    ends = [0] + split_batch_idx(x.size(0), batch)
-    result = torch.empty(x.size(0), device=device, dtype=dtype)
-    for a, b in zip(ends[:-1], ends[1:]):
-        result[a:b] = func(convert(x[a:b])).to(dtype).view(-1)
-    return result
+    packed = x.dtype == torch.uint8
+    if not packed and x.size(1) != sorb:
+        raise AssertionError("expected +-1 rows of length sorb")
+    feed = (lambda rows: onv_to_tensor(rows, sorb)) if packed else (lambda rows: rows)
+    n = x.size(0)
+    if batch == -1 or n == 0 or batch >= n:
+        return func(feed(x)).to(dtype)
+    out = torch.empty(n, device=device, dtype=dtype)
+    lo = 0
+    for hi in split_batch_idx(n, batch):
+        out[lo:hi] = func(feed(x[lo:hi])).to(dtype).view(-1)
+        lo = hi
+    return out
 
 
 # ---- spin-flip symmetry helpers (utils/public_function.py:966-1018) ----------------------------------
