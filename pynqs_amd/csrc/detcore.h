@@ -211,29 +211,46 @@ __device__ __forceinline__ uint64_t hash_of(const uint64_t (&q)[LEN]) {
   return h ^ (h >> 29);
 }
 
-// Bloom prefilter of the same keys (2 bits per key out of one hash), appended to the table: the fused sample-space
-// kernel copies it into LDS and asks it before every probe.  Most x' are not in the sample table (85 % for the
-// Fe2S2 CI space), and a probe drags a whole cache line through the vector L1 for 16 useful bytes -- the kernel
-// was bound by exactly that (TA busy 82 %).  About 8 filter bits per key, at most kFilterMaxBits (16 KiB of LDS):
-// a larger filter costs more in LDS occupancy than its lower false-positive rate returns.
-constexpr uint32_t kFilterMaxBits = 1u << 17;
+// Bloom prefilter of the same keys (2 bits per key), appended to the table: the fused sample-space kernel copies it
+// into LDS and asks it before anything else is done for a column.  Most x' are not in the sample table (85 % for
+// the Fe2S2 CI space, far more for larger systems), so the filter decides what a column costs.  Its hash is a
+// Zobrist hash -- the XOR of one fixed 32-bit value per occupied orbital -- because that one follows from the
+// walker's hash and the 2 or 4 orbitals an excitation flips, without forming x' at all.
+constexpr uint32_t kFilterMaxBits = 1u << 18;  // 32 KiB of LDS; also the most the 32-bit hash can address twice
+
+__host__ __device__ inline uint32_t zobrist32(uint32_t orbital) {
+  uint32_t z = (orbital + 1u) * 0x9e3779b1u;
+  z ^= z >> 15; z *= 0x85ebca77u;
+  z ^= z >> 13; z *= 0xc2b2ae3du;
+  return z ^ (z >> 16);
+}
+
+template <int LEN>
+__host__ __device__ inline uint32_t zobrist_of(const uint64_t (&q)[LEN]) {
+  uint32_t z = 0;
+  for (int w = 0; w < LEN; ++w)
+    for (uint64_t b = q[w]; b; b &= b - 1) z ^= zobrist32(64u * w + (uint32_t)__builtin_ctzll(b));
+  return z;
+}
 
 inline uint32_t hash_filter_bits(int64_t nkeys) {  // host side
   if (nkeys <= 0) return 0;
-  // largest power of two <= 8 bits per key, at most kFilterMaxBits.  Measured on Fe2S2 (18496 keys, 8192 walkers) with
-  // the kernel's order-free singles/diagonal (no staging scratch in LDS): 2 / 4 / 8 / 16 bits per key -> 0.345 / 0.298 /
-  // 0.271 / 0.294 ms (false positives vs LDS occupancy); no filter 0.447 ms
+  // largest power of two <= 8 bits per key, in [1024, kFilterMaxBits] (PYNQS_FILTER_BITS lowers the cap, 0 = no filter).
+  // Measured on Fe2S2 (18496 keys, 8192 walkers): 2 / 4 / 8 / 16 bits per key -> 0.345 / 0.298 / 0.271 / 0.294 ms
+  // (false positives against LDS occupancy); no filter 0.447 ms.
   static const uint64_t maxbits = getenv("PYNQS_FILTER_BITS") ? strtoull(getenv("PYNQS_FILTER_BITS"), nullptr, 10) : kFilterMaxBits;
   if (maxbits == 0) return 0;
+  const uint64_t cap = maxbits < kFilterMaxBits ? maxbits : kFilterMaxBits;
   uint64_t b = 1024;
   static const uint64_t per_key = getenv("PYNQS_FILTER_PER_KEY") ? strtoull(getenv("PYNQS_FILTER_PER_KEY"), nullptr, 10) : 8;
-  while (2 * b <= per_key * (uint64_t)nkeys && 2 * b <= maxbits) b <<= 1;
+  while (2 * b <= per_key * (uint64_t)nkeys && 2 * b <= cap) b <<= 1;
   return b >= (uint64_t)nkeys ? (uint32_t)b : 0u;  // below one bit per key it rejects too little
 }
 
-__host__ __device__ inline void filter_positions(uint64_t h, uint32_t fbits, uint32_t &b0, uint32_t &b1) {
-  b0 = (uint32_t)(h >> 20) & (fbits - 1u);
-  b1 = (uint32_t)(h >> 41) & (fbits - 1u);
+// the two filter bits of a key: the low and the high log2(fbits) bits of its Zobrist hash (fbits = 2^k, 10 <= k <= 18)
+__host__ __device__ inline void filter_positions(uint32_t z, uint32_t fbits, uint32_t &b0, uint32_t &b1) {
+  b0 = z & (fbits - 1u);
+  b1 = z >> (uint32_t)__builtin_clz(fbits - 1u);  // 32 - k
 }
 
 // First probe only: the slot content (to let a caller issue several independent first probes back to back).

@@ -26,30 +26,16 @@ struct LookupSink {
   const double *__restrict__ wf;
   double *__restrict__ psi0;  // this walker's psi(x) slot
   double re, im;
-  uint32_t filt;   // LDS address of the Bloom filter words (HASH only)
-  uint32_t fbits;  // its size in bits, 0 = no filter
-  // false: the key is certainly not in the table
-  __device__ __forceinline__ bool maybe(uint64_t h) const {
-    if (!fbits) return true;
-    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-    uint32_t b0, b1;
-    filter_positions(h, fbits, b0, b1);
-    const uint32_t w0 = *reinterpret_cast<lds_cu32 *>(filt + 4u * (b0 >> 5)), w1 = *reinterpret_cast<lds_cu32 *>(filt + 4u * (b1 >> 5));
-    return ((w0 >> (b0 & 31u)) & (w1 >> (b1 & 31u)) & 1u) != 0u;
-  }
-  // the two look-ups of a sink call: filter, then both first probes in flight together
+  // the two look-ups of a sink call: both first probes in flight together
   __device__ __forceinline__ void lookup2(uint32_t c0, double h0, const uint64_t (&k0)[LEN], uint32_t c1, double h1, const uint64_t (&k1)[LEN]) {
-    const uint64_t g0 = hash_of<LEN>(k0), g1 = hash_of<LEN>(k1);
-    const bool m0 = maybe(g0), m1 = maybe(g1);
-    HashProbe<LEN> p0, p1;
-    if (m0) p0 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, g0);
-    if (m1) p1 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, g1);
-    accumulate(c0, h0, m0 ? hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0) : -1);
-    accumulate(c1, h1, m1 ? hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1) : -1);
+    const HashProbe<LEN> p0 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, hash_of<LEN>(k0));
+    const HashProbe<LEN> p1 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, hash_of<LEN>(k1));
+    accumulate(c0, h0, hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0));
+    accumulate(c1, h1, hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1));
   }
   __device__ __forceinline__ void add(uint32_t col, double h, const uint64_t (&ket)[LEN]) {
     int64_t pos;
-    if constexpr (HASH) pos = maybe(hash_of<LEN>(ket)) ? hash_find<LEN>(keys, (uint64_t)nkeys, ket) : -1;
+    if constexpr (HASH) pos = hash_find<LEN>(keys, (uint64_t)nkeys, ket);
     else pos = lut_find<LEN>(keys, nkeys, ket);
     accumulate(col, h, pos);
   }
@@ -87,38 +73,13 @@ struct LookupSink {
   }
 };
 
-template <int LEN, bool CPLX, bool HASH>
-__global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
-                                                                   uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
-                                                                   const double *__restrict__ plan,
-                                                                   const uint64_t *__restrict__ keys, int64_t nkeys,
-                                                                   const double *__restrict__ wf, double *__restrict__ acc,
-                                                                   double *__restrict__ psi0, uint32_t fbits) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ double red[2][kBlock / 64];
-  __shared__ uint32_t next_tile;
-  uint64_t walker;
-  uint32_t chunk;
-  map_workgroup(nchunks, xcd_map, walker, chunk);
+// Sum of a workgroup's per-lane partial sums into acc[walker]: lanes (xor butterfly), then waves, in a fixed order.
+// (Which tile a wave gets is dynamic, so the order of the additions inside a lane, and with it the last bits of the
+// sum, can vary from run to run; with more than one chunk per walker the chunks meet through float atomics.)
+template <bool CPLX>
+__device__ __forceinline__ void store_walker_sum(double re, double im, double (*red)[kBlock / 64], uint32_t nchunks, uint64_t walker,
+                                                 double *__restrict__ acc) {
   const int tid = threadIdx.x;
-  if (tid == 0) next_tile = 0;
-  Walker<LEN> wk;
-  load_walker<LEN>(bra + walker * LEN, wk);
-  const LdsLayout L = carve_lds(smem, p);
-  // the table's Bloom filter follows its slots in memory; its LDS copy follows the staging scratch
-  const uint32_t filt_off = (uint32_t)((lds_bytes(p, 0) + 15) & ~(size_t)15);  // no staging scratch: order-free singles / diagonal
-  if (HASH && fbits) {
-    const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(keys + (uint64_t)nkeys * hash_slot_words(LEN));
-    uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
-    for (uint32_t i = tid; i < fbits / 32; i += kBlock) lf[i] = gf[i];
-  }
-  const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier: the filter copy is visible
-  LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0,
-                                   __builtin_amdgcn_groupstaticsize() + filt_off, HASH ? fbits : 0u};
-  visit_tiles<LEN, double, LookupSink<LEN, CPLX, HASH>, false>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
-  double re = sink.re, im = sink.im;
-  // fixed-order reduction: lanes (xor butterfly), then waves.  (Which tile a wave gets is dynamic, so the
-  // order of the additions inside a lane, and with it the last bits of the sum, can vary from run to run.)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     re += __shfl_xor(re, o);
@@ -137,6 +98,224 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
       else atomicAdd(acc + walker, sr);
     }
   }
+}
+
+template <int LEN, bool CPLX, bool HASH>
+__global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
+                                                                   uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
+                                                                   const double *__restrict__ plan,
+                                                                   const uint64_t *__restrict__ keys, int64_t nkeys,
+                                                                   const double *__restrict__ wf, double *__restrict__ acc,
+                                                                   double *__restrict__ psi0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ double red[2][kBlock / 64];
+  __shared__ uint32_t next_tile;
+  uint64_t walker;
+  uint32_t chunk;
+  map_workgroup(nchunks, xcd_map, walker, chunk);
+  const int tid = threadIdx.x;
+  if (tid == 0) next_tile = 0;
+  Walker<LEN> wk;
+  load_walker<LEN>(bra + walker * LEN, wk);
+  const LdsLayout L = carve_lds(smem, p);
+  const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier
+  LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0};
+  visit_tiles<LEN, double, LookupSink<LEN, CPLX, HASH>, false>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+  store_walker_sum<CPLX>(sink.re, sink.im, red, nchunks, walker, acc);
+}
+
+// -------------------------------------------------------------------------------------------------
+// SAMPLE_SPACE with the filter in front (hash table with a Bloom filter, i.e. every table of up to 2^18 keys).
+// The kernel above does everything for every column -- decode, integral gather, sign, x', hash, probe -- although
+// nearly all x' are not in the table: at sorb 120 that was 177 vector instructions and 9 vector-memory instructions
+// per column (TD busy 95 %), 8 of the 9 being probe chains that lasted as long as the slowest lane's.  Here a
+// column first costs only its decode and a filter test on the Zobrist hash  zx ^ Z[o1] ^ Z[o2] (^ Z[o3] ^ Z[o4])  of
+// the orbitals it flips (detcore.h) -- no integral, no x'.  The ranks that pass are parked in a wave-private LDS
+// queue, and whenever 64 are waiting the wave evaluates them together, all lanes busy: matrix element and x' from
+// the rank (the same helpers as everywhere else), probe, accumulate.
+constexpr uint32_t kQueue = 128;  // ranks a wave can park: < 64 left over + 64 new ones
+__host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits) { return fbits / 8 + 4 * 192 + (kBlock / 64) * kQueue * 4; }
+
+template <int LEN, bool CPLX>
+struct Candidates {
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const SDParams &p;
+  const PlanLayout &pl;
+  const LdsLayout &L;
+  const Walker<LEN> &wk;
+  int nocc;
+  const double *__restrict__ plan;
+  const uint64_t *__restrict__ table;
+  uint64_t cap;
+  const double *__restrict__ wf;
+  uint32_t filt, fbits;  // LDS address and size of the filter
+  uint32_t zorb;         // LDS address of Z[orbital]
+  uint32_t queue;        // LDS address of this wave's queue
+  uint32_t zx;           // Zobrist hash of the walker
+  uint32_t qn;           // parked ranks (wave-uniform)
+  double re, im;
+
+  __device__ __forceinline__ uint32_t Z(uint32_t orbital_times_4) const { return *reinterpret_cast<lds_u32 *>(zorb + orbital_times_4); }
+  // Zobrist hash of x' from the table entries of its excitation (orbital | orbital << 8 | ...)
+  __device__ __forceinline__ uint32_t flipped(uint32_t e) const { return Z((e << 2) & 0x3fcu) ^ Z((e >> 6) & 0x3fcu); }
+  __device__ __forceinline__ bool maybe(uint32_t z) const {  // false: certainly not in the table
+    uint32_t b0, b1;
+    filter_positions(z, fbits, b0, b1);
+    const uint32_t w0 = *reinterpret_cast<lds_u32 *>(filt + 4u * (b0 >> 5)), w1 = *reinterpret_cast<lds_u32 *>(filt + 4u * (b1 >> 5));
+    return ((w0 >> (b0 & 31u)) & (w1 >> (b1 & 31u)) & 1u) != 0u;
+  }
+  __device__ __forceinline__ void value(int64_t pos, double &vr, double &vi) const {  // psi of table entry pos, 0 if pos < 0
+    vr = 0.0; vi = 0.0;
+    if (pos >= 0) {
+      if constexpr (CPLX) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 v = *reinterpret_cast<const d2 *>(wf + 2 * pos);
+        vr = v[0]; vi = v[1];
+      } else vr = wf[pos];
+    }
+  }
+  __device__ __forceinline__ void add(double h, int64_t pos) {
+    double vr, vi;
+    value(pos, vr, vi);
+    re += h * vr;
+    if constexpr (CPLX) im += h * vi;
+  }
+  // evaluate the top n parked ranks (all 64 lanes active, n <= min(qn, 64)).  LDS operations of a wave execute in order.
+  __device__ __forceinline__ void drain(uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+    double h = 0.0;
+    int64_t pos = -1;
+    if (lane < n) {
+      const uint32_t r = *reinterpret_cast<lds_u32 *>(queue + 4u * (qn - n + lane));
+      uint64_t ket[LEN];
+      if (r < p.d1) {
+        h = fast_single<double>(r, p, pl, L, nocc, plan);
+        const uint32_t e = L.tab[p.offSa + r];
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
+        toggle<LEN>(ket, e & 0xff);
+        toggle<LEN>(ket, (e >> 8) & 0xff);
+      } else {
+        h = double_element<LEN, double>(r, p, pl, L, plan, wk, ket);
+      }
+      pos = hash_find<LEN>(table, cap, ket);
+    }
+    qn = __builtin_amdgcn_readfirstlane(qn - n);
+    __builtin_amdgcn_wave_barrier();
+    add(h, pos);
+  }
+  __device__ __forceinline__ void park(uint32_t r, bool pass) {  // all 64 lanes active
+    const uint64_t m = __ballot(pass);
+    if (!m) return;
+    if (pass) {
+      const uint32_t lane = threadIdx.x & 63;
+      *reinterpret_cast<lds_u32 *>(queue + 4u * (qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))) = r;
+    }
+    qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
+    if (qn >= 64u) drain(64u);
+  }
+};
+
+template <int LEN, bool CPLX>
+__global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
+                                                                            uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
+                                                                            const double *__restrict__ plan,
+                                                                            const uint64_t *__restrict__ table, int64_t cap,
+                                                                            const double *__restrict__ wf, double *__restrict__ acc,
+                                                                            double *__restrict__ psi0, uint32_t fbits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ double red[2][kBlock / 64];
+  __shared__ uint32_t next_tile;
+  uint64_t walker;
+  uint32_t chunk;
+  map_workgroup(nchunks, xcd_map, walker, chunk);
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) next_tile = 0;
+  Walker<LEN> wk;
+  load_walker<LEN>(bra + walker * LEN, wk);
+  const LdsLayout L = carve_lds(smem, p);
+  // after the walker tables (no staging scratch: order-free singles / diagonal): filter, Z[orbital], the waves' queues
+  const uint32_t filt_off = (uint32_t)((lds_bytes(p, 0) + 15) & ~(size_t)15), z_off = filt_off + fbits / 8, q_off = z_off + 4 * 192;
+  {
+    const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(table + (uint64_t)cap * hash_slot_words(LEN));
+    uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
+    for (uint32_t i = tid; i < fbits / 32; i += kBlock) lf[i] = gf[i];
+    uint32_t *lz = reinterpret_cast<uint32_t *>(smem + z_off);
+    if (tid < 192) lz[tid] = zobrist32((uint32_t)tid);
+  }
+  const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier: filter and Z are visible
+  uint32_t zx = 0;
+#pragma unroll
+  for (int w = 0; w < LEN; ++w)
+    if ((wk.w[w] >> lane) & 1ull) zx ^= zobrist32(64u * w + (uint32_t)lane);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) zx ^= __shfl_xor(zx, o);
+  const uint32_t dyn = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
+  Candidates<LEN, CPLX> cand{p, pl, L, wk, nocc, plan, table, (uint64_t)cap, wf, dyn + filt_off, fbits, dyn + z_off,
+                             dyn + q_off + (uint32_t)(tid >> 6) * (kQueue * 4u), zx, 0u, 0.0, 0.0};
+
+  // tiles as in plan_tiles.h (EXACT = false): 0 = column 0, then 64 singles each (dealt round-robin over the walker's
+  // workgroups), then 256 ranks of one class of doubles each
+  constexpr uint32_t kRanks = 256;
+  const uint32_t ncomb = p.nsd + 1;
+  const uint32_t lo = chunk * chunk_len, hi = min(lo + chunk_len, ncomb);
+  const uint32_t rlo = lo == 0 ? 0 : lo - 1, rhi = hi - 1;
+  const ClassRange gA = class_range<false>(p.d1, p.d2, rlo, rhi, 0u), gB = class_range<false>(p.d2, p.d3, rlo, rhi, 0u),
+                   gO = class_range<false>(p.d3, p.nsd, rlo, rhi, 0u);
+  const uint32_t tA = (gA.npairs + kRanks - 1) / kRanks, tB = (gB.npairs + kRanks - 1) / kRanks, tO = (gO.npairs + kRanks - 1) / kRanks;
+  const uint32_t tS_all = (p.d1 + 63u) / 64u;
+  const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
+  const uint32_t ntiles = 1 + tS + tA + tB + tO;
+  for (;;) {
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(&next_tile, 1u);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (tile >= ntiles) break;
+    if (tile == 0) {
+      if (lo == 0) {  // column 0: <x|H|x> psi(x), and psi(x) itself
+        const double v = fast_diag<double>(p, pl, L, plan);
+        if (lane == 0) {
+          double vr, vi;
+          cand.value(hash_find<LEN>(table, (uint64_t)cap, wk.w), vr, vi);
+          double *__restrict__ out = psi0 + (CPLX ? 2 : 1) * walker;
+          out[0] = vr;
+          cand.re += v * vr;
+          if constexpr (CPLX) { out[1] = vi; cand.im += v * vi; }
+        }
+      }
+      continue;
+    }
+    if (tile <= tS) {
+      const uint32_t r = (chunk + (tile - 1) * nchunks) * 64u + (uint32_t)lane;
+      const bool valid = r < p.d1;
+      const uint32_t e = L.tab[p.offSa + (valid ? r : p.d1 - 1)];
+      cand.park(r, valid && cand.maybe(zx ^ cand.flipped(e)));
+      continue;
+    }
+    tile -= 1 + tS;
+    const int k = tile < tA ? 0 : (tile < tA + tB ? 1 : 2);
+    const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
+    const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kRanks;
+    const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
+    uint32_t rr[4];
+    bool pass[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // independent: the LDS reads of the four groups overlap
+      const uint32_t m = first + 64u * j + (uint32_t)lane;
+      const bool valid = m < g.npairs;
+      rr[j] = g.r_e + (valid ? m : g.npairs - 1);
+      uint32_t slow, u;
+      class_split(rr[j], c, slow, u);
+      uint32_t f = u + c.rot;
+      f = f >= c.nfast ? f - c.nfast : f;
+      pass[j] = valid && cand.maybe(zx ^ cand.flipped(L.tab[c.off_fast + f]) ^ cand.flipped(L.tab[c.off_slow + slow]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cand.park(rr[j], pass[j]);
+  }
+  if (cand.qn) cand.drain(cand.qn);
+  store_walker_sum<CPLX>(cand.re, cand.im, red, nchunks, walker, acc);
 }
 
 // Insert key i of the sorted key array: claim a slot by CAS on its index word, then write the key words
@@ -160,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__re
       for (int w = 0; w < LEN; ++w) table[s * W + w] = q[w];
       if (fbits) {
         uint32_t b0, b1;
-        filter_positions(hq, fbits, b0, b1);
+        filter_positions(zobrist_of<LEN>(q), fbits, b0, b1);
         uint32_t *filter = reinterpret_cast<uint32_t *>(table + cap * W);
         atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
         atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
@@ -325,20 +504,32 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   uint32_t nchunks, chunk_len;
   plan_chunks(nbatch, p.nsd + 1, &nchunks, &chunk_len);
   const uint32_t fbits = hash ? hash_filter_bits(nkeys) : 0u;
-  const size_t lds = ((lds_bytes(p, 0) + 15) & ~(size_t)15) + fbits / 8;
+  const size_t lds = ((lds_bytes(p, 0) + 15) & ~(size_t)15) + (fbits ? filtered_extra_lds(fbits) : 0);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   const double *pd = (const double *)plan;
   const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
-#define PYNQS_SS_LAUNCH(C, H)                                                                                              \
-  hipLaunchKernelGGL((eloc_sample_space_kernel<LEN, C, H>), dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, \
-                     chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0, fbits)
+#define PYNQS_SS_ARGS dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0
+#define PYNQS_SS_LAUNCH(KERNEL, ...)                                                                                              \
+  do {                                                                                                                            \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)lds) != hipSuccess)                                                           \
+      return check_launch("hipFuncSetAttribute");                                                                                \
+    hipLaunchKernelGGL((KERNEL), PYNQS_SS_ARGS, ##__VA_ARGS__);                                                                   \
+  } while (0)
   DISPATCH_LEN(len, {
-    if (wf_is_complex) { if (hash) PYNQS_SS_LAUNCH(true, true); else PYNQS_SS_LAUNCH(true, false); }
-    else { if (hash) PYNQS_SS_LAUNCH(false, true); else PYNQS_SS_LAUNCH(false, false); }
+    if (fbits) {  // hash table with its filter
+      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true>), fbits);
+      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false>), fbits);
+    } else if (wf_is_complex) {
+      if (hash) PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, true, true>)); else PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, true, false>));
+    } else {
+      if (hash) PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, false, true>)); else PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, false, false>));
+    }
   });
+#undef PYNQS_SS_ARGS
 #undef PYNQS_SS_LAUNCH
   const uint32_t g2 = (uint32_t)((nbatch + kBlock - 1) / kBlock);
   if (wf_is_complex) hipLaunchKernelGGL((eloc_divide_kernel<true>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
