@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
 // queue, and whenever 64 are waiting the wave evaluates them together, all lanes busy: matrix element and x' from
 // the rank (the same helpers as everywhere else), probe, accumulate.
 constexpr uint32_t kQueue = 128;  // ranks a wave can park: < 64 left over + 64 new ones
-__host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits) { return fbits / 8 + 4 * 192 + (kBlock / 64) * kQueue * 4; }
+__host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits) { return fbits / 8 + 4 * 192 + (kBlock / 64) * 2 * kQueue * 4; }
 
 template <int LEN, bool CPLX>
 struct Candidates {
@@ -150,9 +150,9 @@ struct Candidates {
   const double *__restrict__ wf;
   uint32_t filt, fbits;  // LDS address and size of the filter
   uint32_t zorb;         // LDS address of Z[orbital]
-  uint32_t queue;        // LDS address of this wave's queue
+  uint32_t queue;        // LDS address of this wave's two queues (doubles, singles)
   uint32_t zx;           // Zobrist hash of the walker
-  uint32_t qn;           // parked ranks (wave-uniform)
+  uint32_t qn, sn;       // parked doubles / singles (wave-uniform)
   double re, im;
 
   __device__ __forceinline__ uint32_t Z(uint32_t orbital_times_4) const { return *reinterpret_cast<lds_u32 *>(zorb + orbital_times_4); }
@@ -180,16 +180,20 @@ struct Candidates {
     re += h * vr;
     if constexpr (CPLX) im += h * vi;
   }
-  // evaluate the top n parked ranks (all 64 lanes active, n <= min(qn, 64)).  LDS operations of a wave execute in order.
+  // evaluate the top n parked ranks of one queue (all 64 lanes active, n <= min(count, 64)).  LDS operations of a wave
+  // execute in order.  Singles have their own queue: one costs nele gathers, and a lane-per-candidate loop over them
+  // lasts as long for one single among 63 doubles as for 64 singles.
+  template <bool SINGLES>
   __device__ __forceinline__ void drain(uint32_t n) {
     const uint32_t lane = threadIdx.x & 63;
+    uint32_t &count = SINGLES ? sn : qn;
     __builtin_amdgcn_wave_barrier();
     double h = 0.0;
     int64_t pos = -1;
     if (lane < n) {
-      const uint32_t r = *reinterpret_cast<lds_u32 *>(queue + 4u * (qn - n + lane));
+      const uint32_t r = *reinterpret_cast<lds_u32 *>(queue + (SINGLES ? 4u * kQueue : 0u) + 4u * (count - n + lane));
       uint64_t ket[LEN];
-      if (r < p.d1) {
+      if constexpr (SINGLES) {
         h = fast_single<double>(r, p, pl, L, nocc, plan);
         const uint32_t e = L.tab[p.offSa + r];
 #pragma unroll
@@ -201,19 +205,21 @@ struct Candidates {
       }
       pos = hash_find<LEN>(table, cap, ket);
     }
-    qn = __builtin_amdgcn_readfirstlane(qn - n);
+    count = __builtin_amdgcn_readfirstlane(count - n);
     __builtin_amdgcn_wave_barrier();
     add(h, pos);
   }
+  template <bool SINGLES>
   __device__ __forceinline__ void park(uint32_t r, bool pass) {  // all 64 lanes active
     const uint64_t m = __ballot(pass);
     if (!m) return;
+    uint32_t &count = SINGLES ? sn : qn;
     if (pass) {
       const uint32_t lane = threadIdx.x & 63;
-      *reinterpret_cast<lds_u32 *>(queue + 4u * (qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))) = r;
+      *reinterpret_cast<lds_u32 *>(queue + (SINGLES ? 4u * kQueue : 0u) + 4u * (count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))) = r;
     }
-    qn = __builtin_amdgcn_readfirstlane(qn + (uint32_t)__popcll(m));
-    if (qn >= 64u) drain(64u);
+    count = __builtin_amdgcn_readfirstlane(count + (uint32_t)__popcll(m));
+    if (count >= 64u) drain<SINGLES>(64u);
   }
 };
 
@@ -253,10 +259,11 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
   for (int o = 32; o > 0; o >>= 1) zx ^= __shfl_xor(zx, o);
   const uint32_t dyn = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
   Candidates<LEN, CPLX> cand{p, pl, L, wk, nocc, plan, table, (uint64_t)cap, wf, dyn + filt_off, fbits, dyn + z_off,
-                             dyn + q_off + (uint32_t)(tid >> 6) * (kQueue * 4u), zx, 0u, 0.0, 0.0};
+                             dyn + q_off + (uint32_t)(tid >> 6) * (2u * kQueue * 4u), zx, 0u, 0u, 0.0, 0.0};
 
-  // tiles as in plan_tiles.h (EXACT = false): 0 = column 0, then 64 singles each (dealt round-robin over the walker's
-  // workgroups), then 256 ranks of one class of doubles each
+  // tiles: 0 = column 0; 1 = this workgroup's share of the singles (blocks of 64 dealt round-robin over the walker's
+  // workgroups, as in plan_tiles.h) -- one wave takes them all, so that its singles queue fills; then 256 ranks of one
+  // class of doubles each
   constexpr uint32_t kRanks = 256;
   const uint32_t ncomb = p.nsd + 1;
   const uint32_t lo = chunk * chunk_len, hi = min(lo + chunk_len, ncomb);
@@ -264,9 +271,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
   const ClassRange gA = class_range<false>(p.d1, p.d2, rlo, rhi, 0u), gB = class_range<false>(p.d2, p.d3, rlo, rhi, 0u),
                    gO = class_range<false>(p.d3, p.nsd, rlo, rhi, 0u);
   const uint32_t tA = (gA.npairs + kRanks - 1) / kRanks, tB = (gB.npairs + kRanks - 1) / kRanks, tO = (gO.npairs + kRanks - 1) / kRanks;
-  const uint32_t tS_all = (p.d1 + 63u) / 64u;
-  const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
-  const uint32_t ntiles = 1 + tS + tA + tB + tO;
+  const uint32_t ntiles = 2 + tA + tB + tO;
   for (;;) {
     uint32_t tile = 0;
     if (lane == 0) tile = atomicAdd(&next_tile, 1u);
@@ -286,35 +291,45 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
       }
       continue;
     }
-    if (tile <= tS) {
-      const uint32_t r = (chunk + (tile - 1) * nchunks) * 64u + (uint32_t)lane;
-      const bool valid = r < p.d1;
-      const uint32_t e = L.tab[p.offSa + (valid ? r : p.d1 - 1)];
-      cand.park(r, valid && cand.maybe(zx ^ cand.flipped(e)));
+    if (tile == 1) {
+      for (uint32_t r0 = chunk * 64u; r0 < p.d1; r0 += nchunks * 64u) {
+        const uint32_t r = r0 + (uint32_t)lane;
+        const uint32_t e = L.tab[p.offSa + min(r, p.d1 - 1)];
+        cand.template park<true>(r, (r < p.d1) & cand.maybe(zx ^ cand.flipped(e)));
+      }
+      if (cand.sn) cand.template drain<true>(cand.sn);
       continue;
     }
-    tile -= 1 + tS;
+    tile -= 2;
     const int k = tile < tA ? 0 : (tile < tA + tB ? 1 : 2);
     const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
     const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kRanks;
     const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
+    // rank -> (slow, fast) by one division for the lane's first rank, then 64 further per group
+    const uint32_t q64 = mdiv(64u, c.dv), r64 = 64u - q64 * c.nfast;
+    const uint32_t nslow = (uint32_t)(k == 0 ? p.nvAA : (k == 1 ? p.nvBB : p.nSb));
+    const uint32_t last = g.npairs - 1;
+    uint32_t slow, u;
+    class_split(g.r_e + min(first + (uint32_t)lane, last), c, slow, u);
     uint32_t rr[4];
     bool pass[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {  // independent: the LDS reads of the four groups overlap
+    for (int j = 0; j < 4; ++j) {  // independent and branch-free: the LDS reads of the four groups overlap
       const uint32_t m = first + 64u * j + (uint32_t)lane;
-      const bool valid = m < g.npairs;
-      rr[j] = g.r_e + (valid ? m : g.npairs - 1);
-      uint32_t slow, u;
-      class_split(rr[j], c, slow, u);
+      rr[j] = g.r_e + m;
       uint32_t f = u + c.rot;
       f = f >= c.nfast ? f - c.nfast : f;
-      pass[j] = valid && cand.maybe(zx ^ cand.flipped(L.tab[c.off_fast + f]) ^ cand.flipped(L.tab[c.off_slow + slow]));
+      // (lanes past the end of the class read a valid but meaningless entry: slow is clamped to the class's last row)
+      const uint32_t z = zx ^ cand.flipped(L.tab[c.off_fast + f]) ^ cand.flipped(L.tab[c.off_slow + min(slow, nslow - 1u)]);
+      pass[j] = (m <= last) & cand.maybe(z);
+      u += r64;
+      slow += q64 + (u >= c.nfast ? 1u : 0u);
+      u = u >= c.nfast ? u - c.nfast : u;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cand.park(rr[j], pass[j]);
+    for (int j = 0; j < 4; ++j) cand.template park<false>(rr[j], pass[j]);
   }
-  if (cand.qn) cand.drain(cand.qn);
+  if (cand.qn) cand.template drain<false>(cand.qn);
   store_walker_sum<CPLX>(cand.re, cand.im, red, nchunks, walker, acc);
 }
 
