@@ -225,12 +225,23 @@ __host__ __device__ inline uint32_t zobrist32(uint32_t orbital) {
   return z ^ (z >> 16);
 }
 
+// a second, independent value per orbital for the second-level filter
+__host__ __device__ inline uint32_t zobrist32b(uint32_t orbital) {
+  uint32_t z = (orbital + 0x51u) * 0x7feb352du;
+  z ^= z >> 16; z *= 0x846ca68bu;
+  z ^= z >> 15; z *= 0x9e3779b1u;
+  return z ^ (z >> 13);
+}
+
 template <int LEN>
-__host__ __device__ inline uint32_t zobrist_of(const uint64_t (&q)[LEN]) {
-  uint32_t z = 0;
+__host__ __device__ inline void zobrist_of(const uint64_t (&q)[LEN], uint32_t &z, uint32_t &z2) {
+  z = 0; z2 = 0;
   for (int w = 0; w < LEN; ++w)
-    for (uint64_t b = q[w]; b; b &= b - 1) z ^= zobrist32(64u * w + (uint32_t)__builtin_ctzll(b));
-  return z;
+    for (uint64_t b = q[w]; b; b &= b - 1) {
+      const uint32_t o = 64u * w + (uint32_t)__builtin_ctzll(b);
+      z ^= zobrist32(o);
+      z2 ^= zobrist32b(o);
+    }
 }
 
 inline uint32_t hash_filter_bits(int64_t nkeys) {  // host side
@@ -245,6 +256,17 @@ inline uint32_t hash_filter_bits(int64_t nkeys) {  // host side
   static const uint64_t per_key = getenv("PYNQS_FILTER_PER_KEY") ? strtoull(getenv("PYNQS_FILTER_PER_KEY"), nullptr, 10) : 8;
   while (2 * b <= per_key * (uint64_t)nkeys && 2 * b <= cap) b <<= 1;
   return b >= (uint64_t)nkeys ? (uint32_t)b : 0u;  // below one bit per key it rejects too little
+}
+
+// Second-level filter (stays in global memory, L2-resident): 32 bits per key on the second Zobrist hash, asked only
+// for the columns that passed the LDS filter, 64 of them at a time.  With 2-8 bits per key the LDS filter lets 5-15 %
+// of the columns through; at sorb 120 the integral gathers and table probes of those false positives were the
+// kernel's HBM traffic.
+inline uint32_t hash_filter2_bits(int64_t nkeys) {  // host side; 0 when there is no LDS filter either
+  if (hash_filter_bits(nkeys) == 0) return 0;
+  uint64_t b = 1u << 15;
+  while (b < 32ull * (uint64_t)nkeys && b < (1u << 26)) b <<= 1;
+  return (uint32_t)b;
 }
 
 // the two filter bits of a key: the low and the high log2(fbits) bits of its Zobrist hash (fbits = 2^k, 10 <= k <= 18)

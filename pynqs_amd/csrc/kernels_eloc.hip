@@ -133,10 +133,22 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
 // the orbitals it flips (detcore.h) -- no integral, no x'.  The ranks that pass are parked in a wave-private LDS
 // queue, and whenever 64 are waiting the wave evaluates them together, all lanes busy: matrix element and x' from
 // the rank (the same helpers as everywhere else), probe, accumulate.
-constexpr uint32_t kQueue = 128;  // ranks a wave can park: < 64 left over + 64 new ones
-__host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits) { return fbits / 8 + 4 * 192 + (kBlock / 64) * 2 * kQueue * 4; }
+// Two queues per kind (doubles, singles): ranks that passed the LDS filter wait for the second-level filter (global
+// memory, its own Zobrist hash, 32 bits per key), the ones that pass that wait for their evaluation.  Singles are kept
+// apart from doubles: one costs nele gathers, and a lane-per-candidate loop over them lasts as long for one single
+// among 63 doubles as for 64 singles.
+// Queue sizes: < 64 left over + what is parked between two pumps (one level: a pump after every group of 64 ranks).
+__host__ __device__ constexpr uint32_t q1_doubles(bool two) { return two ? 320u : 128u; }
+constexpr uint32_t kQ1Singles = 128, kQ2 = 128;
+__host__ __device__ constexpr uint32_t queue_words(bool two) { return q1_doubles(two) + kQ1Singles + (two ? 2 * kQ2 : 0u); }
+__host__ __device__ constexpr uint32_t z_bytes(int sorb) { return 4u * (((uint32_t)sorb + 15u) & ~15u); }  // one Z[orbital] table
+__host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits, int sorb, bool two) {
+  return fbits / 8 + (two ? 2 : 1) * z_bytes(sorb) + (kBlock / 64) * queue_words(two) * 4;
+}
 
-template <int LEN, bool CPLX>
+// TWO = false: no second level, queue 1 is evaluated directly (strong LDS filter, or many true hits: the second level
+// then only adds work).
+template <int LEN, bool CPLX, bool TWO>
 struct Candidates {
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   const SDParams &p;
@@ -148,20 +160,32 @@ struct Candidates {
   const uint64_t *__restrict__ table;
   uint64_t cap;
   const double *__restrict__ wf;
-  uint32_t filt, fbits;  // LDS address and size of the filter
-  uint32_t zorb;         // LDS address of Z[orbital]
-  uint32_t queue;        // LDS address of this wave's two queues (doubles, singles)
-  uint32_t zx;           // Zobrist hash of the walker
-  uint32_t qn, sn;       // parked doubles / singles (wave-uniform)
+  const uint32_t *__restrict__ filt2;  // second-level filter
+  uint32_t f2bits;
+  uint32_t filt, fbits;  // LDS address and size of the first filter
+  uint32_t zorb;         // LDS address of Z[orbital] (z_bytes), followed by the second level's Z2[orbital] if TWO
+  uint32_t queue;        // LDS address of this wave's queues: doubles 1, singles 1, doubles 2, singles 2
+  uint32_t zx, zx2;      // Zobrist hashes of the walker
+  uint32_t n1[2], n2[2]; // entries of the queues, [0] doubles, [1] singles (wave-uniform)
   double re, im;
 
   __device__ __forceinline__ uint32_t Z(uint32_t orbital_times_4) const { return *reinterpret_cast<lds_u32 *>(zorb + orbital_times_4); }
-  // Zobrist hash of x' from the table entries of its excitation (orbital | orbital << 8 | ...)
+  // Zobrist hash of the orbitals of a table entry (orbital | orbital << 8 | ...)
   __device__ __forceinline__ uint32_t flipped(uint32_t e) const { return Z((e << 2) & 0x3fcu) ^ Z((e >> 6) & 0x3fcu); }
+  __device__ __forceinline__ uint32_t flipped2(uint32_t e) const {
+    const uint32_t z2 = z_bytes(p.sorb);
+    return Z(z2 + ((e << 2) & 0x3fcu)) ^ Z(z2 + ((e >> 6) & 0x3fcu));
+  }
   __device__ __forceinline__ bool maybe(uint32_t z) const {  // false: certainly not in the table
     uint32_t b0, b1;
     filter_positions(z, fbits, b0, b1);
     const uint32_t w0 = *reinterpret_cast<lds_u32 *>(filt + 4u * (b0 >> 5)), w1 = *reinterpret_cast<lds_u32 *>(filt + 4u * (b1 >> 5));
+    return ((w0 >> (b0 & 31u)) & (w1 >> (b1 & 31u)) & 1u) != 0u;
+  }
+  __device__ __forceinline__ bool maybe2(uint32_t z2) const {
+    uint32_t b0, b1;
+    filter_positions(z2, f2bits, b0, b1);
+    const uint32_t w0 = filt2[b0 >> 5], w1 = filt2[b1 >> 5];
     return ((w0 >> (b0 & 31u)) & (w1 >> (b1 & 31u)) & 1u) != 0u;
   }
   __device__ __forceinline__ void value(int64_t pos, double &vr, double &vi) const {  // psi of table entry pos, 0 if pos < 0
@@ -180,18 +204,66 @@ struct Candidates {
     re += h * vr;
     if constexpr (CPLX) im += h * vi;
   }
-  // evaluate the top n parked ranks of one queue (all 64 lanes active, n <= min(count, 64)).  LDS operations of a wave
-  // execute in order.  Singles have their own queue: one costs nele gathers, and a lane-per-candidate loop over them
-  // lasts as long for one single among 63 doubles as for 64 singles.
+  template <bool SINGLES, int STAGE>
+  __device__ __forceinline__ uint32_t qaddr() const {
+    return queue + 4u * (STAGE == 1 ? (SINGLES ? q1_doubles(TWO) : 0u) : q1_doubles(TWO) + kQ1Singles + (SINGLES ? kQ2 : 0u));
+  }
+  // all 64 lanes active (so are all callers below); LDS operations of a wave execute in order
+  template <bool SINGLES, int STAGE>
+  __device__ __forceinline__ void park(uint32_t r, bool pass) {
+    const uint64_t m = __ballot(pass);
+    if (!m) return;
+    uint32_t &count = STAGE == 1 ? n1[SINGLES] : n2[SINGLES];
+    if (pass) {
+      const uint32_t lane = threadIdx.x & 63;
+      *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, STAGE>() + 4u * (count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))) = r;
+    }
+    count = __builtin_amdgcn_readfirstlane(count + (uint32_t)__popcll(m));
+  }
+  // the two table entries of double rank r (any class)
+  __device__ __forceinline__ void double_entries(uint32_t r, uint32_t &e0, uint32_t &e1) const {
+    const bool opp = r >= p.d3;
+    const int spin = r >= p.d2;
+    const DoubleClass c = opp ? make_opp_spin(p, pl) : make_same_spin(p, pl, spin);
+    uint32_t slow, u;
+    class_split(r, c, slow, u);
+    uint32_t f = u + c.rot;
+    f = f >= c.nfast ? f - c.nfast : f;
+    e0 = L.tab[c.off_fast + f];
+    e1 = L.tab[c.off_slow + slow];
+  }
+  // second-level filter for the top n <= 64 ranks of queue 1; survivors move to queue 2
   template <bool SINGLES>
-  __device__ __forceinline__ void drain(uint32_t n) {
+  __device__ __forceinline__ void stage1(uint32_t n) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t &count = SINGLES ? sn : qn;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t r = 0;
+    bool pass = false;
+    if (lane < n) {
+      r = *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, 1>() + 4u * (n1[SINGLES] - n + lane));
+      uint32_t z2 = zx2;
+      if constexpr (SINGLES) z2 ^= flipped2(L.tab[p.offSa + r]);
+      else {
+        uint32_t e0, e1;
+        double_entries(r, e0, e1);
+        z2 ^= flipped2(e0) ^ flipped2(e1);
+      }
+      pass = maybe2(z2);
+    }
+    n1[SINGLES] = __builtin_amdgcn_readfirstlane(n1[SINGLES] - n);
+    __builtin_amdgcn_wave_barrier();
+    park<SINGLES, 2>(r, pass);
+  }
+  // evaluation of the top n <= 64 ranks of queue STAGE: matrix element, x', probe, accumulate
+  template <bool SINGLES, int STAGE>
+  __device__ __forceinline__ void evaluate(uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t &count = STAGE == 1 ? n1[SINGLES] : n2[SINGLES];
     __builtin_amdgcn_wave_barrier();
     double h = 0.0;
     int64_t pos = -1;
     if (lane < n) {
-      const uint32_t r = *reinterpret_cast<lds_u32 *>(queue + (SINGLES ? 4u * kQueue : 0u) + 4u * (count - n + lane));
+      const uint32_t r = *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, STAGE>() + 4u * (count - n + lane));
       uint64_t ket[LEN];
       if constexpr (SINGLES) {
         h = fast_single<double>(r, p, pl, L, nocc, plan);
@@ -209,27 +281,38 @@ struct Candidates {
     __builtin_amdgcn_wave_barrier();
     add(h, pos);
   }
+  // work off whole batches of 64
   template <bool SINGLES>
-  __device__ __forceinline__ void park(uint32_t r, bool pass) {  // all 64 lanes active
-    const uint64_t m = __ballot(pass);
-    if (!m) return;
-    uint32_t &count = SINGLES ? sn : qn;
-    if (pass) {
-      const uint32_t lane = threadIdx.x & 63;
-      *reinterpret_cast<lds_u32 *>(queue + (SINGLES ? 4u * kQueue : 0u) + 4u * (count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))) = r;
+  __device__ __forceinline__ void pump() {
+    while (n1[SINGLES] >= 64u) {
+      if constexpr (TWO) {
+        stage1<SINGLES>(64u);
+        if (n2[SINGLES] >= 64u) evaluate<SINGLES, 2>(64u);
+      } else {
+        evaluate<SINGLES, 1>(64u);
+      }
     }
-    count = __builtin_amdgcn_readfirstlane(count + (uint32_t)__popcll(m));
-    if (count >= 64u) drain<SINGLES>(64u);
+  }
+  // ... and everything that is left
+  template <bool SINGLES>
+  __device__ __forceinline__ void flush() {
+    pump<SINGLES>();
+    if constexpr (TWO) {
+      if (n1[SINGLES]) stage1<SINGLES>(n1[SINGLES]);
+      while (n2[SINGLES]) evaluate<SINGLES, 2>(min(n2[SINGLES], 64u));
+    } else {
+      if (n1[SINGLES]) evaluate<SINGLES, 1>(n1[SINGLES]);
+    }
   }
 };
 
-template <int LEN, bool CPLX>
+template <int LEN, bool CPLX, bool TWO>
 __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
                                                                             uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
                                                                             const double *__restrict__ plan,
                                                                             const uint64_t *__restrict__ table, int64_t cap,
                                                                             const double *__restrict__ wf, double *__restrict__ acc,
-                                                                            double *__restrict__ psi0, uint32_t fbits) {
+                                                                            double *__restrict__ psi0, uint32_t fbits, uint32_t f2bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double red[2][kBlock / 64];
   __shared__ uint32_t next_tile;
@@ -241,25 +324,28 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
-  // after the walker tables (no staging scratch: order-free singles / diagonal): filter, Z[orbital], the waves' queues
-  const uint32_t filt_off = (uint32_t)((lds_bytes(p, 0) + 15) & ~(size_t)15), z_off = filt_off + fbits / 8, q_off = z_off + 4 * 192;
+  // after the walker tables (no staging scratch: order-free singles / diagonal): filter, Z[orbital], Z2[orbital], the waves' queues
+  const uint32_t filt_off = (uint32_t)((lds_bytes(p, 0) + 15) & ~(size_t)15), z_off = filt_off + fbits / 8, q_off = z_off + (TWO ? 2 : 1) * z_bytes(p.sorb);
+  const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(table + (uint64_t)cap * hash_slot_words(LEN));
   {
-    const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(table + (uint64_t)cap * hash_slot_words(LEN));
     uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
     for (uint32_t i = tid; i < fbits / 32; i += kBlock) lf[i] = gf[i];
     uint32_t *lz = reinterpret_cast<uint32_t *>(smem + z_off);
-    if (tid < 192) lz[tid] = zobrist32((uint32_t)tid);
+    if (tid < p.sorb) {
+      lz[tid] = zobrist32((uint32_t)tid);
+      if constexpr (TWO) lz[z_bytes(p.sorb) / 4 + tid] = zobrist32b((uint32_t)tid);
+    }
   }
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier: filter and Z are visible
-  uint32_t zx = 0;
+  uint32_t zx = 0, zx2 = 0;
 #pragma unroll
   for (int w = 0; w < LEN; ++w)
-    if ((wk.w[w] >> lane) & 1ull) zx ^= zobrist32(64u * w + (uint32_t)lane);
+    if ((wk.w[w] >> lane) & 1ull) { zx ^= zobrist32(64u * w + (uint32_t)lane); zx2 ^= zobrist32b(64u * w + (uint32_t)lane); }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) zx ^= __shfl_xor(zx, o);
+  for (int o = 32; o > 0; o >>= 1) { zx ^= __shfl_xor(zx, o); zx2 ^= __shfl_xor(zx2, o); }
   const uint32_t dyn = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
-  Candidates<LEN, CPLX> cand{p, pl, L, wk, nocc, plan, table, (uint64_t)cap, wf, dyn + filt_off, fbits, dyn + z_off,
-                             dyn + q_off + (uint32_t)(tid >> 6) * (2u * kQueue * 4u), zx, 0u, 0u, 0.0, 0.0};
+  Candidates<LEN, CPLX, TWO> cand{p, pl, L, wk, nocc, plan, table, (uint64_t)cap, wf, gf + fbits / 32, f2bits, dyn + filt_off, fbits, dyn + z_off,
+                             dyn + q_off + (uint32_t)(tid >> 6) * (queue_words(TWO) * 4u), zx, zx2, {0u, 0u}, {0u, 0u}, 0.0, 0.0};
 
   // tiles: 0 = column 0; 1 = this workgroup's share of the singles (blocks of 64 dealt round-robin over the walker's
   // workgroups, as in plan_tiles.h) -- one wave takes them all, so that its singles queue fills; then 256 ranks of one
@@ -295,9 +381,10 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
       for (uint32_t r0 = chunk * 64u; r0 < p.d1; r0 += nchunks * 64u) {
         const uint32_t r = r0 + (uint32_t)lane;
         const uint32_t e = L.tab[p.offSa + min(r, p.d1 - 1)];
-        cand.template park<true>(r, (r < p.d1) & cand.maybe(zx ^ cand.flipped(e)));
+        cand.template park<true, 1>(r, (r < p.d1) & cand.maybe(zx ^ cand.flipped(e)));
+        cand.template pump<true>();
       }
-      if (cand.sn) cand.template drain<true>(cand.sn);
+      cand.template flush<true>();
       continue;
     }
     tile -= 2;
@@ -327,9 +414,13 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
       u = u >= c.nfast ? u - c.nfast : u;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cand.template park<false>(rr[j], pass[j]);
+    for (int j = 0; j < 4; ++j) {
+      cand.template park<false, 1>(rr[j], pass[j]);
+      if constexpr (!TWO) cand.template pump<false>();
+    }
+    if constexpr (TWO) cand.template pump<false>();
   }
-  if (cand.qn) cand.template drain<false>(cand.qn);
+  cand.template flush<false>();
   store_walker_sum<CPLX>(cand.re, cand.im, red, nchunks, walker, acc);
 }
 
@@ -337,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
 // (lookups only start after the build kernel has finished).
 template <int LEN>
 __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__restrict__ keys, int64_t nkeys, uint64_t cap,
-                                                            uint64_t *__restrict__ table, uint32_t fbits) {
+                                                            uint64_t *__restrict__ table, uint32_t fbits, uint32_t f2bits) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nkeys) return;
   uint64_t q[LEN];
@@ -353,9 +444,14 @@ __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__re
 #pragma unroll
       for (int w = 0; w < LEN; ++w) table[s * W + w] = q[w];
       if (fbits) {
-        uint32_t b0, b1;
-        filter_positions(zobrist_of<LEN>(q), fbits, b0, b1);
+        uint32_t z, z2, b0, b1;
+        zobrist_of<LEN>(q, z, z2);
         uint32_t *filter = reinterpret_cast<uint32_t *>(table + cap * W);
+        filter_positions(z, fbits, b0, b1);
+        atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
+        atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
+        filter += fbits / 32;  // second level
+        filter_positions(z2, f2bits, b0, b1);
         atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
         atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
       }
@@ -519,7 +615,11 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   uint32_t nchunks, chunk_len;
   plan_chunks(nbatch, p.nsd + 1, &nchunks, &chunk_len);
   const uint32_t fbits = hash ? hash_filter_bits(nkeys) : 0u;
-  const size_t lds = ((lds_bytes(p, 0) + 15) & ~(size_t)15) + (fbits ? filtered_extra_lds(fbits) : 0);
+  // second-level filter when the LDS one has fewer than 6 bits per key (it then lets > 8 % of the columns through);
+  // PYNQS_FILTER2=0/1 forces it off / on
+  static const int f2env = getenv("PYNQS_FILTER2") ? atoi(getenv("PYNQS_FILTER2")) : -1;
+  const bool two_level = f2env >= 0 ? f2env != 0 : (uint64_t)fbits < 6ull * (uint64_t)nkeys;
+  const size_t lds = ((lds_bytes(p, 0) + 15) & ~(size_t)15) + (fbits ? filtered_extra_lds(fbits, sorb, two_level) : 0);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;
@@ -535,9 +635,15 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
     hipLaunchKernelGGL((KERNEL), PYNQS_SS_ARGS, ##__VA_ARGS__);                                                                   \
   } while (0)
   DISPATCH_LEN(len, {
-    if (fbits) {  // hash table with its filter
-      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true>), fbits);
-      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false>), fbits);
+    if (fbits) {  // hash table with its filters
+      const uint32_t f2bits = hash_filter2_bits(nkeys);
+      if (two_level) {
+        if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, true>), fbits, f2bits);
+        else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, true>), fbits, f2bits);
+      } else {
+        if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, false>), fbits, f2bits);
+        else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, false>), fbits, f2bits);
+      }
     } else if (wf_is_complex) {
       if (hash) PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, true, true>)); else PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, true, false>));
     } else {
@@ -568,7 +674,7 @@ extern "C" int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch,
 extern "C" int64_t pynqs_hash_bytes(int64_t nkeys, int sorb) {
   if (nkeys < 0 || sorb < 1 || sorb > kMaxSorb) return -1;
   const int len = (sorb - 1) / 64 + 1;
-  return (int64_t)(hash_capacity(nkeys) * (uint64_t)hash_slot_words(len) * 8 + hash_filter_bits(nkeys) / 8);
+  return (int64_t)(hash_capacity(nkeys) * (uint64_t)hash_slot_words(len) * 8 + hash_filter_bits(nkeys) / 8 + hash_filter2_bits(nkeys) / 8);
 }
 
 extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, void *table, void *stream) {
@@ -581,10 +687,11 @@ extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, v
   const size_t slot_bytes = cap * (size_t)hash_slot_words(len) * 8;
   const uint32_t fbits = hash_filter_bits(nkeys);
   if (hipMemsetAsync(table, 0xFF, slot_bytes, st) != hipSuccess) return check_launch("hash memset");
-  if (fbits && hipMemsetAsync((char *)table + slot_bytes, 0, fbits / 8, st) != hipSuccess) return check_launch("filter memset");
+  const uint32_t f2bits = hash_filter2_bits(nkeys);
+  if (fbits && hipMemsetAsync((char *)table + slot_bytes, 0, fbits / 8 + f2bits / 8, st) != hipSuccess) return check_launch("filter memset");
   if (nkeys == 0) return PYNQS_OK;
   const uint32_t grid = (uint32_t)((nkeys + kBlock - 1) / kBlock);
-  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table, fbits));
+  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table, fbits, f2bits));
   return check_launch("hash_build");
 }
 
