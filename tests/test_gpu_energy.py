@@ -296,3 +296,63 @@ def test_reduce_compaction_large_system():
     assert torch.equal(row, r2) and torch.equal(col.long(), c2)
     assert torch.equal(h, hm[keep]) and torch.equal(onv, comb[keep])
     assert torch.equal(counts, keep.sum(1))
+
+
+def _random_walkers(rng, n, sorb, no):
+    k = sorb // 2
+    L = (sorb - 1) // 64 + 1
+    words = np.zeros((n, L), dtype=np.uint64)
+    for spin in (0, 1):
+        orb = 2 * np.argsort(rng.random((n, k)), axis=1)[:, :no] + spin
+        for c in range(no):
+            o = orb[:, c]
+            np.bitwise_or.at(words, (np.arange(n), o // 64), np.uint64(1) << (o % 64).astype(np.uint64))
+    return words
+
+
+def _excite(rng, words, sorb, count, singles):
+    """`count` determinants, each a single (one spin) or an alpha-beta double excitation of one of `words`."""
+    n = words.shape[0]
+    src = words[np.arange(count) % n].copy()
+    orb = np.arange(sorb)
+    occ = ((src[:, orb // 64] >> (orb % 64).astype(np.uint64)) & np.uint64(1)).astype(bool)
+    rows = np.arange(count)
+    for spin in ((0,) if singles else (0, 1)):
+        same = (orb % 2 == spin)[None, :]
+        score = rng.random((count, sorb))
+        for o in (np.argmax(np.where(occ & same, score, -1.0), axis=1), np.argmax(np.where(~occ & same, score, -1.0), axis=1)):
+            src[rows, o // 64] ^= np.uint64(1) << (o % 64).astype(np.uint64)
+    return src
+
+
+@pytest.mark.parametrize("sorb,no,nkeys", [(40, 5, 150), (40, 5, 200), (72, 6, 150), (72, 6, 200), (136, 4, 3000), (136, 4, 5000)])
+def test_sample_space_kernel_filter_levels(sorb, no, nkeys):
+    """The fused SAMPLE_SPACE kernel with its candidate filters (Zobrist hash in LDS; second level in global memory
+    when the first has < 6 bits per key: 200 and 5000 keys here, 150 and 3000 keys take the one-level kernel) against
+    the oracle, on sample spaces that hold the walkers, singles and doubles of them, and unrelated determinants."""
+    from oracle import oracle as O
+    from pynqs_amd import energy, public_function as pf
+
+    rng = np.random.default_rng(1000 * sorb + nkeys)
+    dev = torch.device("cuda")
+    n = 24
+    x = _random_walkers(rng, n, sorb, no)
+    pool = np.concatenate([x, _excite(rng, x, sorb, nkeys // 3, True), _excite(rng, x, sorb, nkeys // 3, False),
+                           _random_walkers(rng, nkeys, sorb, no)])
+    keys = np.unique(pool, axis=0)
+    keys = keys[rng.permutation(keys.shape[0])[:nkeys]]
+    keys = np.unique(np.concatenate([x, keys]), axis=0)
+    wf = rng.standard_normal(keys.shape[0]) + 1j * rng.standard_normal(keys.shape[0])
+    h1 = rng.standard_normal((sorb, sorb)); h1 = (h1 + h1.T).reshape(-1)
+    pair = sorb * (sorb - 1) // 2
+    h2 = rng.standard_normal(pair * (pair + 1) // 2)
+    L = x.shape[1]
+    tb = lambda w: torch.from_numpy(w.view(np.uint8).reshape(-1, 8 * L)).to(dev)
+    lut = pf.WavefunctionLUT(tb(keys), torch.from_numpy(wf).to(dev), sorb, device=dev)
+    assert lut.hashtable is not None
+    e, _, p0, _ = energy.local_energy(tb(x), torch.from_numpy(h1).to(dev), torch.from_numpy(h2).to(dev), None, None, sorb, 2 * no, no, no,
+                                      WF_LUT=lut, use_sample_space=True, dtype=torch.complex128)
+    e_ref, p_ref = O.eloc_sample_space(x.view(np.uint8).reshape(n, 8 * L), h1, h2, sorb, 2 * no, no, no, lut.bra_key.cpu().numpy(),
+                                       lut.wf_value.cpu().numpy())
+    np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
