@@ -76,8 +76,8 @@ struct LookupSink {
 // Sum of a workgroup's per-lane partial sums into acc[walker]: lanes (xor butterfly), then waves, in a fixed order.
 // (Which tile a wave gets is dynamic, so the order of the additions inside a lane, and with it the last bits of the
 // sum, can vary from run to run; with more than one chunk per walker the chunks meet through float atomics.)
-template <bool CPLX>
-__device__ __forceinline__ void store_walker_sum(double re, double im, double (*red)[kBlock / 64], uint32_t nchunks, uint64_t walker,
+template <bool CPLX, int NW>
+__device__ __forceinline__ void store_walker_sum(double re, double im, double (*red)[NW], uint32_t nchunks, uint64_t walker,
                                                  double *__restrict__ acc) {
   const int tid = threadIdx.x;
 #pragma unroll
@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_walker_sum(double re, double im, double (*
   __syncthreads();
   if (tid == 0) {
     double sr = 0.0, si = 0.0;
-    for (int w = 0; w < kBlock / 64; ++w) { sr += red[0][w]; si += red[1][w]; }
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { sr += red[0][w]; si += red[1][w]; }
     if (nchunks == 1) {
       if constexpr (CPLX) { acc[2 * walker] = sr; acc[2 * walker + 1] = si; }
       else acc[walker] = sr;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier
   LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0};
   visit_tiles<LEN, double, LookupSink<LEN, CPLX, HASH>, false>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
-  store_walker_sum<CPLX>(sink.re, sink.im, red, nchunks, walker, acc);
+  store_walker_sum<CPLX, kBlock / 64>(sink.re, sink.im, red, nchunks, walker, acc);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -142,8 +142,12 @@ __host__ __device__ constexpr uint32_t q1_doubles(bool two) { return two ? 320u 
 constexpr uint32_t kQ1Singles = 128, kQ2 = 128;
 __host__ __device__ constexpr uint32_t queue_words(bool two) { return q1_doubles(two) + kQ1Singles + (two ? 2 * kQ2 : 0u); }
 __host__ __device__ constexpr uint32_t z_bytes(int sorb) { return 4u * (((uint32_t)sorb + 15u) & ~15u); }  // one Z[orbital] table
-__host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits, int sorb, bool two) {
-  return fbits / 8 + (two ? 2 : 1) * z_bytes(sorb) + (kBlock / 64) * queue_words(two) * 4;
+// Workgroups of 256 threads, or of 512 when tables + filter leave room for only two workgroups per CU (sorb >~ 100): the
+// waves of a workgroup share them, so that doubles the waves in flight (multi-word determinants only: one-word systems
+// never get there).
+constexpr int kBigBlock = 512;
+__host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits, int sorb, bool two, int block) {
+  return fbits / 8 + (two ? 2 : 1) * z_bytes(sorb) + (size_t)(block / 64) * queue_words(two) * 4;
 }
 
 // TWO = false: no second level, queue 1 is evaluated directly (strong LDS filter, or many true hits: the second level
@@ -220,17 +224,31 @@ struct Candidates {
     }
     count = __builtin_amdgcn_readfirstlane(count + (uint32_t)__popcll(m));
   }
-  // the two table entries of double rank r (any class)
-  __device__ __forceinline__ void double_entries(uint32_t r, uint32_t &e0, uint32_t &e1) const {
-    const bool opp = r >= p.d3;
-    const int spin = r >= p.d2;
-    const DoubleClass c = opp ? make_opp_spin(p, pl) : make_same_spin(p, pl, spin);
-    uint32_t slow, u;
-    class_split(r, c, slow, u);
-    uint32_t f = u + c.rot;
-    f = f >= c.nfast ? f - c.nfast : f;
-    e0 = L.tab[c.off_fast + f];
-    e1 = L.tab[c.off_slow + slow];
+  // With two levels a parked double is its class and its two table indices, class << 30 | slow << 15 | fast (class 0 / 1: same spin
+  // alpha / beta, 2: opposite spin; both indices < 2^15 for sorb <= 192): no division and no class branches afterwards.
+  static __device__ __forceinline__ uint32_t pack(int k, uint32_t slow, uint32_t f) { return ((uint32_t)k << 30) | (slow << 15) | f; }
+  __device__ __forceinline__ void double_entries(uint32_t code, uint32_t &i0, uint32_t &i1) const {  // indices into L.tab / L.msk
+    const uint32_t k = code >> 30;
+    i0 = (uint32_t)(k == 0 ? p.offHPa : (k == 1 ? p.offHPb : p.offSa)) + (code & 0x7fffu);
+    i1 = (uint32_t)(k == 0 ? p.offPPa : (k == 1 ? p.offPPb : p.offSb)) + ((code >> 15) & 0x7fffu);
+  }
+  __device__ __forceinline__ double double_value(uint32_t code, uint64_t (&ket)[LEN]) const {
+    const uint32_t k = code >> 30;
+    uint32_t i0, i1;
+    double_entries(code, i0, i1);
+    PendingDouble<double> d;
+    d.e0 = L.tab[i0];
+    d.e1 = L.tab[i1];
+    if constexpr (LEN == 1) { d.k0 = L.msk[i0]; d.k1 = L.msk[i1]; }
+    DoubleClass c;
+    c.opposite = k == 2;
+    if (c.opposite) {  // (branches rather than selects: the table bases stay scalar)
+      d.v = plan[pl.offVab + __umul24((d.e1 >> 17) & 0x7fffu, (uint32_t)(pl.K * pl.K)) + ((d.e0 >> 17) & 0x7fffu)];
+    } else {
+      const double *__restrict__ V = plan + pl.offVss + (size_t)k * pl.NP * pl.NP;
+      d.v = V[__umul24((d.e1 >> 17) & 0x1fffu, (uint32_t)pl.NP) + ((d.e0 >> 17) & 0x1fffu)];
+    }
+    return finish_double<LEN, double>(d, c, wk, ket);
   }
   // second-level filter for the top n <= 64 ranks of queue 1; survivors move to queue 2
   template <bool SINGLES>
@@ -244,9 +262,9 @@ struct Candidates {
       uint32_t z2 = zx2;
       if constexpr (SINGLES) z2 ^= flipped2(L.tab[p.offSa + r]);
       else {
-        uint32_t e0, e1;
-        double_entries(r, e0, e1);
-        z2 ^= flipped2(e0) ^ flipped2(e1);
+        uint32_t i0, i1;
+        double_entries(r, i0, i1);
+        z2 ^= flipped2(L.tab[i0]) ^ flipped2(L.tab[i1]);
       }
       pass = maybe2(z2);
     }
@@ -273,7 +291,9 @@ struct Candidates {
         toggle<LEN>(ket, e & 0xff);
         toggle<LEN>(ket, (e >> 8) & 0xff);
       } else {
-        h = double_element<LEN, double>(r, p, pl, L, plan, wk, ket);
+        // (one level: the queue holds plain ranks -- the packed form costs this variant 16 more VGPRs and a wave per SIMD)
+        if constexpr (TWO) h = double_value(r, ket);
+        else h = double_element<LEN, double>(r, p, pl, L, plan, wk, ket);
       }
       pos = hash_find<LEN>(table, cap, ket);
     }
@@ -306,15 +326,15 @@ struct Candidates {
   }
 };
 
-template <int LEN, bool CPLX, bool TWO>
-__global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
+template <int LEN, bool CPLX, bool TWO, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
                                                                             uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
                                                                             const double *__restrict__ plan,
                                                                             const uint64_t *__restrict__ table, int64_t cap,
                                                                             const double *__restrict__ wf, double *__restrict__ acc,
                                                                             double *__restrict__ psi0, uint32_t fbits, uint32_t f2bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ double red[2][kBlock / 64];
+  __shared__ double red[2][BLOCK / 64];
   __shared__ uint32_t next_tile;
   uint64_t walker;
   uint32_t chunk;
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
   const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(table + (uint64_t)cap * hash_slot_words(LEN));
   {
     uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
-    for (uint32_t i = tid; i < fbits / 32; i += kBlock) lf[i] = gf[i];
+    for (uint32_t i = tid; i < fbits / 32; i += BLOCK) lf[i] = gf[i];
     uint32_t *lz = reinterpret_cast<uint32_t *>(smem + z_off);
     if (tid < p.sorb) {
       lz[tid] = zobrist32((uint32_t)tid);
@@ -403,9 +423,9 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // independent and branch-free: the LDS reads of the four groups overlap
       const uint32_t m = first + 64u * j + (uint32_t)lane;
-      rr[j] = g.r_e + m;
       uint32_t f = u + c.rot;
       f = f >= c.nfast ? f - c.nfast : f;
+      rr[j] = TWO ? cand.pack(k, slow, f) : g.r_e + m;
       // (lanes past the end of the class read a valid but meaningless entry: slow is clamped to the class's last row)
       const uint32_t z = zx ^ cand.flipped(L.tab[c.off_fast + f]) ^ cand.flipped(L.tab[c.off_slow + min(slow, nslow - 1u)]);
       pass[j] = (m <= last) & cand.maybe(z);
@@ -421,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_filtered_kernel(cons
     if constexpr (TWO) cand.template pump<false>();
   }
   cand.template flush<false>();
-  store_walker_sum<CPLX>(cand.re, cand.im, red, nchunks, walker, acc);
+  store_walker_sum<CPLX, BLOCK / 64>(cand.re, cand.im, red, nchunks, walker, acc);
 }
 
 // Insert key i of the sorted key array: claim a slot by CAS on its index word, then write the key words
@@ -619,14 +639,18 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   // PYNQS_FILTER2=0/1 forces it off / on
   static const int f2env = getenv("PYNQS_FILTER2") ? atoi(getenv("PYNQS_FILTER2")) : -1;
   const bool two_level = f2env >= 0 ? f2env != 0 : (uint64_t)fbits < 6ull * (uint64_t)nkeys;
-  const size_t lds = ((lds_bytes(p, 0) + 15) & ~(size_t)15) + (fbits ? filtered_extra_lds(fbits, sorb, two_level) : 0);
+  const size_t lds_fixed = (lds_bytes(p, 0) + 15) & ~(size_t)15;
+  static const int blk_env = getenv("PYNQS_SS_BLOCK") ? atoi(getenv("PYNQS_SS_BLOCK")) : 0;
+  const int block = (!fbits || len == 1) ? kBlock : (blk_env == 256 || blk_env == 512) ? blk_env
+                    : (lds_fixed + filtered_extra_lds(fbits, sorb, two_level, kBlock) > 52 * 1024 ? kBigBlock : kBlock);
+  const size_t lds = lds_fixed + (fbits ? filtered_extra_lds(fbits, sorb, two_level, block) : 0);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   const double *pd = (const double *)plan;
   const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
-#define PYNQS_SS_ARGS dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0
+#define PYNQS_SS_ARGS dim3((uint32_t)grid), dim3(block), lds, st, bra, p, pl, nchunks, chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0
 #define PYNQS_SS_LAUNCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                            \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -634,15 +658,23 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
       return check_launch("hipFuncSetAttribute");                                                                                \
     hipLaunchKernelGGL((KERNEL), PYNQS_SS_ARGS, ##__VA_ARGS__);                                                                   \
   } while (0)
+#define PYNQS_SS_FILTERED(B)                                                                                      \
+  do {                                                                                                            \
+    if (two_level) {                                                                                              \
+      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, true, B>), fbits, f2bits);  \
+      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, true, B>), fbits, f2bits);              \
+    } else {                                                                                                      \
+      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, false, B>), fbits, f2bits); \
+      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, false, B>), fbits, f2bits);             \
+    }                                                                                                             \
+  } while (0)
   DISPATCH_LEN(len, {
     if (fbits) {  // hash table with its filters
       const uint32_t f2bits = hash_filter2_bits(nkeys);
-      if (two_level) {
-        if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, true>), fbits, f2bits);
-        else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, true>), fbits, f2bits);
+      if constexpr (LEN >= 2) {
+        if (block == kBigBlock) PYNQS_SS_FILTERED(kBigBlock); else PYNQS_SS_FILTERED(kBlock);
       } else {
-        if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, false>), fbits, f2bits);
-        else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, false>), fbits, f2bits);
+        PYNQS_SS_FILTERED(kBlock);
       }
     } else if (wf_is_complex) {
       if (hash) PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, true, true>)); else PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, true, false>));
@@ -650,6 +682,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
       if (hash) PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, false, true>)); else PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, false, false>));
     }
   });
+#undef PYNQS_SS_FILTERED
 #undef PYNQS_SS_ARGS
 #undef PYNQS_SS_LAUNCH
   const uint32_t g2 = (uint32_t)((nbatch + kBlock - 1) / kBlock);
