@@ -325,11 +325,13 @@ def _excite(rng, words, sorb, count, singles):
     return src
 
 
-@pytest.mark.parametrize("sorb,no,nkeys", [(40, 5, 150), (40, 5, 200), (72, 6, 150), (72, 6, 200), (136, 4, 3000), (136, 4, 5000)])
-def test_sample_space_kernel_filter_levels(sorb, no, nkeys):
+@pytest.mark.parametrize("sorb,no,nkeys,use_hash", [(40, 5, 150, True), (40, 5, 200, True), (72, 6, 150, True), (72, 6, 200, True),
+                                                    (136, 4, 3000, True), (136, 4, 5000, True), (40, 5, 300_000, True),
+                                                    (40, 5, 200, False), (136, 4, 3000, False)])
+def test_sample_space_kernel_filter_levels(sorb, no, nkeys, use_hash):
     """The fused SAMPLE_SPACE kernel with its candidate filters (Zobrist hash in LDS; second level in global memory
-    when the first has < 6 bits per key: 200 and 5000 keys here, 150 and 3000 keys take the one-level kernel) against
-    the oracle, on sample spaces that hold the walkers, singles and doubles of them, and unrelated determinants."""
+    when the first has < 6 bits per key: 200 and 5000 keys here, 150 and 3000 keys take the one-level kernel), without
+    them, and with the sorted-key search, against the oracle, on sample spaces that hold the walkers, singles and doubles of them, and unrelated determinants."""
     from oracle import oracle as O
     from pynqs_amd import energy, public_function as pf
 
@@ -348,8 +350,15 @@ def test_sample_space_kernel_filter_levels(sorb, no, nkeys):
     h2 = rng.standard_normal(pair * (pair + 1) // 2)
     L = x.shape[1]
     tb = lambda w: torch.from_numpy(w.view(np.uint8).reshape(-1, 8 * L)).to(dev)
-    lut = pf.WavefunctionLUT(tb(keys), torch.from_numpy(wf).to(dev), sorb, device=dev)
-    assert lut.hashtable is not None
+    # 300 000 keys: more than the LDS filter takes (< 1 bit per key) -> the unfiltered hash kernel; use_hash False: the
+    # binary search over the sorted keys, as the reference does
+    old_flag = pf.USE_HASH
+    pf.USE_HASH = use_hash
+    try:
+        lut = pf.WavefunctionLUT(tb(keys), torch.from_numpy(wf).to(dev), sorb, device=dev)
+    finally:
+        pf.USE_HASH = old_flag
+    assert (lut.hashtable is not None) == use_hash
     e, _, p0, _ = energy.local_energy(tb(x), torch.from_numpy(h1).to(dev), torch.from_numpy(h2).to(dev), None, None, sorb, 2 * no, no, no,
                                       WF_LUT=lut, use_sample_space=True, dtype=torch.complex128)
     e_ref, p_ref = O.eloc_sample_space(x.view(np.uint8).reshape(n, 8 * L), h1, h2, sorb, 2 * no, no, no, lut.bra_key.cpu().numpy(),
