@@ -391,7 +391,7 @@ class RbmFused(Workload):
                 "sample": f"{reps} x oracle eloc_simple_rbm (C restatement: materialise + RBM forward on every x', OpenMP) on the first {sample} walkers ({el:.1f} s)"}
 
 
-def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -> Workload:
+def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", keys: int = 65536) -> Workload:
     if name == "fe2s2_eloc_sample_space":
         d = load_fe2s2()
         ci = d["ci_space"]
@@ -416,13 +416,13 @@ def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan") -
         h1, h2 = synth_integrals(sorb)
         return RbmFused(f"syn{sorb}", sorb, 2 * no, no, no, h1, h2, synth_walkers(walkers, sorb, no, no, 4321 + rank), dev)
     if name.startswith("syn") and name.endswith("_eloc_sample_space"):
-        # sample space = this rank's walkers plus seeded double excitations of them (64 Ki keys): as in a VMC step, a tiny part of
+        # sample space = this rank's walkers plus seeded double excitations of them (`keys` of them, 64 Ki by default): as in a VMC step, a tiny part of
         # the connected space is in the table
         sorb = int(name[3:-18])
         no = {56: 7, 120: 30, 184: 46}.get(sorb, sorb // 4)
         h1, h2 = synth_integrals(sorb)
         x = synth_walkers(walkers, sorb, no, no, 4321 + rank)
-        more = synth_connected(x, sorb, max(65536 - walkers, 0), 99)
+        more = synth_connected(x, sorb, max(keys - walkers, 0), 99)
         keys = torch.unique(torch.cat([x, more]), dim=0)
         return SampleSpaceFused(f"syn{sorb}", sorb, 2 * no, no, no, h1, h2, x, keys, dev)
     if name.startswith("syn") and name.endswith("_dropin"):
@@ -443,6 +443,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="fe2s2_dropin")
     ap.add_argument("--walkers", type=int, default=8192, help="walkers per GPU")
+    ap.add_argument("--keys", type=int, default=65536, help="sample-space size of the syn<sorb>_eloc_sample_space workloads")
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
     ap.add_argument("--no-comb", action="store_true", help="diagnostic: skip the comb output (Hmat only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -465,7 +466,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    wl = make_workload(args.workload, args.walkers, rank, dev, args.path)
+    wl = make_workload(args.workload, args.walkers, rank, dev, args.path, args.keys)
     if args.no_comb:
         wl.comb_ptr = None
 

@@ -261,9 +261,11 @@ inline uint32_t hash_filter_bits(int64_t nkeys) {  // host side
 // Second-level filter (stays in global memory, L2-resident): 32 bits per key on the second Zobrist hash, asked only
 // for the columns that passed the LDS filter, 64 of them at a time.  With 2-8 bits per key the LDS filter lets 5-15 %
 // of the columns through; at sorb 120 the integral gathers and table probes of those false positives were the
-// kernel's HBM traffic.
-inline uint32_t hash_filter2_bits(int64_t nkeys) {  // host side; 0 when there is no LDS filter either
-  if (hash_filter_bits(nkeys) == 0) return 0;
+// kernel's HBM traffic.  Tables too large for an LDS filter (> 2^18 keys: less than one bit per key) use this one alone,
+// asked for every column.
+inline uint32_t hash_filter2_bits(int64_t nkeys) {  // host side
+  static const bool off = getenv("PYNQS_FILTER_BITS") && strtoull(getenv("PYNQS_FILTER_BITS"), nullptr, 10) == 0;
+  if (nkeys <= 0 || off) return 0;
   uint64_t b = 1u << 15;
   while (b < 32ull * (uint64_t)nkeys && b < (1u << 26)) b <<= 1;
   return (uint32_t)b;

@@ -181,6 +181,7 @@ struct Candidates {
     return Z(z2 + ((e << 2) & 0x3fcu)) ^ Z(z2 + ((e >> 6) & 0x3fcu));
   }
   __device__ __forceinline__ bool maybe(uint32_t z) const {  // false: certainly not in the table
+    if (!fbits) return maybe2(z);  // (wave-uniform) no LDS filter: the table is too large for one; Z[] then holds the second hash
     uint32_t b0, b1;
     filter_positions(z, fbits, b0, b1);
     const uint32_t w0 = *reinterpret_cast<lds_u32 *>(filt + 4u * (b0 >> 5)), w1 = *reinterpret_cast<lds_u32 *>(filt + 4u * (b1 >> 5));
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
     for (uint32_t i = tid; i < fbits / 32; i += BLOCK) lf[i] = gf[i];
     uint32_t *lz = reinterpret_cast<uint32_t *>(smem + z_off);
     if (tid < p.sorb) {
-      lz[tid] = zobrist32((uint32_t)tid);
+      lz[tid] = fbits ? zobrist32((uint32_t)tid) : zobrist32b((uint32_t)tid);
       if constexpr (TWO) lz[z_bytes(p.sorb) / 4 + tid] = zobrist32b((uint32_t)tid);
     }
   }
@@ -360,7 +361,10 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
   uint32_t zx = 0, zx2 = 0;
 #pragma unroll
   for (int w = 0; w < LEN; ++w)
-    if ((wk.w[w] >> lane) & 1ull) { zx ^= zobrist32(64u * w + (uint32_t)lane); zx2 ^= zobrist32b(64u * w + (uint32_t)lane); }
+    if ((wk.w[w] >> lane) & 1ull) {
+      zx2 ^= zobrist32b(64u * w + (uint32_t)lane);
+      zx ^= fbits ? zobrist32(64u * w + (uint32_t)lane) : zobrist32b(64u * w + (uint32_t)lane);
+    }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { zx ^= __shfl_xor(zx, o); zx2 ^= __shfl_xor(zx2, o); }
   const uint32_t dyn = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
@@ -463,17 +467,21 @@ __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__re
     if (old == ~0ull) {
 #pragma unroll
       for (int w = 0; w < LEN; ++w) table[s * W + w] = q[w];
-      if (fbits) {
+      if (fbits || f2bits) {
         uint32_t z, z2, b0, b1;
         zobrist_of<LEN>(q, z, z2);
         uint32_t *filter = reinterpret_cast<uint32_t *>(table + cap * W);
-        filter_positions(z, fbits, b0, b1);
-        atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
-        atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
-        filter += fbits / 32;  // second level
-        filter_positions(z2, f2bits, b0, b1);
-        atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
-        atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
+        if (fbits) {
+          filter_positions(z, fbits, b0, b1);
+          atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
+          atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
+          filter += fbits / 32;
+        }
+        if (f2bits) {  // second level
+          filter_positions(z2, f2bits, b0, b1);
+          atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
+          atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
+        }
       }
       return;
     }
@@ -638,12 +646,14 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   // second-level filter when the LDS one has fewer than 6 bits per key (it then lets > 8 % of the columns through);
   // PYNQS_FILTER2=0/1 forces it off / on
   static const int f2env = getenv("PYNQS_FILTER2") ? atoi(getenv("PYNQS_FILTER2")) : -1;
-  const bool two_level = f2env >= 0 ? f2env != 0 : (uint64_t)fbits < 6ull * (uint64_t)nkeys;
+  const uint32_t f2bits = hash ? hash_filter2_bits(nkeys) : 0u;
+  const bool filtered = fbits || f2bits;
+  const bool two_level = fbits && f2bits && (f2env >= 0 ? f2env != 0 : (uint64_t)fbits < 6ull * (uint64_t)nkeys);
   const size_t lds_fixed = (lds_bytes(p, 0) + 15) & ~(size_t)15;
   static const int blk_env = getenv("PYNQS_SS_BLOCK") ? atoi(getenv("PYNQS_SS_BLOCK")) : 0;
-  const int block = (!fbits || len == 1) ? kBlock : (blk_env == 256 || blk_env == 512) ? blk_env
+  const int block = (!filtered || len == 1) ? kBlock : (blk_env == 256 || blk_env == 512) ? blk_env
                     : (lds_fixed + filtered_extra_lds(fbits, sorb, two_level, kBlock) > 52 * 1024 ? kBigBlock : kBlock);
-  const size_t lds = lds_fixed + (fbits ? filtered_extra_lds(fbits, sorb, two_level, block) : 0);
+  const size_t lds = lds_fixed + (filtered ? filtered_extra_lds(fbits, sorb, two_level, block) : 0);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;
@@ -669,8 +679,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
     }                                                                                                             \
   } while (0)
   DISPATCH_LEN(len, {
-    if (fbits) {  // hash table with its filters
-      const uint32_t f2bits = hash_filter2_bits(nkeys);
+    if (filtered) {  // hash table with its filters
       if constexpr (LEN >= 2) {
         if (block == kBigBlock) PYNQS_SS_FILTERED(kBigBlock); else PYNQS_SS_FILTERED(kBlock);
       } else {
@@ -721,7 +730,7 @@ extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, v
   const uint32_t fbits = hash_filter_bits(nkeys);
   if (hipMemsetAsync(table, 0xFF, slot_bytes, st) != hipSuccess) return check_launch("hash memset");
   const uint32_t f2bits = hash_filter2_bits(nkeys);
-  if (fbits && hipMemsetAsync((char *)table + slot_bytes, 0, fbits / 8 + f2bits / 8, st) != hipSuccess) return check_launch("filter memset");
+  if ((fbits || f2bits) && hipMemsetAsync((char *)table + slot_bytes, 0, fbits / 8 + f2bits / 8, st) != hipSuccess) return check_launch("filter memset");
   if (nkeys == 0) return PYNQS_OK;
   const uint32_t grid = (uint32_t)((nkeys + kBlock - 1) / kBlock);
   DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table, fbits, f2bits));
