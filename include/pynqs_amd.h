@@ -137,6 +137,13 @@ int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, 
                                  const void *plan, const void *table, int64_t nkeys, const double *wf,
                                  int wf_is_complex, double *eloc, double *psi0, void *stream);
 
+/* ---- duplicates among determinants, without a sort (`Func`, vmc/energy/flip.py:44-50: torch.unique(dim=0,
+ * return_inverse=True) on the x' that reach the ansatz).  first[i] = smallest j with onv[j] == onv[i] (int32[n]);
+ * the rows with first[i] == i are the distinct determinants in order of first appearance.  Deterministic.
+ *   pynqs_unique_workspace : [host] bytes of scratch for n rows (-1: n out of range, n < 2^30)             */
+int64_t pynqs_unique_workspace(int64_t n);
+int pynqs_unique_first(const uint64_t *onv, int64_t n, int sorb, void *workspace, int32_t *first, void *stream);
+
 /* ---- SIMPLE method with a real RBM amplitude, fully fused, f64 -------------------------------------------
  * vmc/energy/eloc.py:121-203 (_simple: get_comb_hij_fused + ansatz on all nbatch*ncomb kets + contraction) for
  * the reference's RBMWavefunction with rbm_type "real" (vmc/ansatz/rbm/rbm.py:186-211):

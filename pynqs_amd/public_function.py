@@ -70,11 +70,26 @@ def torch_sort_onv(bra: Tensor, little_endian: bool = True) -> Tensor:
 
 def unique_onv(x: Tensor) -> Tuple[Tensor, Tensor]:
     """(unique rows, inverse) of a uint8 onv batch, like torch.unique(x, dim=0, return_inverse=True) up to the
-    ORDER of the unique rows (callers only use rows[inverse]; vmc/energy/flip.py:44-50).  torch's row-wise unique
-    sorts with a byte-by-byte comparator; here rows are compared as 64-bit words: one radix sort for one-word
-    determinants (3.3x faster on 7e5 Fe2S2 rows), len stable sorts otherwise."""
+    ORDER of the unique rows (callers only use rows[inverse]; vmc/energy/flip.py:44-50).  torch's row-wise unique is a
+    multi-pass sort; on the GPU the rows go through a hash table of row indices instead (pynqs_unique_first: every
+    row learns the first row with its determinant), and the unique rows come in order of first appearance:
+    0.27 -> 0.09 ms on the 7e5 kept x' of 8192 Fe2S2 walkers.  CPU tensors: word-wise sorts."""
     assert x.dim() == 2 and x.dtype == torch.uint8 and x.size(1) % 8 == 0
     n, L = x.size(0), x.size(1) // 8
+    if x.is_cuda and 0 < n < 2**30 and L <= 3:
+        from . import _native as N
+
+        xc = x.contiguous()
+        dev = x.device
+        ws = torch.empty(N.lib().pynqs_unique_workspace(n), dtype=torch.uint8, device=dev)
+        first = torch.empty(n, dtype=torch.int32, device=dev)
+        # any sorb with this word count gives the same kernel
+        N.check(N.lib().pynqs_unique_first(xc.data_ptr(), n, 64 * L, ws.data_ptr(), first.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                "pynqs_unique_first")
+        first = first.long()
+        is_rep = first == torch.arange(n, device=dev)
+        uid = torch.cumsum(is_rep, 0) - 1
+        return xc[is_rep], uid[first]
     words = x.contiguous().view(torch.int64)  # [n, L]
     if L == 1 or n == 0:
         u, inv = torch.unique(words.view(-1) if L == 1 else words, return_inverse=True, dim=0 if L > 1 else None)

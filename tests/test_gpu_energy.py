@@ -365,3 +365,26 @@ def test_sample_space_kernel_filter_levels(sorb, no, nkeys, use_hash):
                                        lut.wf_value.cpu().numpy())
     np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
     np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
+
+
+@pytest.mark.parametrize("L,n,distinct", [(1, 1, 1), (1, 1000, 7), (1, 700_000, 90_000), (2, 300_000, 300_000), (3, 250_000, 1000)])
+def test_unique_onv_on_gpu(L, n, distinct):
+    """public_function.unique_onv on the GPU (pynqs_unique_first: hash table of row indices, no sort) against
+    torch.unique(dim=0): same set of rows, rows[inverse] reproduces the input, unique rows in order of first appearance,
+    identical from run to run."""
+    from pynqs_amd.public_function import unique_onv
+
+    g = torch.Generator().manual_seed(100 * L + n % 97)
+    pool = torch.randint(-2**62, 2**62, (distinct, L), generator=g, dtype=torch.int64)
+    pool[:, -1] &= (1 << 40) - 1  # stay within 64 (L - 1) + 40 orbitals
+    x = pool[torch.randint(0, distinct, (n,), generator=g)].contiguous().view(torch.uint8).view(n, 8 * L).cuda()
+    u, inv = unique_onv(x)
+    assert torch.equal(u[inv], x)
+    ref = torch.unique(x, dim=0)
+    assert u.size(0) == ref.size(0)
+    assert torch.equal(torch.unique(u, dim=0), ref)
+    # order of first appearance
+    firsts = torch.full((u.size(0),), n, dtype=torch.int64, device=x.device).scatter_reduce(0, inv, torch.arange(n, device=x.device), "amin")
+    assert bool((firsts[1:] > firsts[:-1]).all())
+    u2, inv2 = unique_onv(x)
+    assert torch.equal(u, u2) and torch.equal(inv, inv2)
