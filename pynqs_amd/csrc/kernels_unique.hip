@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlock) void unique_insert_kernel(const uint64_t *_
 #pragma unroll
     for (int w = 0; w < LEN; ++w) same = same && onv[(int64_t)cur * LEN + w] == q[w];
     if (same) {
-      atomicMin(table + s, (int32_t)i);
+      if ((int32_t)i < cur) atomicMin(table + s, (int32_t)i);  // (a popular x' occurs thousands of times: no atomic unless it can lower the slot)
       break;
     }
     s = (s + 1) & mask;

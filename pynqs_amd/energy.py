@@ -265,11 +265,12 @@ def reduce_compact_sampled(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele:
     slot_row = torch.repeat_interleave(torch.arange(n, device=dev), draws_per_row)
     used = int(d_ends[-1].item()) if n else 0
     valid = s_col[:used] >= 0
-    s_row = slot_row[valid]
+    keep = torch.nonzero(valid).squeeze(1)  # one compaction for the four arrays
+    s_row = slot_row[keep]
     # records per walker: a segmented sum over its slot range (scatter_add_ here: 0.6 ms of atomics on 5 M rows)
     s_counts = torch.segment_reduce(valid.to(torch.float64), "sum", lengths=draws_per_row, unsafe=True).to(torch.int64) if used else \
         torch.zeros(n, dtype=torch.int64, device=dev)
-    return (row, col, onv, h, counts), (s_row, s_col[:used][valid], s_onv[:used][valid], s_h[:used][valid], s_counts)
+    return (row, col, onv, h, counts), (s_row, s_col[keep], s_onv[keep], s_h[keep], s_counts)
 
 
 def local_energy(
