@@ -391,6 +391,32 @@ class RbmFused(Workload):
                 "sample": f"{reps} x oracle eloc_simple_rbm (C restatement: materialise + RBM forward on every x', OpenMP) on the first {sample} walkers ({el:.1f} s)"}
 
 
+class DecoderAmplitude(torch.nn.Module):
+    """Stand-in for BASELINE.json's 'Transformer ansatz' (DecoderWaveFunction defaults d_model 32, 6 layers,
+    8 heads, vmc/ansatz/transformer/decoder.py:43-69): an autoregressive decoder over the sorb/2 spatial orbitals (4 occupation
+    states each), psi(x) = exp(1/2 sum_i log p(t_i | t_<i)) cos(phase).  Random weights (seed 7); ansatz families themselves are
+    outside this package -- this only gives the psi(x') calls of the local-energy path a realistic cost."""
+
+    def __init__(self, sorb: int, d_model: int = 32, n_layers: int = 6, n_heads: int = 8):
+        super().__init__()
+        self.k = sorb // 2
+        self.embed = torch.nn.Embedding(5, d_model)  # 4 occupations + start token
+        self.pos = torch.nn.Parameter(0.02 * torch.randn(self.k, d_model))
+        layer = torch.nn.TransformerEncoderLayer(d_model, n_heads, dim_feedforward=4 * d_model, dropout=0.0, batch_first=True)
+        self.layers = torch.nn.TransformerEncoder(layer, n_layers, enable_nested_tensor=False)
+        self.head = torch.nn.Linear(d_model, 4)
+        self.phase = torch.nn.Linear(d_model, 1)
+        self.register_buffer("mask", torch.triu(torch.ones(self.k, self.k, dtype=torch.bool), diagonal=1))
+
+    def forward(self, x):  # x: +-1 [n, sorb]
+        occ = (x > 0).long()
+        tok = occ[:, 0::2] + 2 * occ[:, 1::2]  # [n, k]
+        inp = torch.cat([torch.full_like(tok[:, :1], 4), tok[:, :-1]], 1)
+        hid = self.layers(self.embed(inp) + self.pos, mask=self.mask)
+        logp = torch.log_softmax(self.head(hid), -1).gather(-1, tok.unsqueeze(-1)).squeeze(-1).sum(-1)
+        return torch.exp(0.5 * logp) * torch.cos(self.phase(hid[:, -1]).squeeze(-1))
+
+
 def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", keys: int = 65536) -> Workload:
     if name == "fe2s2_eloc_sample_space":
         d = load_fe2s2()
@@ -612,6 +638,24 @@ def main():
                 el3 = (time.perf_counter() - t0) / reps
                 extra[tag] = {"value": nw / el3, "unit": "local energies/s", "walkers": nw, "ms_per_step": el3 * 1e3,
                               "mean_eloc": float(e_.mean().item())}
+            # BASELINE config C3: the same REDUCE local energies with a Transformer-decoder amplitude (stand-in, see DecoderAmplitude)
+            torch.manual_seed(7)
+            dec = DecoderAmplitude(sorb).to(dev).double().eval()
+            xg = torch.from_numpy(np.ascontiguousarray(d["ci_space"][:8192])).to(dev)
+            fn = lambda: E.total_energy(xg, 8192, 200_000, h1g, h2g, dec, sorb, nele, noA, noB, use_unique=True, reduce_psi=True, eps=1e-2)
+            fn(); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            e_, _, _ = fn()
+            torch.cuda.synchronize(dev)
+            el3 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            row_, col_, onv_, h_, cnt_ = E.reduce_compact(xg, h1g, h2g, sorb, nele, noA, noB, 1e-2)
+            torch.cuda.synchronize(dev)
+            el4 = time.perf_counter() - t0
+            extra["fe2s2_eloc_reduce_eps1e-2_decoder_torch"] = {
+                "value": 8192 / el3, "unit": "local energies/s", "walkers": 8192, "ms_per_step": el3 * 1e3, "mean_eloc": float(e_.mean().item()),
+                "ansatz": "autoregressive Transformer decoder, d_model 32, 6 layers, 8 heads, f64, random weights (stand-in)",
+                "determinant_part_ms": el4 * 1e3}
             torch.set_default_dtype(old_default)
             E.FUSED_RBM = old_fused_rbm
         except Exception as e:  # pragma: no cover
