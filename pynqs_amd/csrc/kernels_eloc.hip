@@ -1,10 +1,14 @@
 // kernels_eloc.hip -- fused local-energy kernels on the integral plan: the excitation list and its matrix
 // elements are consumed on chip, comb / Hmat are never written to HBM.
-//   eloc_sample_space_kernel : E_loc(x) = sum_x' <x|H|x'> psi(x') / psi(x), psi from a sorted sample table
-//                              (vmc/energy/eloc.py:326-401 + utils/public_function.py:817-838)
-//   reduce_count / reduce_emit : keep only |<x|H|x'>| >= eps (vmc/energy/eloc.py:297-298), compacted in
-//                              ascending column order
-// Matrix elements are bit-identical to kernels_plan.hip (same helpers, same order of additions).
+//   eloc_sample_space_filtered_kernel : E_loc(x) = sum_x' <x|H|x'> psi(x') / psi(x), psi from the hash table of the sample
+//                              space (vmc/energy/eloc.py:326-401 + utils/public_function.py:817-838); a Zobrist-hash filter
+//                              decides per column before any other work, candidates are queued and evaluated 64 at a time
+//   eloc_sample_space_kernel : the same sum with every column evaluated in place (tile scheduler + LookupSink): sorted
+//                              keys (binary search), or a hash table built without filters
+//   hash_build / hash_lookup : the table (the reference's optional GPU table, cuda_tensor.cpp:489-559) and its filters
+//   reduce_count / reduce_emit : keep only |<x|H|x'>| >= eps (vmc/energy/eloc.py:297-298), compacted in a reproducible order
+// Matrix elements of the doubles are bit-identical to kernels_plan.hip (same helpers); the sample-space kernels add the
+// terms of <x|H|x> and of the singles in an order-free way (E_loc is a rounded sum, tolerance 1e-8 Ha).
 #include "detcore.h"
 #include "launch.h"
 #include "plan.h"
