@@ -411,7 +411,11 @@ __device__ __forceinline__ void pair_unrank(int q, int &hi, int &lo) {
 // Builds merged / occv / tables for the workgroup's walker.  All threads of the block must call it;
 // ends with a barrier.  Returns the walker's electron count (length of occv).
 template <int LEN>
-__device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const SDParams &p, const LdsLayout &L) {
+// zorb (one-word determinants only): a per-orbital 32-bit value in LDS, written before the call; the msk area then
+// receives, instead of the ket masks, the XOR of the two orbitals' values per table entry as uint32 (the
+// filter-first sample-space kernel, kernels_eloc.hip).
+__device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const SDParams &p, const LdsLayout &L,
+                                                   const uint32_t *zorb = nullptr) {
   const int tid = threadIdx.x;
   const int sorb = p.sorb;
   // actual alpha / beta electron counts of this walker (the reference's slot counters run on the
@@ -466,8 +470,12 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     const uint32_t sp = (uint32_t)(q >> 1) * (uint32_t)(p.sorb >> 1) + (uint32_t)(h >> 1);
     L.tab[(beta ? p.offSb : p.offSa) + ia] = (uint32_t)h | ((uint32_t)q << 8) | (par << 16) | (sp << 17);
     if constexpr (LEN == 1) {
-      const uint64_t bits = (1ull << h) ^ (1ull << q);
-      L.msk[(beta ? p.offSb : p.offSa) + ia] = beta ? bits : (bits ^ wk.w[0]);
+      if (zorb) {
+        reinterpret_cast<uint32_t *>(L.msk)[(beta ? p.offSb : p.offSa) + ia] = zorb[h] ^ zorb[q];
+      } else {
+        const uint64_t bits = (1ull << h) ^ (1ull << q);
+        L.msk[(beta ? p.offSb : p.offSa) + ia] = beta ? bits : (bits ^ wk.w[0]);
+      }
     }
   }
   // pair tables: hole pairs (hi > lo among occupied slots) and particle pairs (virtual slots)
@@ -488,8 +496,12 @@ __device__ __forceinline__ int build_walker_tables(const Walker<LEN> &wk, const 
     const uint32_t m1 = (uint32_t)o1 >> 1, m0 = (uint32_t)o0 >> 1;
     L.tab[off + q] = (uint32_t)o1 | ((uint32_t)o0 << 8) | (par << 16) | ((m1 * (m1 - 1) / 2 + m0) << 17);
     if constexpr (LEN == 1) {
-      const uint64_t bits = (1ull << o1) ^ (1ull << o0);
-      L.msk[off + q] = extra ? bits : (bits ^ wk.w[0]);
+      if (zorb) {
+        reinterpret_cast<uint32_t *>(L.msk)[off + q] = zorb[o1] ^ zorb[o0];
+      } else {
+        const uint64_t bits = (1ull << o1) ^ (1ull << o0);
+        L.msk[off + q] = extra ? bits : (bits ^ wk.w[0]);
+      }
     }
   }
   __syncthreads();

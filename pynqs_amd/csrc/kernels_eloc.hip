@@ -144,14 +144,20 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
 // Queue sizes: < 64 left over + what is parked between two pumps (one level: a pump after every group of 64 ranks).
 __host__ __device__ constexpr uint32_t q1_doubles(bool two) { return two ? 320u : 128u; }
 constexpr uint32_t kQ1Singles = 128, kQ2 = 128;
-__host__ __device__ constexpr uint32_t queue_words(bool two) { return q1_doubles(two) + kQ1Singles + (two ? 2 * kQ2 : 0u); }
+// bytes of a wave's queues: doubles are 32-bit entries, singles 16-bit ranks (there are fewer than 2^16 singles)
+__host__ __device__ constexpr uint32_t queue_bytes(bool two) { return q1_doubles(two) * 4 + kQ1Singles * 2 + (two ? kQ2 * 4 + kQ2 * 2 : 0u); }
+// LDS in front of the filter: the walker tables; for one-word determinants the ket-mask area (8 bytes per table entry)
+// shrinks to the precombined Zobrist values (4 bytes per entry)
+__host__ __device__ inline size_t filtered_fixed_lds(const SDParams &p) {
+  return (lds_tab_bytes(p) + (p.sorb <= 64 ? (size_t)p.tabEntries * 4 : 0) + 15) & ~(size_t)15;
+}
 __host__ __device__ constexpr uint32_t z_bytes(int sorb) { return 4u * (((uint32_t)sorb + 15u) & ~15u); }  // one Z[orbital] table
 // Workgroups of 256 threads, or of 512 when tables + filter leave room for only two workgroups per CU (sorb >~ 100): the
 // waves of a workgroup share them, so that doubles the waves in flight (multi-word determinants only: one-word systems
 // never get there).
 constexpr int kBigBlock = 512;
 __host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits, int sorb, bool two, int block) {
-  return fbits / 8 + (two ? 2 : 1) * z_bytes(sorb) + (size_t)(block / 64) * queue_words(two) * 4;
+  return fbits / 8 + (two ? 2 : 1) * z_bytes(sorb) + (size_t)(block / 64) * queue_bytes(two);
 }
 
 // TWO = false: no second level, queue 1 is evaluated directly (strong LDS filter, or many true hits: the second level
@@ -172,6 +178,7 @@ struct Candidates {
   uint32_t f2bits;
   uint32_t filt, fbits;  // LDS address and size of the first filter
   uint32_t zorb;         // LDS address of Z[orbital] (z_bytes), followed by the second level's Z2[orbital] if TWO
+  uint32_t ztab;         // one-word determinants: LDS address of the per-entry Z[o1] ^ Z[o2] (in place of the ket masks)
   uint32_t queue;        // LDS address of this wave's queues: doubles 1, singles 1, doubles 2, singles 2
   uint32_t zx, zx2;      // Zobrist hashes of the walker
   uint32_t n1[2], n2[2]; // entries of the queues, [0] doubles, [1] singles (wave-uniform)
@@ -183,6 +190,38 @@ struct Candidates {
   __device__ __forceinline__ uint32_t flipped2(uint32_t e) const {
     const uint32_t z2 = z_bytes(p.sorb);
     return Z(z2 + ((e << 2) & 0x3fcu)) ^ Z(z2 + ((e >> 6) & 0x3fcu));
+  }
+  // ... or, for one-word determinants, straight from the precombined table (entry index as in L.tab)
+  __device__ __forceinline__ uint32_t flipped_at(uint32_t index) const {
+    if constexpr (LEN == 1) return *reinterpret_cast<lds_u32 *>(ztab + 4u * index);
+    else return flipped(L.tab[index]);
+  }
+  // a double from its two table entries, without the ket-mask tables
+  __device__ __forceinline__ double double_from_entries(uint32_t e0, uint32_t e1, bool opp, const double *__restrict__ V, uint32_t mask, uint32_t mul,
+                                                        uint64_t (&ket)[LEN]) const {
+    PendingDouble<double> d;
+    d.e0 = e0;
+    d.e1 = e1;
+    if constexpr (LEN == 1) {
+      d.k0 = wk.w[0] ^ (1ull << (e0 & 0xff)) ^ (1ull << ((e0 >> 8) & 0xff));
+      d.k1 = (1ull << (e1 & 0xff)) ^ (1ull << ((e1 >> 8) & 0xff));
+    }
+    d.v = V[__umul24((e1 >> 17) & mask, mul) + ((e0 >> 17) & mask)];
+    DoubleClass c;
+    c.opposite = opp;
+    return finish_double<LEN, double>(d, c, wk, ket);
+  }
+  // any double rank (one level: the queue holds plain ranks)
+  __device__ __forceinline__ double double_from_rank(uint32_t r, uint64_t (&ket)[LEN]) const {
+    const bool opp = r >= p.d3;
+    const int spin = r >= p.d2;
+    const DoubleClass c = opp ? make_opp_spin(p, pl) : make_same_spin(p, pl, spin);
+    uint32_t slow, u;
+    class_split(r, c, slow, u);
+    uint32_t f = u + c.rot;
+    f = f >= c.nfast ? f - c.nfast : f;
+    const double *__restrict__ V = opp ? plan + pl.offVab : plan + pl.offVss + (size_t)spin * pl.NP * pl.NP;
+    return double_from_entries(L.tab[c.off_fast + f], L.tab[c.off_slow + slow], opp, V, c.mask, c.mul, ket);
   }
   __device__ __forceinline__ bool maybe(uint32_t z) const {  // false: certainly not in the table
     if (!fbits) return maybe2(z);  // (wave-uniform) no LDS filter: the table is too large for one; Z[] then holds the second hash
@@ -213,9 +252,23 @@ struct Candidates {
     re += h * vr;
     if constexpr (CPLX) im += h * vi;
   }
+  // entry i of a queue (layout of a wave's queues: doubles 1 | singles 1 | doubles 2 | singles 2)
   template <bool SINGLES, int STAGE>
-  __device__ __forceinline__ uint32_t qaddr() const {
-    return queue + 4u * (STAGE == 1 ? (SINGLES ? q1_doubles(TWO) : 0u) : q1_doubles(TWO) + kQ1Singles + (SINGLES ? kQ2 : 0u));
+  __device__ __forceinline__ uint32_t qaddr(uint32_t i) const {
+    const uint32_t base = STAGE == 1 ? (SINGLES ? q1_doubles(TWO) * 4 : 0u) : q1_doubles(TWO) * 4 + kQ1Singles * 2 + (SINGLES ? kQ2 * 4 : 0u);
+    return queue + base + (SINGLES ? 2u : 4u) * i;
+  }
+  template <bool SINGLES, int STAGE>
+  __device__ __forceinline__ uint32_t qread(uint32_t i) const {
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    if constexpr (SINGLES) return *reinterpret_cast<lds_u16 *>(qaddr<SINGLES, STAGE>(i));
+    else return *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, STAGE>(i));
+  }
+  template <bool SINGLES, int STAGE>
+  __device__ __forceinline__ void qwrite(uint32_t i, uint32_t r) const {
+    typedef __attribute__((address_space(3))) uint16_t lds_u16;
+    if constexpr (SINGLES) *reinterpret_cast<lds_u16 *>(qaddr<SINGLES, STAGE>(i)) = (uint16_t)r;
+    else *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, STAGE>(i)) = r;
   }
   // all 64 lanes active (so are all callers below); LDS operations of a wave execute in order
   template <bool SINGLES, int STAGE>
@@ -225,7 +278,7 @@ struct Candidates {
     uint32_t &count = STAGE == 1 ? n1[SINGLES] : n2[SINGLES];
     if (pass) {
       const uint32_t lane = threadIdx.x & 63;
-      *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, STAGE>() + 4u * (count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))) = r;
+      qwrite<SINGLES, STAGE>(count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), r);
     }
     count = __builtin_amdgcn_readfirstlane(count + (uint32_t)__popcll(m));
   }
@@ -241,19 +294,10 @@ struct Candidates {
     const uint32_t k = code >> 30;
     uint32_t i0, i1;
     double_entries(code, i0, i1);
-    PendingDouble<double> d;
-    d.e0 = L.tab[i0];
-    d.e1 = L.tab[i1];
-    if constexpr (LEN == 1) { d.k0 = L.msk[i0]; d.k1 = L.msk[i1]; }
-    DoubleClass c;
-    c.opposite = k == 2;
-    if (c.opposite) {  // (branches rather than selects: the table bases stay scalar)
-      d.v = plan[pl.offVab + __umul24((d.e1 >> 17) & 0x7fffu, (uint32_t)(pl.K * pl.K)) + ((d.e0 >> 17) & 0x7fffu)];
-    } else {
-      const double *__restrict__ V = plan + pl.offVss + (size_t)k * pl.NP * pl.NP;
-      d.v = V[__umul24((d.e1 >> 17) & 0x1fffu, (uint32_t)pl.NP) + ((d.e0 >> 17) & 0x1fffu)];
-    }
-    return finish_double<LEN, double>(d, c, wk, ket);
+    const uint32_t e0 = L.tab[i0], e1 = L.tab[i1];
+    if (k == 2)  // (branches rather than selects: the table bases stay scalar)
+      return double_from_entries(e0, e1, true, plan + pl.offVab, 0x7fffu, (uint32_t)(pl.K * pl.K), ket);
+    return double_from_entries(e0, e1, false, plan + pl.offVss + (size_t)k * pl.NP * pl.NP, 0x1fffu, (uint32_t)pl.NP, ket);
   }
   // second-level filter for the top n <= 64 ranks of queue 1; survivors move to queue 2
   template <bool SINGLES>
@@ -263,7 +307,7 @@ struct Candidates {
     uint32_t r = 0;
     bool pass = false;
     if (lane < n) {
-      r = *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, 1>() + 4u * (n1[SINGLES] - n + lane));
+      r = qread<SINGLES, 1>(n1[SINGLES] - n + lane);
       uint32_t z2 = zx2;
       if constexpr (SINGLES) z2 ^= flipped2(L.tab[p.offSa + r]);
       else {
@@ -286,7 +330,7 @@ struct Candidates {
     double h = 0.0;
     int64_t pos = -1;
     if (lane < n) {
-      const uint32_t r = *reinterpret_cast<lds_u32 *>(qaddr<SINGLES, STAGE>() + 4u * (count - n + lane));
+      const uint32_t r = qread<SINGLES, STAGE>(count - n + lane);
       uint64_t ket[LEN];
       if constexpr (SINGLES) {
         h = fast_single<double>(r, p, pl, L, nocc, plan);
@@ -298,7 +342,7 @@ struct Candidates {
       } else {
         // (one level: the queue holds plain ranks -- the packed form costs this variant 16 more VGPRs and a wave per SIMD)
         if constexpr (TWO) h = double_value(r, ket);
-        else h = double_element<LEN, double>(r, p, pl, L, plan, wk, ket);
+        else h = double_from_rank(r, ket);
       }
       pos = hash_find<LEN>(table, cap, ket);
     }
@@ -350,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   // after the walker tables (no staging scratch: order-free singles / diagonal): filter, Z[orbital], Z2[orbital], the waves' queues
-  const uint32_t filt_off = (uint32_t)((lds_bytes(p, 0) + 15) & ~(size_t)15), z_off = filt_off + fbits / 8, q_off = z_off + (TWO ? 2 : 1) * z_bytes(p.sorb);
+  const uint32_t filt_off = (uint32_t)filtered_fixed_lds(p), z_off = filt_off + fbits / 8, q_off = z_off + (TWO ? 2 : 1) * z_bytes(p.sorb);
   const uint32_t *__restrict__ gf = reinterpret_cast<const uint32_t *>(table + (uint64_t)cap * hash_slot_words(LEN));
   {
     uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
@@ -361,7 +405,8 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
       if constexpr (TWO) lz[z_bytes(p.sorb) / 4 + tid] = zobrist32b((uint32_t)tid);
     }
   }
-  const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier: filter and Z are visible
+  // (its first barrier publishes Z[] to the table loops; it ends with a barrier: tables and filter are visible)
+  const int nocc = build_walker_tables<LEN>(wk, p, L, LEN == 1 ? reinterpret_cast<const uint32_t *>(smem + z_off) : nullptr);
   uint32_t zx = 0, zx2 = 0;
 #pragma unroll
   for (int w = 0; w < LEN; ++w)
@@ -373,7 +418,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
   for (int o = 32; o > 0; o >>= 1) { zx ^= __shfl_xor(zx, o); zx2 ^= __shfl_xor(zx2, o); }
   const uint32_t dyn = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
   Candidates<LEN, CPLX, TWO> cand{p, pl, L, wk, nocc, plan, table, (uint64_t)cap, wf, gf + fbits / 32, f2bits, dyn + filt_off, fbits, dyn + z_off,
-                             dyn + q_off + (uint32_t)(tid >> 6) * (queue_words(TWO) * 4u), zx, zx2, {0u, 0u}, {0u, 0u}, 0.0, 0.0};
+                             dyn + (uint32_t)lds_tab_bytes(p), dyn + q_off + (uint32_t)(tid >> 6) * queue_bytes(TWO), zx, zx2, {0u, 0u}, {0u, 0u}, 0.0, 0.0};
 
   // tiles: 0 = column 0; 1 = this workgroup's share of the singles (blocks of 64 dealt round-robin over the walker's
   // workgroups, as in plan_tiles.h) -- one wave takes them all, so that its singles queue fills; then 256 ranks of one
@@ -408,8 +453,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
     if (tile == 1) {
       for (uint32_t r0 = chunk * 64u; r0 < p.d1; r0 += nchunks * 64u) {
         const uint32_t r = r0 + (uint32_t)lane;
-        const uint32_t e = L.tab[p.offSa + min(r, p.d1 - 1)];
-        cand.template park<true, 1>(r, (r < p.d1) & cand.maybe(zx ^ cand.flipped(e)));
+        cand.template park<true, 1>(r, (r < p.d1) & cand.maybe(zx ^ cand.flipped_at((uint32_t)p.offSa + min(r, p.d1 - 1))));
         cand.template pump<true>();
       }
       cand.template flush<true>();
@@ -435,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
       f = f >= c.nfast ? f - c.nfast : f;
       rr[j] = TWO ? cand.pack(k, slow, f) : g.r_e + m;
       // (lanes past the end of the class read a valid but meaningless entry: slow is clamped to the class's last row)
-      const uint32_t z = zx ^ cand.flipped(L.tab[c.off_fast + f]) ^ cand.flipped(L.tab[c.off_slow + min(slow, nslow - 1u)]);
+      const uint32_t z = zx ^ cand.flipped_at(c.off_fast + f) ^ cand.flipped_at(c.off_slow + min(slow, nslow - 1u));
       pass[j] = (m <= last) & cand.maybe(z);
       u += r64;
       slow += q64 + (u >= c.nfast ? 1u : 0u);
@@ -653,7 +697,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   const uint32_t f2bits = hash ? hash_filter2_bits(nkeys) : 0u;
   const bool filtered = fbits || f2bits;
   const bool two_level = fbits && f2bits && (f2env >= 0 ? f2env != 0 : (uint64_t)fbits < 6ull * (uint64_t)nkeys);
-  const size_t lds_fixed = (lds_bytes(p, 0) + 15) & ~(size_t)15;
+  const size_t lds_fixed = filtered ? filtered_fixed_lds(p) : (lds_bytes(p, 0) + 15) & ~(size_t)15;
   static const int blk_env = getenv("PYNQS_SS_BLOCK") ? atoi(getenv("PYNQS_SS_BLOCK")) : 0;
   const int block = (!filtered || len == 1) ? kBlock : (blk_env == 256 || blk_env == 512) ? blk_env
                     : (lds_fixed + filtered_extra_lds(fbits, sorb, two_level, kBlock) > 52 * 1024 ? kBigBlock : kBlock);
