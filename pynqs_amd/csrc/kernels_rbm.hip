@@ -93,7 +93,7 @@ __host__ __device__ inline size_t rbm_region_bytes(const SDParams &p, uint32_t h
 
 __host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayout &rl, uint32_t hw) {
   return rbm_q_offset(p) + rbm_region_bytes(p, hw) +
-         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 48;  // + red, counters
+         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 144;  // + red (up to 16 waves), counters
 }
 
 __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o >> 1) + ((o & 1u) ? K : 0u); }
@@ -103,15 +103,15 @@ __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o 
 //                   in every round each wave holds the 16 x 64 running products of ONE tile in registers across the
 //                   windows (two barriers per window).
 template <int LEN, bool WINDOWED>
-__global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
+__global__ __launch_bounds__(WINDOWED ? 1024 : kBlock, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
                                                           RbmBlocks B, uint32_t nchunks, uint32_t hw, const double *__restrict__ plan,
                                                           const double *__restrict__ rbm, double *__restrict__ eloc,
                                                           double *__restrict__ psi) {
   // no static __shared__ here: with the dynamic region at LDS address 0 the row offsets below are the addresses and
   // the ds_read immediates carry the rest (a static in front costs one v_add per read)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *red = reinterpret_cast<double *>(smem + lds_bytes_rbm(p, rl, hw) - 48);  // [kBlock / 64]
-  uint32_t *next_tile_p = reinterpret_cast<uint32_t *>(red + kBlock / 64);
+  double *red = reinterpret_cast<double *>(smem + lds_bytes_rbm(p, rl, hw) - 144);  // [16]: one per wave
+  uint32_t *next_tile_p = reinterpret_cast<uint32_t *>(red + 16);
   uint32_t *next_single_p = next_tile_p + 1;
   const uint64_t wg = blockIdx.x;
   const uint64_t walker = wg / nchunks;
@@ -450,15 +450,33 @@ __global__ __launch_bounds__(kBlock, 4) void eloc_rbm_kernel(const uint64_t *__r
 using namespace pynqs;
 
 static constexpr size_t kRbmMaxLds = 158 * 1024;  // of the CU's 160 KiB
-static constexpr size_t kRbmWindowLds = 64 * 1024;  // LDS target of the windowed kernel (2 workgroups per CU)
+
+// Shape of the windowed kernel (sorb x num_hidden does not fit in LDS), by the number of tiles a walker's row has:
+// many tiles -> ONE workgroup of 1024 threads per CU around a 136 KiB window (16 waves share it, half as many windows
+// and barriers: sorb 120, 240 hidden units, 1024 walkers: 70.3 ms with 256 threads and 64 KiB, 41.6 with 512 and 64 KiB,
+// 32.6 with 1024 and 136 KiB); fewer tiles than waves would idle -> 512 or 256 threads, two workgroups per CU around
+// 64 KiB windows.  PYNQS_RBM_BLOCK / PYNQS_RBM_WINDOW_KB override.
+struct RbmShape {
+  uint32_t threads;
+  size_t window_lds;
+};
+static RbmShape rbm_windowed_shape(uint32_t ntiles) {
+  static const int blk_env = getenv("PYNQS_RBM_BLOCK") ? atoi(getenv("PYNQS_RBM_BLOCK")) : 0;
+  static const int win_env = getenv("PYNQS_RBM_WINDOW_KB") ? atoi(getenv("PYNQS_RBM_WINDOW_KB")) : 0;
+  RbmShape s;
+  s.threads = (blk_env == 256 || blk_env == 512 || blk_env == 1024) ? (uint32_t)blk_env : (ntiles >= 64 ? 1024u : (ntiles >= 24 ? 512u : 256u));
+  s.window_lds = (size_t)(win_env > 0 ? win_env : (s.threads == 1024 ? 136 : 64)) * 1024;
+  if (s.window_lds > kRbmMaxLds) s.window_lds = kRbmMaxLds;
+  return s;
+}
 
 // hidden units resident in LDS: all of them (rl.Hloop) when that fits, else the largest multiple of 8 that keeps the
-// workgroup within kRbmWindowLds (at least 8); 0 if not even that fits
-static uint32_t rbm_window(const SDParams &p, const RbmLayout &rl) {
+// workgroup within window_lds (at least 8); 0 if not even that fits
+static uint32_t rbm_window(const SDParams &p, const RbmLayout &rl, size_t window_lds) {
   if (lds_bytes_rbm(p, rl, (uint32_t)rl.Hloop) <= kRbmMaxLds) return (uint32_t)rl.Hloop;
   const size_t other = lds_bytes_rbm(p, rl, 0u) - rbm_region_bytes(p, 0u);
   for (uint32_t hw = 256; hw >= 8; hw -= 8)
-    if (other + rbm_region_bytes(p, hw) <= (hw > 8 ? kRbmWindowLds : kRbmMaxLds)) return hw;
+    if (other + rbm_region_bytes(p, hw) <= (hw > 8 ? window_lds : kRbmMaxLds)) return hw;
   return 0;
 }
 
@@ -473,7 +491,7 @@ extern "C" int pynqs_eloc_rbm_supported(int sorb, int nele, int noA, int noB, in
   PlanLayout pl;
   RbmLayout rl;
   if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl) || !make_rbm_layout(sorb, nhidden, &rl)) return 0;
-  return rbm_window(p, rl) > 0 ? 1 : 0;
+  return rbm_window(p, rl, kRbmMaxLds) > 0 ? 1 : 0;
 }
 
 extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb,
@@ -499,10 +517,6 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   if (nbatch < 0 || nbatch > 0x7fffffffll) return set_error(PYNQS_EINVAL, "bad nbatch");
   if (nbatch == 0) return PYNQS_OK;
   if (!bra || !plan || !rbm_table || !eloc) return set_error(PYNQS_EINVAL, "null pointer");
-  const uint32_t hw = rbm_window(p, rl);
-  if (hw == 0) return set_error(PYNQS_EINVAL, "the walker tables of this system leave no LDS for the RBM rows");
-  const bool windowed = hw < (uint32_t)rl.Hloop;
-  const size_t lds = lds_bytes_rbm(p, rl, hw);
   const RbmBlocks B = make_rbm_blocks(p);
   // few walkers: cut a walker's tiles over several workgroups (each repeats the per-walker set-up)
   uint32_t nchunks = 1;
@@ -511,6 +525,11 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
     const uint32_t maxc = B.ntiles / 4 > 0 ? B.ntiles / 4 : 1;
     if (nchunks > maxc) nchunks = maxc;
   }
+  const RbmShape shape = rbm_windowed_shape(B.ntiles / nchunks);
+  const uint32_t hw = rbm_window(p, rl, shape.window_lds);
+  if (hw == 0) return set_error(PYNQS_EINVAL, "the walker tables of this system leave no LDS for the RBM rows");
+  const bool windowed = hw < (uint32_t)rl.Hloop;
+  const size_t lds = lds_bytes_rbm(p, rl, hw);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   hipStream_t st = (hipStream_t)stream;
@@ -518,7 +537,7 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   const int len = (sorb - 1) / 64 + 1;
   // (3-wave workgroups divide Fe2S2's 9 tiles evenly but leave only 12 waves per CU -- LDS allows 4 workgroups --
   // and were 8 % slower at 80 hidden units; the kernel itself runs with any multiple of 64 threads >= 128)
-  const uint32_t threads = kBlock;
+  const uint32_t threads = windowed ? shape.threads : (uint32_t)kBlock;
 #define PYNQS_RBM_LAUNCH(W)                                                                                                     \
   do {                                                                                                                          \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN, W>),                       \
