@@ -152,9 +152,9 @@ __host__ __device__ inline size_t filtered_fixed_lds(const SDParams &p) {
   return (lds_tab_bytes(p) + (p.sorb <= 64 ? (size_t)p.tabEntries * 4 : 0) + 15) & ~(size_t)15;
 }
 __host__ __device__ constexpr uint32_t z_bytes(int sorb) { return 4u * (((uint32_t)sorb + 15u) & ~15u); }  // one Z[orbital] table
-// Workgroups of 256 threads, or of 512 when tables + filter leave room for only two workgroups per CU (sorb >~ 100): the
-// waves of a workgroup share them, so that doubles the waves in flight (multi-word determinants only: one-word systems
-// never get there).
+// Workgroups of 256 threads, or of 512 / 1024 when tables + filter leave room for only one or two workgroups per CU
+// (sorb >~ 100): the waves of a workgroup share them, so that multiplies the waves in flight (multi-word determinants
+// only: one-word systems never get there).
 constexpr int kBigBlock = 512;
 __host__ __device__ constexpr size_t filtered_extra_lds(uint32_t fbits, int sorb, bool two, int block) {
   return fbits / 8 + (two ? 2 : 1) * z_bytes(sorb) + (size_t)(block / 64) * queue_bytes(two);
@@ -698,9 +698,22 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   const bool filtered = fbits || f2bits;
   const bool two_level = fbits && f2bits && (f2env >= 0 ? f2env != 0 : (uint64_t)fbits < 6ull * (uint64_t)nkeys);
   const size_t lds_fixed = filtered ? filtered_fixed_lds(p) : (lds_bytes(p, 0) + 15) & ~(size_t)15;
+  // workgroup size: whatever puts the most waves on a CU (160 KiB of LDS; the kernel's registers allow 7 waves per SIMD);
+  // the waves of a workgroup share tables and filter.  One-word systems never need more than 256 threads.
   static const int blk_env = getenv("PYNQS_SS_BLOCK") ? atoi(getenv("PYNQS_SS_BLOCK")) : 0;
-  const int block = (!filtered || len == 1) ? kBlock : (blk_env == 256 || blk_env == 512) ? blk_env
-                    : (lds_fixed + filtered_extra_lds(fbits, sorb, two_level, kBlock) > 52 * 1024 ? kBigBlock : kBlock);
+  int block = kBlock;
+  if (filtered && len > 1) {
+    if (blk_env == 256 || blk_env == 512 || blk_env == 1024) block = blk_env;
+    else {
+      size_t best = 0;
+      for (int b = kBlock; b <= 1024; b *= 2) {
+        const size_t need = lds_fixed + filtered_extra_lds(fbits, sorb, two_level, b) + 256;
+        size_t waves = (160 * 1024 / need) * (size_t)(b / 64);
+        if (waves > 28) waves = 28;
+        if (waves > best) { best = waves; block = b; }
+      }
+    }
+  }
   const size_t lds = lds_fixed + (filtered ? filtered_extra_lds(fbits, sorb, two_level, block) : 0);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
@@ -729,7 +742,9 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   DISPATCH_LEN(len, {
     if (filtered) {  // hash table with its filters
       if constexpr (LEN >= 2) {
-        if (block == kBigBlock) PYNQS_SS_FILTERED(kBigBlock); else PYNQS_SS_FILTERED(kBlock);
+        if (block == 1024) PYNQS_SS_FILTERED(1024);
+        else if (block == kBigBlock) PYNQS_SS_FILTERED(kBigBlock);
+        else PYNQS_SS_FILTERED(kBlock);
       } else {
         PYNQS_SS_FILTERED(kBlock);
       }
