@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o 
 //                   in every round each wave holds the 16 x 64 running products of ONE tile in registers across the
 //                   windows (two barriers per window).
 template <int LEN, bool WINDOWED>
-__global__ __launch_bounds__(WINDOWED ? 1024 : kBlock, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
+__global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
                                                           RbmBlocks B, uint32_t nchunks, uint32_t hw, const double *__restrict__ plan,
                                                           const double *__restrict__ rbm, double *__restrict__ eloc,
                                                           double *__restrict__ psi) {
@@ -537,7 +537,22 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   const int len = (sorb - 1) / 64 + 1;
   // (3-wave workgroups divide Fe2S2's 9 tiles evenly but leave only 12 waves per CU -- LDS allows 4 workgroups --
   // and were 8 % slower at 80 hidden units; the kernel itself runs with any multiple of 64 threads >= 128)
-  const uint32_t threads = windowed ? shape.threads : (uint32_t)kBlock;
+  // resident q': the workgroup size that puts the most waves on a CU (the registers allow 16; a workgroup's waves share
+  // its LDS), as long as the walker has at least two tiles per wave.  Fe2S2 (31 KiB): 256 threads, 4 workgroups per CU;
+  // sorb 56 with 112 hidden units (58 KiB): two workgroups per CU -> 512 threads.
+  uint32_t threads = shape.threads;
+  if (!windowed) {
+    static const int blk_env = getenv("PYNQS_RBM_BLOCK") ? atoi(getenv("PYNQS_RBM_BLOCK")) : 0;
+    threads = kBlock;
+    size_t best = 0;
+    for (uint32_t b = kBlock; b <= 1024; b *= 2) {
+      size_t waves = (160 * 1024 / (lds + 256)) * (b / 64);
+      if (waves > 16) waves = 16;
+      if (b > kBlock && B.ntiles / nchunks < 2 * (b / 64)) break;
+      if (waves > best) { best = waves; threads = b; }
+    }
+    if (blk_env == 256 || blk_env == 512 || blk_env == 1024) threads = (uint32_t)blk_env;
+  }
 #define PYNQS_RBM_LAUNCH(W)                                                                                                     \
   do {                                                                                                                          \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN, W>),                       \
