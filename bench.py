@@ -262,7 +262,10 @@ class SampleSpaceFused(Workload):
         self.eloc = torch.empty(self.n, dtype=torch.complex128, device=dev)
         self.psi0 = torch.empty(self.n, dtype=torch.complex128, device=dev)
         self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
-        self.dev, self.path, self.kernel = dev, "plan", "eloc_sample_space_kernel"
+        self.dev, self.path, self.kernel = dev, "plan", "eloc_sample_space_filtered_kernel"
+        self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered, so the "
+                              "SURVEY 8(d) byte count is an upper bound of what is read; the kernel is bound by the vector ALU "
+                              "(profiles/r01_*_eloc_sample_space_*_filtered.txt: VALU busy 90-97 %)")
         self.stats = None
 
     def step(self):
@@ -528,6 +531,8 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         out = {"bound": "hbm", "kernel": w.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": w.bytes_per_walker * w.n}
+        if getattr(w, "roofline_note", None):
+            out["note"] = w.roofline_note
         if traffic:
             # the algorithmic bytes count every integral gather once; for Fe2S2 they are served by the L2, so the
             # fraction can pass 1.  What actually crossed the HBM interface, against the same 8 TB/s:
