@@ -271,6 +271,14 @@ inline uint32_t hash_filter2_bits(int64_t nkeys) {  // host side
   return (uint32_t)b;
 }
 
+// The second-level filter is blocked: both bits of a key lie in ONE 32-bit word (word from the low bits of the hash, the
+// two bit numbers from its top 10 bits), so a query is one load.  (At 32 bits per key the false-positive rate stays
+// below 1 %; the LDS filter, with 2-8 bits per key, keeps two independent positions.)
+__host__ __device__ inline void filter2_position(uint32_t z2, uint32_t f2bits, uint32_t &word, uint32_t &mask) {
+  word = z2 & (f2bits / 32u - 1u);  // f2bits <= 2^26: bits 0..20
+  mask = (1u << ((z2 >> 22) & 31u)) | (1u << (z2 >> 27));
+}
+
 // the two filter bits of a key: the low and the high log2(fbits) bits of its Zobrist hash (fbits = 2^k, 10 <= k <= 18)
 __host__ __device__ inline void filter_positions(uint32_t z, uint32_t fbits, uint32_t &b0, uint32_t &b1) {
   b0 = z & (fbits - 1u);

@@ -231,10 +231,9 @@ struct Candidates {
     return ((w0 >> (b0 & 31u)) & (w1 >> (b1 & 31u)) & 1u) != 0u;
   }
   __device__ __forceinline__ bool maybe2(uint32_t z2) const {
-    uint32_t b0, b1;
-    filter_positions(z2, f2bits, b0, b1);
-    const uint32_t w0 = filt2[b0 >> 5], w1 = filt2[b1 >> 5];
-    return ((w0 >> (b0 & 31u)) & (w1 >> (b1 & 31u)) & 1u) != 0u;
+    uint32_t word, mask;
+    filter2_position(z2, f2bits, word, mask);
+    return (filt2[word] & mask) == mask;
   }
   __device__ __forceinline__ void value(int64_t pos, double &vr, double &vi) const {  // psi of table entry pos, 0 if pos < 0
     vr = 0.0; vi = 0.0;
@@ -526,9 +525,8 @@ __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__re
           filter += fbits / 32;
         }
         if (f2bits) {  // second level
-          filter_positions(z2, f2bits, b0, b1);
-          atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
-          atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
+          filter2_position(z2, f2bits, b0, b1);
+          atomicOr(filter + b0, b1);
         }
       }
       return;
