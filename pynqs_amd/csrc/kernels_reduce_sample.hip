@@ -200,9 +200,13 @@ struct SampleSink {
       pos += __popcll(m);
     }
   }
+  // a tile without draws is not enumerated at all (plan_tiles.h); with 1000 draws over the 4650 tiles of a sorb-120 row
+  // that is four tiles out of five
+  __device__ __forceinline__ bool skip_tile(uint32_t t) const { return tile_draws[t] == 0; }
   __device__ __forceinline__ void tile_begin(uint32_t t) {
     flush();
     tile = t;
+    if (tile_draws[t] == 0) return;
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < kTileCols; i += 64) S.hits[i] = 0u;

@@ -12,6 +12,9 @@
 // cost 0.08-0.1 ms of a 0.26 ms kernel (tools/ab.sh ablations).
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "detcore.h"
 #include "plan.h"
 #include "plan_dev.h"
@@ -90,6 +93,14 @@ __host__ __device__ inline uint32_t max_tiles_per_chunk(const SDParams &p, uint3
 //                tile: for sinks that only accumulate a rounded sum over all columns (fused local energies).
 constexpr int kSinglesPerFastTile = 64;
 
+// optional member of a sink: bool skip_tile(uint32_t tile) (wave-uniform), asked after tile_begin -- true: none of
+// this tile's columns is wanted, do not even enumerate them (the draw pass of the semi-stochastic REDUCE: a tile that
+// received no draws)
+template <typename S, typename = void>
+struct sink_can_skip : std::false_type {};
+template <typename S>
+struct sink_can_skip<S, std::void_t<decltype(std::declval<S &>().skip_tile(0u))>> : std::true_type {};
+
 template <int LEN, typename T, typename Sink, bool EXACT = true>
 __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
@@ -130,6 +141,9 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
     tile = __builtin_amdgcn_readfirstlane(tile);
     if (tile >= ntiles) break;
     sink.tile_begin(tile);  // wave-uniform; everything until the next call belongs to this tile, in a fixed order
+    if constexpr (sink_can_skip<Sink>::value) {
+      if (sink.skip_tile(tile)) continue;
+    }
     if (tile == 0) {
       // unpaired columns of the three classes: lanes 0..5
       if (kPaired && lane < 6) {
