@@ -596,6 +596,13 @@ struct ReduceSink {
     if ((threadIdx.x & 63) == 0) *run = 0;
     if constexpr (EMIT) base = tile_off[t];
   }
+  // emit pass: a tile that keeps nothing (the next offset equals this one) is not enumerated again (plan_tiles.h).
+  // `tiles_left` = entries of the offset array from this workgroup's slice to its end.
+  uint64_t tiles_left;
+  __device__ __forceinline__ bool skip_tile(uint32_t t) const {
+    if constexpr (EMIT) return (uint64_t)t + 1 < tiles_left && tile_off[t + 1] == tile_off[t];
+    else return false;
+  }
   __device__ __forceinline__ void put(int64_t pos, uint32_t col, T h, const uint64_t (&ket)[LEN]) const {
     kept_col[pos] = (int32_t)col;
     kept_h[pos] = h;
@@ -658,7 +665,8 @@ __global__ __launch_bounds__(kBlock) void reduce_tiles_kernel(const uint64_t *__
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
   ReduceSink<LEN, T, EMIT> sink{eps, wave_run + (tid >> 6), EMIT ? nullptr : tile_counts + slot * max_tiles,
-                                EMIT ? tile_off + slot * max_tiles : nullptr, kept_col, kept_onv, kept_h, 0xffffffffu, 0};
+                                EMIT ? tile_off + slot * max_tiles : nullptr, kept_col, kept_onv, kept_h, 0xffffffffu, 0,
+                                ((uint64_t)gridDim.x - slot) * max_tiles};
   visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
   sink.flush();
 }
