@@ -49,4 +49,10 @@ def grad(nqs: nn.Module, states: Tensor, state_prob: Tensor, eloc: Tensor, e_tot
             begin = end
     if ends:
         batch_loss_backward(begin, ends[-1])  # gradient synchronisation happens in this backward
+    elif get_world_size() > 1 and hasattr(nqs, "no_sync"):
+        # an empty shard (fewer unique samples than ranks): the other ranks' last backward waits in DDP's bucketed
+        # all-reduce, so this rank must take part with a zero gradient (the reference indexes idx_lst[-1] of an empty list
+        # and dies, leaving the others hanging).  A forward through the DDP wrapper arms its reducer.
+        zero = states.new_zeros((1,) + tuple(states.shape[1:]))
+        (nqs(zero).to(dtype).sum().real * 0.0).backward()
     return all_reduce_packed([loss_sum], get_world_size())[0]

@@ -23,3 +23,23 @@ class RealRBM(nn.Module):
         bext = torch.cat([self.hidden_bias, self.hidden_bias.new_zeros(1)])
         z = torch.addmm(bext, x, wext.T)
         return z[:, -1].exp() * (2 * z[:, :-1].cosh()).prod(-1)
+
+
+class ComplexRBM(nn.Module):
+    """psi(x) = exp(a.x) prod_h 2 cosh(W x + b)_h with complex128 parameters stored as (re, im) pairs, the layout of the
+    reference's rbm_type "complex" (rbm.py:61-73,147-168; its own psi() cannot run: it casts x back to float64 before
+    the complex mv, rbm.py:198,205).  The complex-valued amplitude of the C4-type configurations (BDG-RNN amplitudes are
+    complex128) for the generic local-energy path."""
+
+    def __init__(self, weights: Tensor, hidden_bias: Tensor, visible_bias: Tensor) -> None:
+        super().__init__()
+        self.params_weights = nn.Parameter(weights.clone())            # [num_hidden, sorb, 2]
+        self.params_hidden_bias = nn.Parameter(hidden_bias.clone())    # [num_hidden, 2]
+        self.params_visible_bias = nn.Parameter(visible_bias.clone())  # [sorb, 2]
+
+    def forward(self, x: Tensor) -> Tensor:
+        W = torch.view_as_complex(self.params_weights)
+        b = torch.view_as_complex(self.params_hidden_bias)
+        a = torch.view_as_complex(self.params_visible_bias)
+        xc = x.to(W.dtype)
+        return torch.mv(xc, a).exp() * (2 * (torch.mm(xc, W.T) + b).cosh()).prod(-1)

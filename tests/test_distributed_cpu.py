@@ -1,5 +1,7 @@
-"""world_size-2 gloo tests (CPU): walker sharding, packed all-reduce statistics and the DDP gradient
-estimator give the same numbers as the single-process evaluation."""
+"""world_size-2 gloo tests (CPU): walker sharding, packed all-reduce statistics, the DDP gradient estimator, GFMC branching
+and the sampler's cross-rank merge.  Expected values are the REFERENCE's, captured by tests/golden/make_golden_r2.py from two
+gloo ranks running the reference's own Python (grad_fe2s2.npz, gfmc_fe2s2.npz, sampler_merge.npz); the emulations of the
+reference's rank-0 protocols further down are kept as additional cases with uneven shards."""
 import os
 import socket
 
@@ -249,3 +251,119 @@ def test_sampler_merge_world_size_two(same_tree):
         assert len(lookup) == mu.size(0)
         for kk, v in zip(mu.numpy(), wfu.numpy()):
             assert lookup[bytes(kk)] == float(v)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# against vectors captured from the reference running on two gloo ranks (tests/golden/make_golden_r2.py)
+def _spawn(worker, world, *args):
+    import queue as _q
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = []
+    while len(out) < world:
+        try:
+            out.append(q.get(timeout=5))
+        except _q.Empty:
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: see its traceback above"
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    out.sort(key=lambda t: t[0])
+    return out
+
+
+def _pack(occ):
+    b = np.packbits(occ, axis=1, bitorder="little")
+    return np.concatenate([b, np.zeros((b.shape[0], 8 - b.shape[1] % 8 if b.shape[1] % 8 else 0), dtype=np.uint8)], axis=1)
+
+
+def _golden_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_default_dtype(torch.float64)  # PyNQS' utils/config.py:100-108 sets this at import; counts / counts.sum() follows it
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import GRAD_CASES, grad_case
+        from pynqs_amd import gfmc, grad as G, sample_comm, stats as S
+
+        res = {}
+        # gradient estimator under DDP (energy_grad.py:118-184)
+        for kind, amd, use_pow in GRAD_CASES:
+            m, states, prob, eloc, e_total, powr, dt, amd_, want = grad_case(kind, amd, use_pow, "cpu", rank, world)
+            ddp = torch.nn.parallel.DistributedDataParallel(m)
+            G.grad(ddp, states, prob, eloc, e_total, powr, dt, amd_)
+            res[f"grad_{kind}_{amd}_{use_pow}"] = ({k: v.grad.numpy() for k, v in m.named_parameters()}, want)
+        # an empty shard must not hang the other rank's DDP reduction (and contributes a zero gradient)
+        m, states, prob, eloc, e_total, powr, dt, amd_, want = grad_case("real", -1, 0, "cpu", 0, 1)
+        ddp = torch.nn.parallel.DistributedDataParallel(m)
+        sl = slice(0, 32) if rank == 0 else slice(0, 0)
+        G.grad(ddp, states[sl], prob[sl] * world, eloc[sl], e_total, 1.0, dt, 7)
+        res["grad_empty_shard"] = ({k: v.grad.numpy() for k, v in m.named_parameters()}, want)
+        # GFMC branching (walker.py:340-408), equal shards
+        gf = golden("gfmc_fe2s2.npz")
+        n = gf["branch_x"].shape[0]
+        k = n // world
+        xb = gfmc.branching(torch.from_numpy(gf["branch_x"][rank * k:(rank + 1) * k].copy()), torch.from_numpy(gf["branch_w"][rank * k:(rank + 1) * k].copy()),
+                            torch.from_numpy(gf[f"branch_ws{world}_xi_r{rank}" if world > 1 else "branch_ws1_xi"].copy()))
+        res["branch"] = xb.numpy()
+        # sampler merge (sample.py:627-772)
+        sm = golden("sampler_merge.npz")
+        for t in (0, 1):
+            pre = f"tree{t}_r{rank}_"
+            onv = torch.from_numpy(_pack(sm[pre + "occ"]))
+            u, _, p, lut, mc = sample_comm.gather_scatter_sample(onv, torch.from_numpy(sm[pre + "counts"].copy()), torch.from_numpy(sm[pre + "wf"].copy()),
+                                                                 40, use_LUT=True, use_same_tree=bool(t), is_onv=True)
+            res[f"gs{t}"] = (u.numpy(), p.numpy(), lut.bra_key.numpy(), lut.wf_value.numpy(), mc.numpy())
+        # statistics
+        prob, el = torch.from_numpy(sm["stats_ws2_prob"].copy()), torch.from_numpy(sm["stats_ws2_eloc"].copy())
+        kk, rr = divmod(prob.numel(), world)
+        b = rank * kk + min(rank, rr); e = b + kk + (1 if rank < rr else 0)
+        st = S.operator_statistics(el[b:e], prob[b:e] * world, 4000, "E")
+        one = S.dist_stats_onepass(el[b:e], prob[b:e] * world, 4000, world)
+        res["stats"] = ({k_: np.asarray(st[k_]) for k_ in ("mean", "var", "sd", "se")}, [np.asarray(t_) for t_ in one])
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_two_against_reference_vectors():
+    world = 2
+    out = _spawn(_golden_worker, world)
+    gf, sm = golden("gfmc_fe2s2.npz"), golden("sampler_merge.npz")
+    for rank, res in out:
+        for key in [k for k in res if k.startswith("grad_")]:
+            got, want = res[key]
+            for name, w in want.items():
+                np.testing.assert_allclose(got[name], w, rtol=1e-10, atol=1e-10 * np.abs(w).max(), err_msg=f"{key} {name} rank {rank}")
+        assert np.array_equal(res["branch"], gf[f"branch_ws2_out_r{rank}"])
+        for t in (0, 1):
+            u, p, keys, wf, mc = res[f"gs{t}"]
+            pre = f"tree{t}_r{rank}_"
+            assert np.array_equal(u, sm[pre + "unique_rank"])
+            np.testing.assert_allclose(p, sm[pre + "prob_rank"], rtol=1e-15)
+            assert np.array_equal(keys, sm[pre + "lut_keys"]) and np.array_equal(wf, sm[pre + "lut_wf"])
+            assert np.array_equal(mc, sm[f"tree{t}_r0_all_counts"])  # the reference keeps the merged counts on rank 0 only
+        st, one = res["stats"]
+        for k in ("mean", "var", "sd", "se"):
+            np.testing.assert_allclose(st[k], sm["stats_ws2_" + k], rtol=1e-12)
+        np.testing.assert_allclose(one[0], sm["stats_ws2_mean"], rtol=1e-12)
+        np.testing.assert_allclose(one[1], sm["stats_ws2_var"], rtol=1e-7)
+
+
+def test_world_size_one_against_reference_vectors():
+    from pynqs_amd import C_extension as cx, gfmc, stats as S
+
+    gf, sm = golden("gfmc_fe2s2.npz"), golden("sampler_merge.npz")
+    xb = gfmc.branching(torch.from_numpy(gf["branch_x"].copy()), torch.from_numpy(gf["branch_w"].copy()), torch.from_numpy(gf["branch_ws1_xi"].copy()))
+    assert np.array_equal(xb.numpy(), gf["branch_ws1_out"])
+    st = S.operator_statistics(torch.from_numpy(sm["stats_ws1_eloc"].copy()), torch.from_numpy(sm["stats_ws1_prob"].copy()), 4000, "E")
+    for k in ("mean", "var", "sd", "se"):
+        np.testing.assert_allclose(np.asarray(st[k]), sm["stats_ws1_" + k], rtol=1e-12)
+    # merge_rank_sample (cpu_tensor.cpp:537-556): scatter-add of the per-rank counts; host tensors in, host tensor out
+    got = cx.merge_rank_sample(torch.from_numpy(sm["mrs_inv"].copy()), torch.from_numpy(sm["mrs_counts"].copy()), torch.from_numpy(sm["mrs_split"].copy()),
+                               int(sm["mrs_length"]))
+    assert np.array_equal(got.numpy(), sm["mrs_out"])

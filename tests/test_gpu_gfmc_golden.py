@@ -1,0 +1,70 @@
+"""GFMC step and sampler natives on the GPU against vectors captured from the reference's Python (gfmc/walker.py:167-279,
+cpp_src/tensor/cpu_tensor.cpp:537-556; tests/golden/make_golden_r2.py -> gfmc_fe2s2.npz, sampler_merge.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fused_sample", [True, False])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_green_kernel_and_move_match_reference_python(fe2s2, tag, fused_sample):
+    """_calculate_green_kernel (fixed-node effective Hamiltonian, sign-flip potential, clamp of negative diagonal kernels:
+    case b clamps 5 of the 16 walkers) and sample_update with the reference's uniforms."""
+    from pynqs_amd import gfmc, public_function as pf
+    from pynqs_amd.rbm import RealRBM
+
+    d, e0 = golden("gfmc_fe2s2.npz"), golden("eloc_e2e_fe2s2.npz")
+    dev = torch.device("cuda")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    old = gfmc.FUSED_SAMPLE
+    try:
+        gfmc.FUSED_SAMPLE = fused_sample
+        rbm = RealRBM(T(e0["W"]), T(e0["hb"]), T(e0["vb"])).to(dev)
+        ab = lambda x, func: pf.ansatz_batch(func, x, 100000, 40, dev, torch.double)  # noqa: E731
+        x = T(d["x"])
+        eloc, gk, comb, stop, mask = gfmc.green_kernel(x, float(d[tag + "_Lambda"]), T(fe2s2["h1e"]), T(fe2s2["h2e"]), rbm, ab, 40, 30, 15, 15,
+                                                       torch.double, None, True)
+        assert stop is False
+        np.testing.assert_allclose(eloc.cpu().numpy(), d[tag + "_eloc"], rtol=0, atol=1e-8)
+        assert np.array_equal(mask.cpu().numpy(), d[tag + "_mask"])
+        np.testing.assert_allclose(gk[:4].cpu().numpy(), d[tag + "_gk4"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(gk[:, 0].cpu().numpy(), d[tag + "_gk_col0"], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(gk.sum(-1).cpu().numpy(), d[tag + "_gk_rowsum"], rtol=1e-11)
+        x_new, w_new, beta, acc = gfmc.sample_update(x, T(d[tag + "_weight"]), comb, gk, T(d[tag + "_rand"]))
+        assert np.array_equal(x_new.cpu().numpy(), d[tag + "_x_new"])
+        np.testing.assert_allclose(w_new.cpu().numpy(), d[tag + "_w_new"], rtol=1e-11)
+        np.testing.assert_allclose(beta.cpu().numpy().reshape(-1), d[tag + "_beta"].reshape(-1), rtol=1e-11)
+        assert acc == int(d[tag + "_accept"])
+    finally:
+        gfmc.FUSED_SAMPLE = old
+        torch.set_default_dtype(old_dt)
+
+
+def test_merge_rank_sample_matches_reference():
+    from pynqs_amd import C_extension as cx
+
+    sm = golden("sampler_merge.npz")
+    dev = torch.device("cuda")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    got = cx.merge_rank_sample(T(sm["mrs_inv"]), T(sm["mrs_counts"]), T(sm["mrs_split"]), int(sm["mrs_length"]))
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), sm["mrs_out"])
+    # the merge of the sampler protocol itself: tensor_to_onv of the occupations, unique + merged counts as rank 0 of the reference
+    for t in (0, 1):
+        occ = np.concatenate([sm[f"tree{t}_r{r}_occ"] for r in (0, 1)])
+        cnt = np.concatenate([sm[f"tree{t}_r{r}_counts"] for r in (0, 1)])
+        onv = cx.tensor_to_onv(T(occ), 40)
+        if t == 0:
+            from pynqs_amd.sample_comm import torch_unique_index
+
+            mu, inv, idx, _ = torch_unique_index(onv)
+            mc = cx.merge_rank_sample(inv.contiguous(), T(cnt), T(np.array([0, sm["tree0_r0_occ"].shape[0], occ.shape[0]])), mu.size(0))
+        else:
+            mu, mc = onv, T(cnt)
+        assert np.array_equal(mc.cpu().numpy(), sm[f"tree{t}_r0_all_counts"])
+        assert np.array_equal(mu.cpu().numpy(), np.concatenate([sm[f"tree{t}_r{r}_unique_rank"] for r in (0, 1)]))

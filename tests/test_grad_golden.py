@@ -1,0 +1,33 @@
+"""pynqs_amd.grad.grad against parameter gradients captured from the reference's vmc/grad/energy_grad.py:118-184 (run under
+DistributedDataParallel on its own RBM / on the complex128 module; tests/golden/make_golden_r2.py -> grad_fe2s2.npz).
+CPU: the estimator is host logic (autograd).  The world_size-2 form is in test_distributed_cpu.py, the CUDA form below (gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GRAD_CASES, grad_case
+
+RTOL = 1e-10
+
+
+def _run(device):
+    from pynqs_amd.grad import grad
+
+    for kind, amd, use_pow in GRAD_CASES:
+        m, states, prob, eloc, e_total, powr, dt, amd_, want = grad_case(kind, amd, use_pow, device)
+        loss = grad(m, states, prob, eloc, e_total, powr, dt, amd_)
+        assert loss.shape == (1,) and loss.dtype == torch.float64
+        got = dict(m.named_parameters())
+        assert set(got) == set(want)
+        for name, w in want.items():
+            scale = np.abs(w).max()
+            np.testing.assert_allclose(got[name].grad.cpu().numpy(), w, rtol=RTOL, atol=RTOL * scale, err_msg=f"{kind} {amd} {name}")
+
+
+def test_grad_matches_reference_cpu():
+    _run("cpu")
+
+
+@pytest.mark.gpu
+def test_grad_matches_reference_gpu():
+    _run("cuda")
