@@ -11,6 +11,11 @@ line (the contract of the build prompt) with `roofline` (dominant kernel, live H
 `cpu_baseline` (reference/oracle timed on the host cores, rank 0, N = 1 only).
 
 Workloads (config.workload):
+  fe2s2_vmc_step (default)   one COMPLETE local-energy step of a VMC iteration on this rank's shard of the walkers
+                 (BASELINE configs C3/C4 on the shipped Fe2S2 problem): fused SAMPLE_SPACE local energies (enumerate, <x|H|x'>,
+                 psi(x') from the sample table, contraction: one kernel) -> weighted moments kernel + ONE packed RCCL all-reduce
+                 of (sum p E, sum p |E|^2, sum p) -> gradient estimator: micro-batched backward of a complex128 module under
+                 DistributedDataParallel (bucketed RCCL all-reduce in the last micro-batch), vmc/grad/energy_grad.py:118-184.
   fe2s2_dropin   get_comb_hij_fused on the shipped Fe2S2 problem (sorb 40, 15a15b, ncomb 7876):
                  comb + Hmat materialised exactly like the reference API (HBM-write bound).
   syn<sorb>_dropin  same on synthetic dense integrals, sorb in {56, 120, 184}.
@@ -18,7 +23,7 @@ Workloads (config.workload):
                  kernel + packed all-reduce.
   fe2s2_eloc_rbm / syn<sorb>_eloc_rbm   complete SIMPLE local energies with a real RBM (alpha = 2) evaluated inside the
                  kernel; the RBM table is rebuilt every step (parameters change every optimisation step).
-With the default workload and N = 1 the line also carries `extra`: the fused workloads above, the larger systems, the
+With the default workload and N = 1 the line also carries `extra`: the drop-in rows/s, the other fused workloads, the larger systems, the
 REDUCE compaction throughput and the generic PyTorch-module paths, each measured in the same run.
 Inputs are resident in HBM before the timed region.  Nothing here reads /root/reference.
 """
@@ -38,6 +43,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+# vector-ALU issue peak in wave64 instructions per second: 256 CUs x 4 SIMDs x 2.4 GHz / VALU_CYCLES cycles per instruction.
+# VALU_CYCLES: tools/micro/valu_peak.hip on one MI355X (profiles/r02_valu_peak.txt)
+VALU_CYCLES = 2.0
+VALU_PEAK_GINST = 256 * 4 * 2.4 / VALU_CYCLES
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -101,6 +110,14 @@ def algorithmic_bytes_dropin(sorb, nele, noA, noB, esize=8):
     return gathers + out + 8 * L, ncomb
 
 
+def dropin_byte_parts(sorb, nele, noA, noB, esize=8):
+    """(integral gathers, outputs, inputs) in bytes per walker: the three terms of algorithmic_bytes_dropin."""
+    total, ncomb = algorithmic_bytes_dropin(sorb, nele, noA, noB, esize)
+    L = (sorb - 1) // 64 + 1
+    out = ncomb * (esize + 8 * L)
+    return total - out - 8 * L, out, 8 * L
+
+
 # ---------------------------------------------------------------------------------------------------
 class Workload:
     name = ""
@@ -123,6 +140,7 @@ class DropinFused(Workload):
         self.h1, self.h2, self.x = h1.to(dev), h2.to(dev), walkers.to(dev).contiguous()
         self.n = self.x.size(0)
         self.bytes_per_walker, self.ncomb = algorithmic_bytes_dropin(sorb, nele, noA, noB)
+        self.gather_bytes_per_walker, self.out_bytes_per_walker, self.in_bytes_per_walker = dropin_byte_parts(sorb, nele, noA, noB)
         L = (sorb - 1) // 64 + 1
         self.comb = torch.empty((self.n, self.ncomb, 8 * L), dtype=torch.uint8, device=dev)
         self.hmat = torch.empty((self.n, self.ncomb), dtype=torch.float64, device=dev)
@@ -205,7 +223,7 @@ class DropinFused(Workload):
             if time.perf_counter() - t0 > budget_s * 0.8 or reps >= 50:
                 break
         el = time.perf_counter() - t0
-        out = {"value": done / el, "unit": "local energies/s", "cores": cores, "kind": kind,
+        out = {"value": done / el, "unit": "S+D rows/s", "cores": cores, "kind": kind,
                "sample": f"{reps} x get_comb_hij_fused on the first {sample} walkers of the same batch ({el:.1f} s)"}
         # the reference's production setting is OMP_NUM_THREADS=1 per GPU process (run.sh:3): the same call on one thread
         try:
@@ -218,7 +236,7 @@ class DropinFused(Workload):
             t0 = time.perf_counter(); r1 = 0
             while time.perf_counter() - t0 < 2.0:
                 one(x[:m1].contiguous()); r1 += 1
-            out["one_thread"] = {"value": m1 * r1 / (time.perf_counter() - t0), "unit": "local energies/s", "cores": 1,
+            out["one_thread"] = {"value": m1 * r1 / (time.perf_counter() - t0), "unit": "S+D rows/s", "cores": 1,
                                  "sample": f"{r1} x the same call on the first {m1} walkers"}
         finally:
             if kind == "reference":
@@ -263,9 +281,9 @@ class SampleSpaceFused(Workload):
         self.psi0 = torch.empty(self.n, dtype=torch.complex128, device=dev)
         self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
         self.dev, self.path, self.kernel = dev, "plan", "eloc_sample_space_filtered_kernel"
-        self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered, so the "
-                              "SURVEY 8(d) byte count is an upper bound of what is read; the kernel is bound by the vector ALU "
-                              "(profiles/r01_*_eloc_sample_space_*_filtered.txt: VALU busy 90-97 %)")
+        self.bound, self.pmc_name = "valu", f"{tag}_eloc_sample_space"
+        self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered; HBM traffic is "
+                              "negligible and the kernel is bound by vector-ALU instruction issue (29-41 instructions per column)")
         self.stats = None
 
     def step(self):
@@ -394,6 +412,114 @@ class RbmFused(Workload):
                 "sample": f"{reps} x oracle eloc_simple_rbm (C restatement: materialise + RBM forward on every x', OpenMP) on the first {sample} walkers ({el:.1f} s)"}
 
 
+class VmcStep(SampleSpaceFused):
+    """One complete local-energy step of a VMC iteration for this rank's walker shard (north star):
+      1. E_loc(x) for every walker: fused SAMPLE_SPACE kernel (psi(x') from the hash table of the sampled determinants, complex128);
+      2. <E>, var: weighted-moments kernel + ONE packed all-reduce of 4 doubles over the ranks (RCCL; dist_stats.py:18-56 issues two
+         all-reduce + barrier pairs);
+      3. gradient estimator (energy_grad.py:118-184): +-1 states (onv_to_tensor), loss = 2 Re sum p conj(ln psi)(E_loc - <E>) in
+         micro-batches under DistributedDataParallel.no_sync(), the last backward runs DDP's bucketed all-reduce (RCCL over xGMI).
+    The amplitude module is a complex128 RBM (alpha = 1, seeded; ansatz families are outside this package) standing in for the example's
+    BDG-RNN: its forward/backward on 8192 x 40 inputs is ~60 small PyTorch kernels, reported separately as `grad_ms`."""
+
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev, micro_batch=4096):
+        super().__init__(tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev)
+        import torch.distributed as dist
+
+        from pynqs_amd import C_extension as cx, grad as G
+        from pynqs_amd.rbm import ComplexRBM
+
+        self.name = f"{tag}_vmc_step"
+        self.cx, self.G = cx, G
+        g = torch.Generator().manual_seed(7)
+        H = sorb
+        m = ComplexRBM(0.02 * (torch.rand(H, sorb, 2, generator=g, dtype=torch.float64) - 0.5),
+                       0.02 * (torch.rand(H, 2, generator=g, dtype=torch.float64) - 0.5),
+                       0.05 * (torch.rand(sorb, 2, generator=g, dtype=torch.float64) - 0.5)).to(dev)
+        self.module = m
+        self.nqs = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) if dist.is_initialized() else m
+        self.micro_batch = micro_batch
+        self.phase_events = []
+
+    def step(self):
+        st = torch.cuda.current_stream(self.dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record(st)
+        ht = self.lut.hashtable
+        rc = self.lib.pynqs_eloc_sample_space_hash(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
+                                                   self.plan.data_ptr(), ht.table.data_ptr(), ht.nkeys, self.lut.wf_value.data_ptr(), 1,
+                                                   self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
+        ev[1].record(st)
+        self.N.check(rc, "pynqs_eloc_sample_space")
+        from pynqs_amd.distributed import get_world_size
+        from pynqs_amd.stats import dist_stats_moments
+
+        self.stats = dist_stats_moments(self.eloc, self.prob, None, get_world_size())
+        ev[2].record(st)
+        states = self.cx.onv_to_tensor(self.x, self.sorb)
+        for p in self.module.parameters():
+            p.grad = None
+        self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, torch.complex128, self.micro_batch)
+        ev[3].record(st)
+        self.phase_events.append(ev)
+        return ev[0], ev[1]
+
+    def phases_ms(self):
+        """Mean GPU-timeline duration of (E_loc kernel, moments + all-reduce, states + gradient estimator) over the recorded steps."""
+        evs, self.phase_events = self.phase_events, []
+        if not evs:
+            return None
+        k = len(evs)
+        return {"eloc_kernel_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / k,
+                "stats_allreduce_ms": sum(e[1].elapsed_time(e[2]) for e in evs) / k,
+                "grad_ms": sum(e[2].elapsed_time(e[3]) for e in evs) / k}
+
+    def cpu_baseline(self, budget_s=15.0):
+        """The reference's own CPU extension (oracle/_ref, compiled from its sources where they lie) running the reference's
+        SAMPLE_SPACE algorithm (vmc/energy/eloc.py:326-401): get_comb_hij_fused -> wavefunction_lut on all x' -> scatter of the hits
+        -> contraction, on 16 host threads and on 1 (run.sh:3).  Falls back to the oracle port when oracle/_ref is absent."""
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")
+        if not (self.sorb <= 64 and os.path.exists(os.path.join(ref_dir, "C_extension.so"))):
+            return super().cpu_baseline(budget_s)
+        sys.path.insert(0, ref_dir)
+        import C_extension as ref  # noqa: the reference module, MAX_SORB_LEN = 1
+
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        x = self.x.cpu(); h1 = self.h1.cpu(); h2 = self.h2.cpu()
+        keys = self.lut.bra_key.cpu().contiguous(); wf = self.lut.wf_value.cpu()
+
+        def fn(m):
+            xs = x[:m].contiguous()
+            comb, hij = ref.get_comb_hij_fused(xs, h1, h2, self.sorb, self.nele, self.noA, self.noB)
+            flat = comb.reshape(-1, comb.size(2))
+            idx, mask = ref.wavefunction_lut(keys, flat, self.sorb)
+            psi = torch.zeros(flat.size(0), dtype=wf.dtype)
+            psi[mask] = wf[idx[mask]]
+            psi = psi.reshape(m, -1)
+            return ((psi.T / psi[:, 0]).T * hij).sum(-1)
+
+        def run(threads, budget):
+            torch.set_num_threads(threads)
+            m = 64
+            t0 = time.perf_counter(); e = fn(m); per = (time.perf_counter() - t0) / m
+            sample = int(max(64, min(self.n, 2048, budget * 0.25 / max(per, 1e-9))))
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget * 0.8 and reps < 100:
+                e = fn(sample); reps += 1
+            el = time.perf_counter() - t0
+            return sample * reps / el, sample, reps, el, e
+
+        v16, s16, r16, el16, e = run(cores, budget_s)
+        dev_e = self.eloc[: e.numel()].cpu()
+        agree = float((dev_e - e).abs().max())
+        v1, s1, r1, el1, _ = run(1, 3.0)
+        torch.set_num_threads(cores)
+        return {"value": v16, "unit": "local energies/s", "cores": cores, "kind": "reference",
+                "sample": f"{r16} x (reference get_comb_hij_fused + wavefunction_lut + contraction, eloc.py:326-401) on the first {s16} walkers of the same batch ({el16:.1f} s)",
+                "max_abs_diff_gpu_vs_reference": agree,
+                "one_thread": {"value": v1, "unit": "local energies/s", "cores": 1, "sample": f"{r1} x the same on the first {s1} walkers ({el1:.1f} s)"}}
+
+
 class DecoderAmplitude(torch.nn.Module):
     """Stand-in for BASELINE.json's 'Transformer ansatz' (DecoderWaveFunction defaults d_model 32, 6 layers,
     8 heads, vmc/ansatz/transformer/decoder.py:43-69): an autoregressive decoder over the sorb/2 spatial orbitals (4 occupation
@@ -421,6 +547,12 @@ class DecoderAmplitude(torch.nn.Module):
 
 
 def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", keys: int = 65536) -> Workload:
+    if name == "fe2s2_vmc_step":
+        d = load_fe2s2()
+        ci = d["ci_space"]
+        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        return VmcStep("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
+                       torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), torch.from_numpy(ci.copy()), dev)
     if name == "fe2s2_eloc_sample_space":
         d = load_fe2s2()
         ci = d["ci_space"]
@@ -466,11 +598,11 @@ def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", k
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step of the headline workload takes 0.2-0.25 ms: 2000 steps = half a second of measurement.  (With 50 steps the GPU
-    # is still ramping up: 0.243 ms per step against 0.208 ms sustained.)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="fe2s2_dropin")
+    # a step of the headline workload takes about a millisecond; an untimed pre-heat (below) brings the clocks up before the
+    # W warm-up steps, so that short runs (--steps 20) measure sustained clocks too
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="fe2s2_vmc_step")
     ap.add_argument("--walkers", type=int, default=8192, help="walkers per GPU")
     ap.add_argument("--keys", type=int, default=65536, help="sample-space size of the syn<sorb>_eloc_sample_space workloads")
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
@@ -489,11 +621,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.workload.endswith("_vmc_step"):
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            # N = 1 runs the same code path as N > 1 (DDP wrapper, RCCL calls on a one-rank communicator)
+            import socket
+
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     wl = make_workload(args.workload, args.walkers, rank, dev, args.path, args.keys)
     if args.no_comb:
@@ -504,9 +643,22 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
+    def preheat(w, seconds=0.4):
+        """Untimed: run the step until the GPU has been busy for `seconds` (clock ramp-up), then drop the recorded events."""
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                w.step()
+            torch.cuda.synchronize(dev)
+        if hasattr(w, "phase_events"):
+            w.phase_events = []
+
     def timed(w, warmup, steps):
+        preheat(w)
         for _ in range(warmup):
             w.step()
+        if hasattr(w, "phase_events"):
+            w.phase_events = []
         barrier()
         t0 = time.perf_counter()
         events = [w.step() for _ in range(steps)]
@@ -519,35 +671,57 @@ def main():
         return float(tmax.item()), kern_ms
 
     def roofline(w, kern_ms):
+        """Roofline of the workload's dominant kernel from its live HIP-event duration.
+        HBM-bound kernels (drop-in rows): achieved = HBM-MANDATORY bytes per launch / time, against 8 TB/s.  Mandatory = what has to cross
+        the HBM interface with perfect caches: outputs + walkers + each integral-plan byte at most once (min(gathers, plan)); SURVEY 8(d)'s
+        algorithmic bytes, which count every gather as HBM traffic although the Fe2S2 plan (2 MiB) lives in the L2, are kept beside it.
+        Vector-ALU-bound kernels: achieved = VALU wave64-instructions per launch (rocprofv3 SQ_INSTS_VALU from profiles/pmc_<workload>.json,
+        scaled to this launch's walkers) / time, against the chip's issue rate CUs x SIMDs x clock / cycles-per-instruction."""
+        t = kern_ms * 1e-3
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{getattr(w, 'pmc_name', w.name)}.json")
+        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        if traffic is not None and pmc.get("walkers"):
+            traffic = traffic * w.n / pmc["walkers"]
         if hasattr(w, "flops_per_walker"):  # f64 vector-ALU bound kernel
-            ach = w.flops_per_walker * w.n / (kern_ms * 1e-3) / 1e12
-            return {"bound": "valu_f64", "kernel": w.kernel, "achieved": ach, "peak": w.F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / w.F64_VECTOR_PEAK_TFLOPS, "traffic": None, "kernel_ms": kern_ms,
-                    "algorithmic_flops_per_launch": w.flops_per_walker * w.n}
-        ach = w.bytes_per_walker * w.n / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"pmc_{w.name}.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        out = {"bound": "hbm", "kernel": w.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-               "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": w.bytes_per_walker * w.n}
+            ach = w.flops_per_walker * w.n / t / 1e12
+            out = {"bound": "valu_f64", "kernel": w.kernel, "achieved": ach, "peak": w.F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": ach / w.F64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "kernel_ms": kern_ms,
+                   "algorithmic_flops_per_launch": w.flops_per_walker * w.n}
+        elif getattr(w, "bound", "hbm") == "valu":
+            insts = pmc.get("valu_insts_per_launch")
+            if insts is not None:
+                insts = insts * w.n / pmc["walkers"]
+            peak = VALU_PEAK_GINST
+            ach = insts / t / 1e9 if insts else None
+            out = {"bound": "valu", "kernel": w.kernel, "achieved": ach, "peak": peak, "unit": "G wave64-instr/s",
+                   "frac": ach / peak if ach else None, "traffic": traffic, "kernel_ms": kern_ms, "valu_instructions_per_launch": insts,
+                   "columns_per_s": w.ncomb * w.n / t,
+                   "source": pmc.get("source", f"no {os.path.basename(pmc_path)}: instruction count unknown")}
+        else:
+            plan_bytes = w.plan.numel() * w.plan.element_size() if getattr(w, "plan", None) is not None else w.gather_bytes_per_walker * w.n
+            mandatory = (w.out_bytes_per_walker + w.in_bytes_per_walker) * w.n + min(w.gather_bytes_per_walker * w.n, plan_bytes)
+            ach = mandatory / t / 1e9
+            alg = w.bytes_per_walker * w.n
+            out = {"bound": "hbm", "kernel": w.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                   "traffic": traffic, "kernel_ms": kern_ms, "hbm_mandatory_bytes_per_launch": mandatory,
+                   "algorithmic_bytes_per_launch": alg, "algorithmic_frac": alg / t / 1e9 / HBM_PEAK_GBS}
+            if traffic:
+                out["hbm_traffic_frac"] = traffic / t / 1e9 / HBM_PEAK_GBS
         if getattr(w, "roofline_note", None):
             out["note"] = w.roofline_note
-        if traffic:
-            # the algorithmic bytes count every integral gather once; for Fe2S2 they are served by the L2, so the
-            # fraction can pass 1.  What actually crossed the HBM interface, against the same 8 TB/s:
-            out["hbm_traffic_frac"] = traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         return out
 
     el, kern_ms = timed(wl, args.warmup, args.steps)
+    phases = wl.phases_ms() if hasattr(wl, "phases_ms") else None
 
     if rank == 0:
         ok_c, dh = wl.parity_gate()
         total_walkers = wl.n * world * args.steps
         out = {
-            "metric": "local energies/sec (whole node)",
+            "metric": "local energies/sec (whole node)" if not isinstance(wl, DropinFused) else "S+D rows/sec: enumerate + <x|H|x'> materialised, no psi (whole node)",
             "value": total_walkers / el,
-            "unit": "local energies/s",
+            "unit": "local energies/s" if not isinstance(wl, DropinFused) else "S+D rows/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -560,17 +734,23 @@ def main():
                     else "synthetic (seeded dense integrals, random walkers)",
             "config": {"workload": wl.name, "sorb": wl.sorb, "nele": wl.nele, "ncomb": wl.ncomb,
                        "walkers_per_gpu": wl.n, "integral_layout": wl.path, "plan_build_ms": wl.plan_build_ms,
-                       "parallelism": f"walker-sharded x{world}" + (", packed RCCL all-reduce of <E_loc>, <|E_loc|^2>" if hasattr(wl, "stats") else ", no data-path collective")},
+                       "parallelism": f"walker-sharded x{world} (one process per GPU)" + (
+                           "; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p); DDP bucketed RCCL all-reduce of the gradient estimator"
+                           if isinstance(wl, VmcStep) else "; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p)" if hasattr(wl, "stats")
+                           else "; no data-path collective")},
             "roofline": roofline(wl, kern_ms),
             "parity": {"exact_part_bit_exact": bool(ok_c), "max_abs_diff_vs_oracle": dh} if ok_c is not None
                       else "oracle too slow at this size (tests/ cover the kernel at sizes it finishes)",
         }
+        if isinstance(wl, VmcStep):
+            out["step_phases_gpu_ms"] = phases
+            out["config"]["amplitude_module"] = "complex128 RBM, alpha = 1 (stand-in for the example's BDG-RNN), micro-batches of %d walkers" % wl.micro_batch
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
-    # secondary measurements (same run, N = 1 only): the complete fused local energy and the larger word counts
-    if world == 1 and not args.no_extra and args.workload == "fe2s2_dropin":
+    # secondary measurements (same run, N = 1 only): drop-in rows, the other fused local energies and the larger word counts
+    if world == 1 and not args.no_extra and args.workload in ("fe2s2_dropin", "fe2s2_vmc_step"):
         extra = {}
-        for name, nw, steps in (("fe2s2_eloc_sample_space", args.walkers, 1000), ("fe2s2_eloc_rbm", args.walkers, 500),
+        for name, nw, steps in (("fe2s2_dropin", args.walkers, 2000), ("fe2s2_eloc_sample_space", args.walkers, 1000), ("fe2s2_eloc_rbm", args.walkers, 500),
                                 ("syn56_eloc_rbm", 4096, 200), ("syn120_dropin", 64, 500), ("syn184_dropin", 16, 200),
                                 ("syn120_eloc_sample_space", args.walkers, 10), ("syn120_eloc_rbm", 512, 10),
                                 ("syn184_eloc_sample_space", 1024, 5), ("syn184_eloc_rbm", 128, 3)):
@@ -578,11 +758,12 @@ def main():
                 w2 = make_workload(name, nw, rank, dev, args.path)
                 el2, k2 = timed(w2, max(2, steps // 10), steps)
                 ok2, d2 = w2.parity_gate()
-                extra[w2.name] = {"value": w2.n * steps / el2, "unit": "local energies/s", "walkers": w2.n, "ncomb": w2.ncomb,
+                extra[w2.name] = {"value": w2.n * steps / el2, "unit": "S+D rows (enumerate + <x|H|x'>, no psi)/s" if name.endswith("_dropin") else "local energies/s",
+                                  "walkers": w2.n, "ncomb": w2.ncomb,
                                   "ms_per_step": el2 / steps * 1e3, "roofline": roofline(w2, k2),
                                   "parity": {"exact_part_bit_exact": bool(ok2), "max_abs_diff_vs_oracle": d2} if ok2 is not None
                                             else "oracle too slow at this size (tests/ cover the kernel at sizes it finishes)"}
-                if name in ("fe2s2_eloc_sample_space", "fe2s2_eloc_rbm") and not args.no_cpu_baseline:
+                if name in ("fe2s2_dropin", "fe2s2_eloc_rbm") and not args.no_cpu_baseline:
                     extra[w2.name]["cpu_baseline"] = w2.cpu_baseline(budget_s=8.0)
                 del w2
                 torch.cuda.empty_cache()

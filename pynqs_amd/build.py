@@ -31,10 +31,33 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_one(args):
+    src, obj, verbose = args
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
+    """One object per .hip file (recompiled only when it or a header is newer), compiled in parallel, then linked."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + sources()
+    from concurrent.futures import ThreadPoolExecutor
+
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(d) for d in glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(_HERE, "..", "include", "pynqs_amd.h")])
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append((src, obj, verbose))
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(_compile_one, jobs))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
