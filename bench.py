@@ -422,7 +422,7 @@ class VmcStep(SampleSpaceFused):
     The amplitude module is a complex128 RBM (alpha = 1, seeded; ansatz families are outside this package) standing in for the example's
     BDG-RNN: its forward/backward on 8192 x 40 inputs is ~60 small PyTorch kernels, reported separately as `grad_ms`."""
 
-    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev, micro_batch=4096):
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev, micro_batch=50000):
         super().__init__(tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev)
         import torch.distributed as dist
 
@@ -744,7 +744,7 @@ def main():
         }
         if isinstance(wl, VmcStep):
             out["step_phases_gpu_ms"] = phases
-            out["config"]["amplitude_module"] = "complex128 RBM, alpha = 1 (stand-in for the example's BDG-RNN), micro-batches of %d walkers" % wl.micro_batch
+            out["config"]["amplitude_module"] = "complex128 RBM, alpha = 1 (stand-in for the example's BDG-RNN), AD_MAX_DIM = %d as in example/Fe2S2 (one micro-batch for 8192 walkers)" % wl.micro_batch
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
     # secondary measurements (same run, N = 1 only): drop-in rows, the other fused local energies and the larger word counts

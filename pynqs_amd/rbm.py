@@ -22,7 +22,9 @@ class RealRBM(nn.Module):
         wext = torch.cat([self.weights, self.visible_bias.unsqueeze(0)], 0)
         bext = torch.cat([self.hidden_bias, self.hidden_bias.new_zeros(1)])
         z = torch.addmm(bext, x, wext.T)
-        return z[:, -1].exp() * (2 * z[:, :-1].cosh()).prod(-1)
+        # exp(a.x + sum ln 2cosh theta): the product of rbm.py:205-206 without prod(), whose backward synchronises with the host
+        # (it looks for zeros with nonzero()) and therefore cannot be captured in a HIP graph (pynqs_amd.grad.GraphedGrad)
+        return (z[:, -1] + (2 * z[:, :-1].cosh()).log().sum(-1)).exp()
 
 
 class ComplexRBM(nn.Module):
@@ -42,4 +44,7 @@ class ComplexRBM(nn.Module):
         b = torch.view_as_complex(self.params_hidden_bias)
         a = torch.view_as_complex(self.params_visible_bias)
         xc = x.to(W.dtype)
-        return torch.mv(xc, a).exp() * (2 * (torch.mm(xc, W.T) + b).cosh()).prod(-1)
+        # exp(sum ln 2cosh) instead of prod: the same value (exp(ln z) = z on every branch), and its backward has no
+        # data-dependent host synchronisation (prod's looks for zeros with nonzero()), so the gradient step can be
+        # captured in a HIP graph (pynqs_amd.grad.GraphedGrad)
+        return (torch.mv(xc, a) + (2 * (torch.mm(xc, W.T) + b).cosh()).log().sum(-1)).exp()
