@@ -91,13 +91,16 @@ class IntegralPlan:
     Built once per pair of integral tensors; values are copies of h1e/h2e elements, so every kernel that
     reads the plan returns bit-identical numbers to the direct-layout kernels."""
 
-    def __init__(self, h1e: Tensor, h2e: Tensor, sorb: int):
+    def __init__(self, h1e: Tensor, h2e: Tensor, sorb: int, device: "torch.device | None" = None):
         code = _fdtype(h1e, h2e)
         _check_integrals(h1e, h2e, sorb)
         nbytes = N.lib().pynqs_plan_bytes(sorb, code)
         if nbytes < 0:
             raise RuntimeError(f"integral plan needs an even sorb in [2, {MAX_SORB}], got {sorb}")
         dev, (a, b), _ = _stage(h1e, h2e)
+        if device is not None and device.type == "cuda" and all(t.device.type == "cpu" for t in (h1e, h2e)):
+            # host-resident integrals go to the device of the walkers, not to the current device
+            dev, a, b = device, h1e.to(device), h2e.to(device)
         self.sorb, self.code, self.dtype, self.device = sorb, code, h1e.dtype, dev
         self.buf = torch.empty(nbytes // h1e.element_size(), dtype=h1e.dtype, device=dev)
         N.check(N.lib().pynqs_plan_build(a.data_ptr(), b.data_ptr(), sorb, code, self.buf.data_ptr(), _stream(dev)), "plan_build")
@@ -111,23 +114,36 @@ class IntegralPlan:
 
 _PLANS: "list[tuple]" = []  # (weakref(h1e), weakref(h2e), versions, sorb, plan), most recent first
 _MAX_PLANS = 4
+_PLAN_BUILDS: "dict[tuple, int]" = {}  # (sorb, numel of h2e, device) -> number of plans built; a climbing count = a caller that re-creates the integrals
+_PLAN_REBUILD_WARN = 16
 
 
-def plan_for(h1e: Tensor, h2e: Tensor, sorb: int) -> "IntegralPlan | None":
-    """Cached IntegralPlan for these tensor objects (None when sorb is odd -> direct kernels)."""
+def plan_for(h1e: Tensor, h2e: Tensor, sorb: int, device: "torch.device | None" = None) -> "IntegralPlan | None":
+    """Cached IntegralPlan for these tensor objects (None when sorb is odd -> direct kernels).  The cache is keyed on the
+    tensor OBJECTS (identity, version counter, storage address): keep h1e / h2e alive between calls.  `device`: where
+    host-resident integrals are staged (the walkers' device)."""
     import weakref
 
     if sorb % 2 or sorb < 2:
         return None
     ver = (h1e._version, h2e._version, h1e.data_ptr(), h2e.data_ptr())
     for i, (r1, r2, v, s, pl) in enumerate(_PLANS):
-        if r1() is h1e and r2() is h2e and v == ver and s == sorb:
+        if r1() is h1e and r2() is h2e and v == ver and s == sorb and (device is None or device.type != "cuda" or pl.device == device
+                                                                       or h1e.device.type == "cuda"):
             if i:
                 _PLANS.insert(0, _PLANS.pop(i))
             return pl
-    pl = IntegralPlan(h1e, h2e, sorb)
+    pl = IntegralPlan(h1e, h2e, sorb, device)
     _PLANS.insert(0, (weakref.ref(h1e), weakref.ref(h2e), ver, sorb, pl))
     del _PLANS[_MAX_PLANS:]
+    key = (sorb, h2e.numel(), str(pl.device))
+    _PLAN_BUILDS[key] = _PLAN_BUILDS.get(key, 0) + 1
+    if _PLAN_BUILDS[key] == _PLAN_REBUILD_WARN:
+        import warnings
+
+        warnings.warn(f"pynqs_amd: the integral plan for sorb = {sorb} ({pl.buf.numel() * pl.buf.element_size() / 2**20:.0f} MiB) has been rebuilt "
+                      f"{_PLAN_REBUILD_WARN} times: the caller passes new h1e / h2e tensor objects (or modifies them in place) on every call. "
+                      "Keep the same tensors alive between calls to reuse the plan.", RuntimeWarning, stacklevel=3)
     return pl
 
 
@@ -210,7 +226,7 @@ def get_comb_hij_fused(bra: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: i
     if bra.numel() == 0:
         return (torch.empty((0, ncomb, 8 * L), dtype=torch.uint8, device=bra.device),
                 torch.empty((0, ncomb), dtype=h1e.dtype, device=h1e.device))
-    plan = plan_for(h1e, h2e, sorb) if USE_PLAN else None
+    plan = plan_for(h1e, h2e, sorb, bra.device) if USE_PLAN else None
     if plan is not None:
         dev = plan.device
         x = bra if bra.device == dev else bra.to(dev)
@@ -355,7 +371,7 @@ def eloc_rbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: RBMTable, sorb: int, 
         raise RuntimeError(f"RBM table was built for sorb = {table.sorb}, not {sorb}")
     if _fdtype(h1e, h2e) != N.PYNQS_F64:
         raise RuntimeError("the fused RBM local energy is float64 only")
-    plan = plan_for(h1e, h2e, sorb)
+    plan = plan_for(h1e, h2e, sorb, bra.device)
     if plan is None:
         raise RuntimeError("the fused RBM local energy needs an even sorb")
     dev, (x,), all_cpu = _stage(bra)

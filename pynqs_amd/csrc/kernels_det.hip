@@ -270,6 +270,7 @@ static int launch_comb_hij(const uint64_t *bra, int64_t nbatch, const SDParams &
 
 extern "C" int pynqs_comb_hij_fused(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
                                     const void *h1e, const void *h2e, int dtype, uint64_t *comb, void *hmat, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   SDParams p;
   if (!make_sd_params(sorb, nele, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
   if (nbatch < 0 || (dtype != PYNQS_F32 && dtype != PYNQS_F64)) return set_error(PYNQS_EINVAL, "bad nbatch/dtype");
@@ -287,6 +288,7 @@ extern "C" int pynqs_comb_hij_fused(const uint64_t *bra, int64_t nbatch, int sor
 
 extern "C" int pynqs_comb(const uint64_t *bra, int64_t nbatch, int sorb, int noA, int noB, uint64_t *comb, double *comb_pm1,
                           void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   SDParams p;
   if (!make_sd_params(sorb, noA + noB, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
   if (nbatch < 0) return set_error(PYNQS_EINVAL, "bad nbatch");
@@ -304,6 +306,7 @@ extern "C" int pynqs_comb(const uint64_t *bra, int64_t nbatch, int sorb, int noA
 
 extern "C" int pynqs_hij(const uint64_t *bra, int64_t n, const uint64_t *ket, int64_t m, int ket_is_3d, const void *h1e,
                          const void *h2e, int dtype, int sorb, int nele, void *hmat, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   if (sorb < 1 || sorb > kMaxSorb || n < 0 || m < 0 || nele < 0 || (dtype != PYNQS_F32 && dtype != PYNQS_F64))
     return set_error(PYNQS_EINVAL, "bad sorb/n/m/dtype");
   if (n == 0 || m == 0) return PYNQS_OK;
@@ -325,6 +328,7 @@ extern "C" int pynqs_hij(const uint64_t *bra, int64_t n, const uint64_t *ket, in
 }
 
 extern "C" int pynqs_onv_to_pm1(const uint64_t *bra, int64_t n, int sorb, int dtype, void *out, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   if (sorb < 1 || sorb > kMaxSorb || n < 0 || (dtype != PYNQS_F32 && dtype != PYNQS_F64))
     return set_error(PYNQS_EINVAL, "bad sorb/n/dtype");
   if (n == 0) return PYNQS_OK;
@@ -344,6 +348,7 @@ extern "C" int pynqs_onv_to_pm1(const uint64_t *bra, int64_t n, int sorb, int dt
 }
 
 extern "C" int pynqs_pm01_to_onv(const uint8_t *occ, int64_t n, int sorb, uint64_t *out, void *stream) {
+  pynqs::DeviceScope device_scope_(occ);
   if (sorb < 1 || sorb > kMaxSorb || n < 0) return set_error(PYNQS_EINVAL, "bad sorb/n");
   if (n == 0) return PYNQS_OK;
   if (!occ || !out) return set_error(PYNQS_EINVAL, "null pointer");
@@ -362,6 +367,7 @@ extern "C" int pynqs_pm01_to_onv(const uint8_t *occ, int64_t n, int sorb, uint64
 
 extern "C" int pynqs_wavefunction_lut(const uint64_t *keys, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb,
                                       int64_t *idx, uint8_t *mask, void *stream) {
+  pynqs::DeviceScope device_scope_(keys);
   if (sorb < 1 || sorb > kMaxSorb || n < 0 || nkeys < 0) return set_error(PYNQS_EINVAL, "bad sorb/n/nkeys");
   if (n == 0) return PYNQS_OK;
   if (!onv || !idx || !mask || (nkeys > 0 && !keys)) return set_error(PYNQS_EINVAL, "null pointer");
@@ -457,6 +463,7 @@ __global__ __launch_bounds__(kBlock) void spin_flip_rand_kernel(const uint64_t *
 
 extern "C" int pynqs_spin_flip_rand(const uint64_t *bra, int64_t n, int sorb, int noA, int noB, uint64_t seed, uint64_t offset,
                                     uint64_t *out, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   SDParams p;
   if (!make_sd_params(sorb, noA + noB, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
   if (n < 0) return set_error(PYNQS_EINVAL, "bad n");

@@ -772,12 +772,14 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
 extern "C" int pynqs_eloc_sample_space(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
                                        const void *plan, const uint64_t *keys, int64_t nkeys, const double *wf,
                                        int wf_is_complex, double *eloc, double *psi0, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   return eloc_sample_space_impl(bra, nbatch, sorb, nele, noA, noB, plan, keys, nkeys, false, wf, wf_is_complex, eloc, psi0, stream);
 }
 
 extern "C" int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
                                             const void *plan, const void *table, int64_t nkeys, const double *wf,
                                             int wf_is_complex, double *eloc, double *psi0, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   return eloc_sample_space_impl(bra, nbatch, sorb, nele, noA, noB, plan, (const uint64_t *)table, nkeys, true, wf, wf_is_complex,
                                 eloc, psi0, stream);
 }
@@ -789,6 +791,7 @@ extern "C" int64_t pynqs_hash_bytes(int64_t nkeys, int sorb) {
 }
 
 extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, void *table, void *stream) {
+  pynqs::DeviceScope device_scope_(keys);
   if (nkeys < 0 || sorb < 1 || sorb > kMaxSorb) return set_error(PYNQS_EINVAL, "bad nkeys/sorb");
   if (!table || (nkeys > 0 && !keys)) return set_error(PYNQS_EINVAL, "null pointer");
   const int len = (sorb - 1) / 64 + 1;
@@ -808,6 +811,7 @@ extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, v
 
 extern "C" int pynqs_hash_lookup(const void *table, int64_t nkeys, const uint64_t *onv, int64_t n, int sorb, int64_t *idx,
                                  uint8_t *mask, void *stream) {
+  pynqs::DeviceScope device_scope_(table);
   if (nkeys < 0 || n < 0 || sorb < 1 || sorb > kMaxSorb) return set_error(PYNQS_EINVAL, "bad nkeys/n/sorb");
   if (n == 0) return PYNQS_OK;
   if (!table || !onv || !idx || !mask) return set_error(PYNQS_EINVAL, "null pointer");
@@ -871,6 +875,7 @@ static int launch_reduce(const uint64_t *bra, int64_t nbatch, int sorb, int nele
 
 extern "C" int pynqs_reduce_count(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                                   int dtype, double eps, uint32_t *tile_counts, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   return launch_reduce<false>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, tile_counts, nullptr, nullptr, nullptr, nullptr,
                               stream);
 }
@@ -878,6 +883,7 @@ extern "C" int pynqs_reduce_count(const uint64_t *bra, int64_t nbatch, int sorb,
 extern "C" int pynqs_reduce_emit(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                                  int dtype, double eps, const int64_t *tile_offsets, int32_t *kept_col, uint64_t *kept_onv,
                                  void *kept_h, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   return launch_reduce<true>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, nullptr, tile_offsets, kept_col, kept_onv, kept_h,
                              stream);
 }

@@ -85,15 +85,20 @@ __global__ __launch_bounds__(kBlock) void gfmc_sample_kernel(const double *__res
     const double target = s_target;
     double run = s_before;
     const int64_t c0 = (int64_t)t * tile, c1 = min(c0 + (int64_t)tile, m);
-    int64_t found = -1;
+    int64_t found = -1, last_pos = -1;
     for (int64_t c = c0; c < c1 && found < 0; c += 64) {
       const double v = c + lane < c1 ? row[c + lane] : 0.0;
       const double incl = wave_incl_scan(v, lane) + run;
       const uint64_t hit = __ballot(c + lane < c1 && incl >= target);
       if (hit) found = c + __ffsll((long long)hit) - 1;
+      const uint64_t pos = __ballot(v > 0.0);
+      if (pos) last_pos = c + 63 - __clzll((long long)pos);
       run = __shfl(incl, 63);
     }
-    if (found < 0) found = c1 - 1;  // rounding at the very end of the row
+    // The tile was chosen from lane-strided partial sums, the scan above adds in column order: when the two roundings
+    // disagree at the tile's end the target is "just behind" the tile's last weight -> take the last column that HAS
+    // weight (never a zero-weight column, which the reference's searchsorted cannot return either)
+    if (found < 0) found = last_pos >= 0 ? last_pos : c1 - 1;
     if (lane == 0) index[walker] = found;
     if (lane < LEN) x_new[walker * LEN + lane] = comb[(walker * m + found) * LEN + lane];
   }
@@ -105,6 +110,7 @@ using namespace pynqs;
 
 extern "C" int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const double *rand_num, const uint64_t *comb, int sorb,
                                  int64_t *index, double *beta, uint64_t *x_new, void *stream) {
+  pynqs::DeviceScope device_scope_(green);
   if (n < 0 || ncomb < 1 || sorb < 1 || sorb > kMaxSorb) return set_error(PYNQS_EINVAL, "bad n / ncomb / sorb");
   if (n == 0) return PYNQS_OK;
   if (!green || !rand_num || !comb || !index || !beta || !x_new) return set_error(PYNQS_EINVAL, "null pointer");
@@ -184,6 +190,7 @@ __global__ void stats_finish_kernel(const double *__restrict__ m, double inv_wor
 }  // namespace pynqs
 
 extern "C" int pynqs_stats_finish(const double *moments, double inv_world, double counts, double *out5, void *stream) {
+  pynqs::DeviceScope device_scope_(moments);
   if (!moments || !out5 || !(counts > 0.0)) return set_error(PYNQS_EINVAL, "bad arguments");
   hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, moments, inv_world, counts, out5);
   return check_launch("stats_finish");
@@ -192,6 +199,7 @@ extern "C" int pynqs_stats_finish(const double *moments, double inv_world, doubl
 extern "C" int64_t pynqs_moments_workspace(void) { return 8 * 4 * (pynqs::kMomentBlocks + 1) + 8; }
 
 extern "C" int pynqs_weighted_moments(const double *x, int is_complex, const double *prob, int64_t n, void *workspace, void *stream) {
+  pynqs::DeviceScope device_scope_(x);
   if (n < 0) return set_error(PYNQS_EINVAL, "bad n");
   if (!workspace || (n > 0 && (!x || !prob))) return set_error(PYNQS_EINVAL, "null pointer");
   double *out = (double *)workspace;

@@ -192,6 +192,7 @@ extern "C" int64_t pynqs_plan_bytes(int sorb, int dtype) {
 }
 
 extern "C" int pynqs_plan_build(const void *h1e, const void *h2e, int sorb, int dtype, void *plan, void *stream) {
+  pynqs::DeviceScope device_scope_(h1e);
   PlanLayout pl;
   if (!make_plan_layout(sorb, &pl)) return set_error(PYNQS_EINVAL, "plan needs an even sorb in [2, 192]");
   if (dtype != PYNQS_F32 && dtype != PYNQS_F64) return set_error(PYNQS_EINVAL, "bad dtype");
@@ -230,6 +231,7 @@ static int launch_plan(const uint64_t *bra, int64_t nbatch, const SDParams &p, c
 
 extern "C" int pynqs_comb_hij_fused_plan(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
                                          const void *plan, int dtype, uint64_t *comb, void *hmat, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   SDParams p;
   PlanLayout pl;
   if (!make_sd_params(sorb, nele, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");

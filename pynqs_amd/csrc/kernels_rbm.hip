@@ -496,6 +496,7 @@ extern "C" int pynqs_eloc_rbm_supported(int sorb, int nele, int noA, int noB, in
 
 extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb,
                                      int nhidden, void *table, void *stream) {
+  pynqs::DeviceScope device_scope_(weights);
   RbmLayout rl;
   if (!make_rbm_layout(sorb, nhidden, &rl)) return set_error(PYNQS_EINVAL, "bad sorb / nhidden");
   if (!weights || !hidden_bias || !table) return set_error(PYNQS_EINVAL, "null pointer");
@@ -508,6 +509,7 @@ extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden
 
 extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                               const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   SDParams p;
   PlanLayout pl;
   RbmLayout rl;

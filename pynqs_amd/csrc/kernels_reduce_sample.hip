@@ -308,6 +308,7 @@ static int launch_rs(const uint64_t *bra, int64_t nbatch, int sorb, int nele, in
 
 extern "C" int pynqs_reduce_count_sums(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                                        int dtype, double eps, uint32_t *tile_counts, double *tile_sums, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   return launch_rs<false>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, tile_counts, tile_sums, nullptr, nullptr, nullptr, 0,
                           nullptr, nullptr, nullptr, stream);
 }
@@ -316,6 +317,7 @@ extern "C" int pynqs_reduce_sample(const uint64_t *bra, int64_t nbatch, int sorb
                                    int dtype, double eps, const int32_t *tile_draws, const int64_t *sample_offsets,
                                    const double *walker_scale, uint64_t seed, int32_t *s_col, uint64_t *s_onv, void *s_h,
                                    void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
   return launch_rs<true>(bra, nbatch, sorb, nele, noA, noB, plan, dtype, eps, nullptr, nullptr, tile_draws, sample_offsets,
                          walker_scale, seed, s_col, s_onv, s_h, stream);
 }

@@ -60,6 +60,7 @@ extern "C" int64_t pynqs_unique_workspace(int64_t n) {
 }
 
 extern "C" int pynqs_unique_first(const uint64_t *onv, int64_t n, int sorb, void *workspace, int32_t *first, void *stream) {
+  pynqs::DeviceScope device_scope_(onv);
   if (n < 0 || n > 0x3fffffffll || sorb < 1 || sorb > kMaxSorb) return set_error(PYNQS_EINVAL, "bad n/sorb");
   if (n == 0) return PYNQS_OK;
   if (!onv || !workspace || !first) return set_error(PYNQS_EINVAL, "null pointer");

@@ -26,6 +26,27 @@ inline int check_launch(const char *what) {
   return PYNQS_OK;
 }
 
+// Every launching entry point runs on the device that owns its first device pointer, whatever the caller's current
+// device is (a caller holding tensors on cuda:k without torch.cuda.set_device(k) would otherwise launch, memset and set
+// function attributes on the wrong GPU); the previous device is restored on return.  ~1 us per call.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(const void *p) {
+    hipPointerAttribute_t a;
+    if (p != nullptr && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeDevice) {
+      if (hipGetDevice(&prev) == hipSuccess && prev != a.device && hipSetDevice(a.device) == hipSuccess) switched = true;
+    } else {
+      (void)hipGetLastError();  // not a device pointer (the argument checks of the entry point report it)
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 // How a walker's row of ncomb columns is split over workgroups.  One workgroup per walker when there
 // are enough walkers to fill the chip (256 CUs x 8 resident workgroups); otherwise rows are cut into
 // chunks (multiples of 256 columns, never shorter than 2048 so that the per-workgroup table build

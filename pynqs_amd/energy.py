@@ -153,7 +153,7 @@ def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi
 
 
 def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT) -> Tuple[Tensor, Tensor]:
-    plan = CX.plan_for(h1e, h2e, sorb)
+    plan = CX.plan_for(h1e, h2e, sorb, x.device)
     dev = x.device
     cplx = WF_LUT.dtype.is_complex
     n = x.size(0)
@@ -176,7 +176,7 @@ def reduce_compact(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, no
     """Kept columns of the REDUCE method, compacted on the GPU: (row int64[m], col int32[m], onv uint8[m, 8*len],
     h[m], counts int64[n]) with |h| >= eps.  Rows ascend; inside a row the records come in the kernels' reproducible
     tile order (sort=True: ascending columns like the reference's boolean mask, at the price of a sort)."""
-    plan = CX.plan_for(h1e, h2e, sorb)
+    plan = CX.plan_for(h1e, h2e, sorb, x.device)
     dev = x.device
     n = x.size(0)
     L = (sorb - 1) // 64 + 1
@@ -213,7 +213,7 @@ def reduce_compact_sampled(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele:
     drawn column and w = (hits / eps_sample) * sign(h) * S_row, S_row = sum of the sub-eps |h| of the row.
     The draws over the tiles of a row come from torch.multinomial, the ones inside a tile from a counter-based
     generator in the kernel seeded with `seed` (default: drawn from torch's generator)."""
-    plan = CX.plan_for(h1e, h2e, sorb)
+    plan = CX.plan_for(h1e, h2e, sorb, x.device)
     dev = x.device
     n = x.size(0)
     L = (sorb - 1) // 64 + 1
@@ -256,7 +256,10 @@ def reduce_compact_sampled(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele:
     s_h = torch.empty(total, dtype=h1e.dtype, device=dev)
     scale = (S / eps_sample).contiguous()
     if seed is None:
-        seed = int(torch.randint(0, 2**62, (1,)).item())
+        # from torch's host generator (reproducible after torch.manual_seed), decorrelated between the ranks: after the usual
+        # manual_seed(seed) every rank's generator is in the same state, and the kernel's stream is keyed by (seed, local walker, tile, k)
+        seed = (int(torch.randint(0, 2**62, (1,)).item()) ^ ((get_rank() + 1) * 0x9E3779B97F4A7C15)) & (2**63 - 1) if get_rank() else \
+            int(torch.randint(0, 2**62, (1,)).item())
     N.check(lib.pynqs_reduce_sample(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, eps_eff, tile_draws.data_ptr(),
                                     sample_off.data_ptr(), scale.data_ptr(), seed, s_col.data_ptr(), s_onv.data_ptr(), s_h.data_ptr(), st),
             "pynqs_reduce_sample")
