@@ -419,10 +419,12 @@ class VmcStep(SampleSpaceFused):
          all-reduce + barrier pairs);
       3. gradient estimator (energy_grad.py:118-184): +-1 states (onv_to_tensor), loss = 2 Re sum p conj(ln psi)(E_loc - <E>) in
          micro-batches under DistributedDataParallel.no_sync(), the last backward runs DDP's bucketed all-reduce (RCCL over xGMI).
+         By default the forward + backward is replayed from a HIP graph and followed by ONE all-reduce of the flat gradient buffer
+         (GraphedGrad: same estimator, same mean-over-ranks reduction as DDP); --eager-grad runs grad() under DDP instead.
     The amplitude module is a complex128 RBM (alpha = 1, seeded; ansatz families are outside this package) standing in for the example's
     BDG-RNN: its forward/backward on 8192 x 40 inputs is ~60 small PyTorch kernels, reported separately as `grad_ms`."""
 
-    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev, micro_batch=50000):
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev, micro_batch=50000, graphed=True):
         super().__init__(tag, sorb, nele, noA, noB, h1, h2, walkers, keys, dev)
         import torch.distributed as dist
 
@@ -440,6 +442,9 @@ class VmcStep(SampleSpaceFused):
         self.nqs = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) if dist.is_initialized() else m
         self.micro_batch = micro_batch
         self.phase_events = []
+        # gradient estimator: forward + backward replayed from a HIP graph, then ONE RCCL all-reduce of the flat gradient buffer
+        # (pynqs_amd.grad.GraphedGrad; mean over the ranks = DistributedDataParallel's convention); --eager-grad: grad() under DDP
+        self.graphed = G.GraphedGrad(m, self.n, sorb, torch.complex128, dev) if graphed else None
 
     def step(self):
         st = torch.cuda.current_stream(self.dev)
@@ -459,7 +464,10 @@ class VmcStep(SampleSpaceFused):
         states = self.cx.onv_to_tensor(self.x, self.sorb)
         for p in self.module.parameters():
             p.grad = None
-        self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, torch.complex128, self.micro_batch)
+        if self.graphed is not None:
+            self.loss = self.graphed(states, self.prob, self.eloc, self.stats[0])
+        else:
+            self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, torch.complex128, self.micro_batch)
         ev[3].record(st)
         self.phase_events.append(ev)
         return ev[0], ev[1]
@@ -546,13 +554,13 @@ class DecoderAmplitude(torch.nn.Module):
         return torch.exp(0.5 * logp) * torch.cos(self.phase(hid[:, -1]).squeeze(-1))
 
 
-def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", keys: int = 65536) -> Workload:
+def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", keys: int = 65536, graphed: bool = True) -> Workload:
     if name == "fe2s2_vmc_step":
         d = load_fe2s2()
         ci = d["ci_space"]
         idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
         return VmcStep("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
-                       torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), torch.from_numpy(ci.copy()), dev)
+                       torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), torch.from_numpy(ci.copy()), dev, graphed=graphed)
     if name == "fe2s2_eloc_sample_space":
         d = load_fe2s2()
         ci = d["ci_space"]
@@ -607,6 +615,7 @@ def main():
     ap.add_argument("--keys", type=int, default=65536, help="sample-space size of the syn<sorb>_eloc_sample_space workloads")
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
     ap.add_argument("--no-comb", action="store_true", help="diagnostic: skip the comb output (Hmat only)")
+    ap.add_argument("--eager-grad", action="store_true", help="fe2s2_vmc_step: gradient estimator by grad() under DistributedDataParallel instead of the HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'extra'")
     args = ap.parse_args()
@@ -634,7 +643,7 @@ def main():
             s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
-    wl = make_workload(args.workload, args.walkers, rank, dev, args.path, args.keys)
+    wl = make_workload(args.workload, args.walkers, rank, dev, args.path, args.keys, not args.eager_grad)
     if args.no_comb:
         wl.comb_ptr = None
 
@@ -735,7 +744,9 @@ def main():
             "config": {"workload": wl.name, "sorb": wl.sorb, "nele": wl.nele, "ncomb": wl.ncomb,
                        "walkers_per_gpu": wl.n, "integral_layout": wl.path, "plan_build_ms": wl.plan_build_ms,
                        "parallelism": f"walker-sharded x{world} (one process per GPU)" + (
-                           "; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p); DDP bucketed RCCL all-reduce of the gradient estimator"
+                           ("; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p); gradient estimator: " +
+                            ("HIP-graph replay + one RCCL all-reduce of the flat gradient buffer (mean over ranks, as DDP)" if wl.graphed is not None
+                             else "DDP bucketed RCCL all-reduce in the last micro-batch's backward"))
                            if isinstance(wl, VmcStep) else "; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p)" if hasattr(wl, "stats")
                            else "; no data-path collective")},
             "roofline": roofline(wl, kern_ms),
