@@ -137,6 +137,19 @@ int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch, int sorb, 
                                  const void *plan, const void *table, int64_t nkeys, const double *wf,
                                  int wf_is_complex, double *eloc, double *psi0, void *stream);
 
+/* ---- spin-flip-projected SAMPLE_SPACE: vmc/energy/flip.py:322-418 (_only_sample_space_flip).
+ *   E_loc(x) = [ sum_k H_k psi(x'_k) + eta * sum_k H_k eta_m(x'_k) psi(flip(x'_k)) ] / (extra_norm^2 psi(x))
+ * with flip = alpha <-> beta exchange and eta_m = (-1)^(doubly occupied orbitals of x') (utils/public_function.py:966-1007).
+ * The first sum / psi(x) is pynqs_eloc_sample_space[_hash]; these entries return the second one:
+ *   out[x] = sum_k H_k eta_m(x'_k) psi(flip(x'_k)) / psi0[x],   psi0 = psi(x) from that call (an INPUT here),
+ * one more pass of the same kernel (the filters are asked with the partner orbitals' Zobrist values).              */
+int pynqs_eloc_sample_space_flip(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                 const void *plan, const uint64_t *keys, int64_t nkeys, const double *wf,
+                                 int wf_is_complex, const double *psi0, double *out, void *stream);
+int pynqs_eloc_sample_space_hash_flip(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                      const void *plan, const void *table, int64_t nkeys, const double *wf,
+                                      int wf_is_complex, const double *psi0, double *out, void *stream);
+
 /* ---- duplicates among determinants, without a sort (`Func`, vmc/energy/flip.py:44-50: torch.unique(dim=0,
  * return_inverse=True) on the x' that reach the ansatz).  first[i] = smallest j with onv[j] == onv[i] (int32[n]);
  * the rows with first[i] == i are the distinct determinants in order of first appearance.  Deterministic.

@@ -23,6 +23,20 @@ namespace pynqs {
 // sum; the workgroup that owns column 0 also stores psi(x).  One workgroup per (walker, chunk); with more than
 // one chunk per walker partial sums meet through float atomics (the last bits then depend on arrival order).
 // HASH: `keys` is a hash table built by pynqs_hash_build (nkeys = its capacity) instead of the sorted keys.
+// Spin-flip partner of a determinant (vmc/energy/flip.py:322-418, utils/public_function.py:966-1007): alpha <-> beta occupations
+// exchanged (orbitals 2k <-> 2k + 1 live in the same word) and the sign (-1)^(doubly occupied spatial orbitals) of x' itself.
+template <int LEN>
+__device__ __forceinline__ bool spin_flip_ket(uint64_t (&ket)[LEN]) {
+  uint32_t pairs = 0;
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) {
+    const uint64_t w = ket[i];
+    pairs += (uint32_t)__popcll(w & (w >> 1) & 0x5555555555555555ull);
+    ket[i] = ((w >> 1) & 0x5555555555555555ull) | ((w & 0x5555555555555555ull) << 1);
+  }
+  return pairs & 1u;  // true: eta_m = -1
+}
+
 template <int LEN, bool CPLX, bool HASH>
 struct LookupSink {
   const uint64_t *__restrict__ keys;
@@ -30,17 +44,27 @@ struct LookupSink {
   const double *__restrict__ wf;
   double *__restrict__ psi0;  // this walker's psi(x) slot
   double re, im;
+  bool flip;  // wave-uniform: look flip(x') up and weight with eta_m(x') (the projected form's second sum); psi0 is not written
   // the two look-ups of a sink call: both first probes in flight together
   __device__ __forceinline__ void lookup2(uint32_t c0, double h0, const uint64_t (&k0)[LEN], uint32_t c1, double h1, const uint64_t (&k1)[LEN]) {
+    if (flip) {
+      add(c0, h0, k0);
+      add(c1, h1, k1);
+      return;
+    }
     const HashProbe<LEN> p0 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, hash_of<LEN>(k0));
     const HashProbe<LEN> p1 = hash_probe_first_h<LEN>(keys, (uint64_t)nkeys, hash_of<LEN>(k1));
     accumulate(c0, h0, hash_resolve<LEN>(p0, keys, (uint64_t)nkeys, k0));
     accumulate(c1, h1, hash_resolve<LEN>(p1, keys, (uint64_t)nkeys, k1));
   }
   __device__ __forceinline__ void add(uint32_t col, double h, const uint64_t (&ket)[LEN]) {
+    uint64_t q[LEN];
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) q[i] = ket[i];
+    if (flip && spin_flip_ket<LEN>(q)) h = -h;
     int64_t pos;
-    if constexpr (HASH) pos = hash_find<LEN>(keys, (uint64_t)nkeys, ket);
-    else pos = lut_find<LEN>(keys, nkeys, ket);
+    if constexpr (HASH) pos = hash_find<LEN>(keys, (uint64_t)nkeys, q);
+    else pos = lut_find<LEN>(keys, nkeys, q);
     accumulate(col, h, pos);
   }
   __device__ __forceinline__ void accumulate(uint32_t col, double h, int64_t pos) {
@@ -54,7 +78,7 @@ struct LookupSink {
     }
     re += h * vr;
     if constexpr (CPLX) im += h * vi;
-    if (col == 0) {
+    if (col == 0 && !flip) {
       psi0[0] = vr;
       if constexpr (CPLX) psi0[1] = vi;
     }
@@ -110,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
                                                                    const double *__restrict__ plan,
                                                                    const uint64_t *__restrict__ keys, int64_t nkeys,
                                                                    const double *__restrict__ wf, double *__restrict__ acc,
-                                                                   double *__restrict__ psi0) {
+                                                                   double *__restrict__ psi0, bool flip) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double red[2][kBlock / 64];
   __shared__ uint32_t next_tile;
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier
-  LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0};
+  LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0, flip};
   visit_tiles<LEN, double, LookupSink<LEN, CPLX, HASH>, false>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
   store_walker_sum<CPLX, kBlock / 64>(sink.re, sink.im, red, nchunks, walker, acc);
 }
@@ -183,6 +207,7 @@ struct Candidates {
   uint32_t zx, zx2;      // Zobrist hashes of the walker
   uint32_t n1[2], n2[2]; // entries of the queues, [0] doubles, [1] singles (wave-uniform)
   double re, im;
+  bool flip;             // wave-uniform: the projected form's second sum (the Z tables then hold Z[orbital ^ 1], see the kernel)
 
   __device__ __forceinline__ uint32_t Z(uint32_t orbital_times_4) const { return *reinterpret_cast<lds_u32 *>(zorb + orbital_times_4); }
   // Zobrist hash of the orbitals of a table entry (orbital | orbital << 8 | ...)
@@ -343,6 +368,7 @@ struct Candidates {
         if constexpr (TWO) h = double_value(r, ket);
         else h = double_from_rank(r, ket);
       }
+      if (flip && spin_flip_ket<LEN>(ket)) h = -h;
       pos = hash_find<LEN>(table, cap, ket);
     }
     count = __builtin_amdgcn_readfirstlane(count - n);
@@ -380,7 +406,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
                                                                             const double *__restrict__ plan,
                                                                             const uint64_t *__restrict__ table, int64_t cap,
                                                                             const double *__restrict__ wf, double *__restrict__ acc,
-                                                                            double *__restrict__ psi0, uint32_t fbits, uint32_t f2bits) {
+                                                                            double *__restrict__ psi0, bool flip, uint32_t fbits, uint32_t f2bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double red[2][BLOCK / 64];
   __shared__ uint32_t next_tile;
@@ -399,9 +425,12 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
     uint32_t *lf = reinterpret_cast<uint32_t *>(smem + filt_off);
     for (uint32_t i = tid; i < fbits / 32; i += BLOCK) lf[i] = gf[i];
     uint32_t *lz = reinterpret_cast<uint32_t *>(smem + z_off);
+    // flip: the table is asked for flip(x'), whose Zobrist hash is the XOR of Z[o ^ 1] over the orbitals o of x' -- the same
+    // scan with the partner orbital's value in every Z slot
+    const uint32_t fx = flip ? 1u : 0u;
     if (tid < p.sorb) {
-      lz[tid] = fbits ? zobrist32((uint32_t)tid) : zobrist32b((uint32_t)tid);
-      if constexpr (TWO) lz[z_bytes(p.sorb) / 4 + tid] = zobrist32b((uint32_t)tid);
+      lz[tid] = fbits ? zobrist32((uint32_t)tid ^ fx) : zobrist32b((uint32_t)tid ^ fx);
+      if constexpr (TWO) lz[z_bytes(p.sorb) / 4 + tid] = zobrist32b((uint32_t)tid ^ fx);
     }
   }
   // (its first barrier publishes Z[] to the table loops; it ends with a barrier: tables and filter are visible)
@@ -410,14 +439,15 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
 #pragma unroll
   for (int w = 0; w < LEN; ++w)
     if ((wk.w[w] >> lane) & 1ull) {
-      zx2 ^= zobrist32b(64u * w + (uint32_t)lane);
-      zx ^= fbits ? zobrist32(64u * w + (uint32_t)lane) : zobrist32b(64u * w + (uint32_t)lane);
+      const uint32_t o = (64u * w + (uint32_t)lane) ^ (flip ? 1u : 0u);
+      zx2 ^= zobrist32b(o);
+      zx ^= fbits ? zobrist32(o) : zobrist32b(o);
     }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { zx ^= __shfl_xor(zx, o); zx2 ^= __shfl_xor(zx2, o); }
   const uint32_t dyn = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
   Candidates<LEN, CPLX, TWO> cand{p, pl, L, wk, nocc, plan, table, (uint64_t)cap, wf, gf + fbits / 32, f2bits, dyn + filt_off, fbits, dyn + z_off,
-                             dyn + (uint32_t)lds_tab_bytes(p), dyn + q_off + (uint32_t)(tid >> 6) * queue_bytes(TWO), zx, zx2, {0u, 0u}, {0u, 0u}, 0.0, 0.0};
+                             dyn + (uint32_t)lds_tab_bytes(p), dyn + q_off + (uint32_t)(tid >> 6) * queue_bytes(TWO), zx, zx2, {0u, 0u}, {0u, 0u}, 0.0, 0.0, flip};
 
   // tiles: 0 = column 0; 1 = this workgroup's share of the singles (blocks of 64 dealt round-robin over the walker's
   // workgroups, as in plan_tiles.h) -- one wave takes them all, so that its singles queue fills; then 256 ranks of one
@@ -440,11 +470,19 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
         const double v = fast_diag<double>(p, pl, L, plan);
         if (lane == 0) {
           double vr, vi;
-          cand.value(hash_find<LEN>(table, (uint64_t)cap, wk.w), vr, vi);
-          double *__restrict__ out = psi0 + (CPLX ? 2 : 1) * walker;
-          out[0] = vr;
-          cand.re += v * vr;
-          if constexpr (CPLX) { out[1] = vi; cand.im += v * vi; }
+          uint64_t q[LEN];
+#pragma unroll
+          for (int i = 0; i < LEN; ++i) q[i] = wk.w[i];
+          double hv = v;
+          if (flip && spin_flip_ket<LEN>(q)) hv = -hv;
+          cand.value(hash_find<LEN>(table, (uint64_t)cap, q), vr, vi);
+          cand.re += hv * vr;
+          if constexpr (CPLX) cand.im += hv * vi;
+          if (!flip) {
+            double *__restrict__ out = psi0 + (CPLX ? 2 : 1) * walker;
+            out[0] = vr;
+            if constexpr (CPLX) out[1] = vi;
+          }
         }
       }
       continue;
@@ -685,7 +723,7 @@ static int eloc_common_checks(int sorb, int nele, int noA, int noB, int64_t nbat
 
 static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                                   const uint64_t *keys, int64_t nkeys, bool hash, const double *wf, int wf_is_complex,
-                                  double *eloc, double *psi0, void *stream) {
+                                  double *eloc, double *psi0, void *stream, bool flip = false) {
   SDParams p;
   PlanLayout pl;
   int rc = eloc_common_checks(sorb, nele, noA, noB, nbatch, &p, &pl);
@@ -727,7 +765,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   const double *pd = (const double *)plan;
   const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
-#define PYNQS_SS_ARGS dim3((uint32_t)grid), dim3(block), lds, st, bra, p, pl, nchunks, chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0
+#define PYNQS_SS_ARGS dim3((uint32_t)grid), dim3(block), lds, st, bra, p, pl, nchunks, chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0, flip
 #define PYNQS_SS_LAUNCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                            \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -782,6 +820,24 @@ extern "C" int pynqs_eloc_sample_space_hash(const uint64_t *bra, int64_t nbatch,
   pynqs::DeviceScope device_scope_(bra);
   return eloc_sample_space_impl(bra, nbatch, sorb, nele, noA, noB, plan, (const uint64_t *)table, nkeys, true, wf, wf_is_complex,
                                 eloc, psi0, stream);
+}
+
+// The second sum of the spin-projected SAMPLE_SPACE local energy (vmc/energy/flip.py:322-418):
+//   out[x] = sum_x' <x|H|x'> eta_m(x') psi(flip(x')) / psi0[x],   psi0 = psi(x) as returned by the calls above (an INPUT here)
+// so that E_loc = (eloc + eta * out) / extra_norm^2.  Same kernels, same filters: the Zobrist tables hold the partner orbitals' values.
+extern "C" int pynqs_eloc_sample_space_flip(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                            const void *plan, const uint64_t *keys, int64_t nkeys, const double *wf,
+                                            int wf_is_complex, const double *psi0, double *out, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
+  return eloc_sample_space_impl(bra, nbatch, sorb, nele, noA, noB, plan, keys, nkeys, false, wf, wf_is_complex, out, (double *)psi0, stream, true);
+}
+
+extern "C" int pynqs_eloc_sample_space_hash_flip(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB,
+                                                 const void *plan, const void *table, int64_t nkeys, const double *wf,
+                                                 int wf_is_complex, const double *psi0, double *out, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
+  return eloc_sample_space_impl(bra, nbatch, sorb, nele, noA, noB, plan, (const uint64_t *)table, nkeys, true, wf, wf_is_complex, out,
+                                (double *)psi0, stream, true);
 }
 
 extern "C" int64_t pynqs_hash_bytes(int64_t nkeys, int sorb) {

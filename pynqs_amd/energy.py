@@ -147,29 +147,39 @@ def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
 
 
 def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa=0, nob=0) -> bool:
-    return (FUSED and WF_LUT is not None and WF_LUT.sort and not (use_spin_raising or use_multi_psi or use_spin_flip)
+    return (FUSED and WF_LUT is not None and WF_LUT.sort and not use_spin_raising
             and sorb % 2 == 0 and h1e.dtype == torch.float64 and WF_LUT.dtype in (torch.float64, torch.complex128)
             and x.is_cuda and WF_LUT.bra_key.is_cuda)
 
 
-def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT) -> Tuple[Tensor, Tensor]:
+def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[Tensor] = None, flip: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """(sum_k H_k t(x'_k) / t(x), t(x), second sum) with t = the table values `wf` (default: WF_LUT's psi), all in ONE kernel pass
+    per sum.  flip: also  sum_k H_k eta_m(x'_k) t(flip(x'_k)) / t(x)  (the projected form's partner term, one more pass)."""
     plan = CX.plan_for(h1e, h2e, sorb, x.device)
     dev = x.device
-    cplx = WF_LUT.dtype.is_complex
+    wf = (WF_LUT.wf_value if wf is None else wf).contiguous()
+    cplx = wf.dtype.is_complex
     n = x.size(0)
-    wf = WF_LUT.wf_value.contiguous()
-    eloc = torch.empty(n, dtype=WF_LUT.dtype, device=dev)
-    psi0 = torch.empty(n, dtype=WF_LUT.dtype, device=dev)
+    eloc = torch.empty(n, dtype=wf.dtype, device=dev)
+    psi0 = torch.empty(n, dtype=wf.dtype, device=dev)
+    part = torch.empty(n, dtype=wf.dtype, device=dev) if flip else None
     st = torch.cuda.current_stream(dev).cuda_stream
     ht = getattr(WF_LUT, "hashtable", None)
+    lib = N.lib()
     if ht is not None:  # 1-2 probes per x' instead of log2(nkeys) dependent ones
-        rc = N.lib().pynqs_eloc_sample_space_hash(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
-                                                  ht.nkeys, wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+        rc = lib.pynqs_eloc_sample_space_hash(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
+                                              ht.nkeys, wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+        if rc == 0 and flip:
+            rc = lib.pynqs_eloc_sample_space_hash_flip(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
+                                                       ht.nkeys, wf.data_ptr(), int(cplx), psi0.data_ptr(), part.data_ptr(), st)
     else:
-        rc = N.lib().pynqs_eloc_sample_space(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
-                                             WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+        rc = lib.pynqs_eloc_sample_space(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
+                                         WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+        if rc == 0 and flip:
+            rc = lib.pynqs_eloc_sample_space_flip(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
+                                                  WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), psi0.data_ptr(), part.data_ptr(), st)
     N.check(rc, "pynqs_eloc_sample_space")
-    return eloc, psi0
+    return eloc, psi0, part
 
 
 def reduce_compact(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, sort: bool = False):
@@ -299,7 +309,29 @@ def local_energy(
 
         # ---- fast path: SAMPLE_SPACE in one kernel ----------------------------------------------------
         if use_sample_space and _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa, nob):
-            eloc, psi0 = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT)
+            if not (use_multi_psi or use_spin_flip):
+                eloc, psi0, _ = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT)
+            else:
+                # projected / multi-psi forms (flip.py:322-418, eloc.py:381-392) on the same kernel:
+                #   E_loc = conj(f(x)) [ sum_k H_k (f psi)(x'_k) + eta sum_k H_k eta_m(x'_k) (f psi)(flip x'_k) ] / (N^2 psi(x))
+                # (f psi) is a table over the sample space: f is evaluated once on the keys instead of on every hit
+                wf = WF_LUT.wf_value
+                if use_multi_psi:
+                    f_keys = Func(partial(ansatz_batch, func=ansatz.module.extra), WF_LUT.bra_key, None, True).to(wf.dtype)  # (the reference
+                    wf = wf * f_keys                                                       # stores f in the table's dtype, flip.py:392)
+                e1, t0x, part = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf, use_spin_flip)
+                if use_spin_flip:
+                    e1 = e1 + SpinProjection.eta * part
+                if use_multi_psi:
+                    # t(x) = f(x) psi(x): back to sum / psi(x) and the reference's factor conj(f(x)); psi(x), f(x) from the table
+                    pos, found = WF_LUT.find(x)
+                    pos = pos.clamp_min(0)
+                    psi0 = torch.where(found, WF_LUT.wf_value[pos], torch.zeros((), dtype=WF_LUT.dtype, device=x.device))
+                    f_x = torch.where(found, f_keys[pos], torch.zeros((), dtype=f_keys.dtype, device=x.device))
+                    e1 = e1 * f_x * f_x.conj()
+                else:
+                    psi0 = t0x
+                eloc = e1 / extra_norm**2
             t1 = time.time_ns()
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 

@@ -141,13 +141,17 @@ class WavefunctionLUT:
         self._bra_key, self._wf_value = self._bra_key.to(device=device), self._wf_value.to(device=device)
         self._rebuild_hash()
 
-    def lookup(self, onv: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
-        """(indices of onv found, indices not found, psi of the found ones) -- public_function.py:817-838."""
+    def find(self, onv: Tensor) -> Tuple[Tensor, Tensor]:
+        """(position of every onv in the sorted keys or -1, found mask)."""
         if self.hashtable is not None and onv.is_cuda:
             pos, found = CX.hash_lookup(self.hashtable, onv)
         else:
             pos, found = wavefunction_lut(self._bra_key, onv, self.sorb)
-        pos, found = pos.to(onv.device), found.to(onv.device)
+        return pos.to(onv.device), found.to(onv.device)
+
+    def lookup(self, onv: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """(indices of onv found, indices not found, psi of the found ones) -- public_function.py:817-838."""
+        pos, found = self.find(onv)
         every = torch.arange(onv.size(0), device=onv.device, dtype=torch.int64)
         return every[found], every[~found], self._wf_value[pos[found]]
 
@@ -185,51 +189,54 @@ def ansatz_batch(func: Callable[[Tensor], Tensor], x: Tensor, batch: int, sorb: 
     return out
 
 
-# ---- spin-flip symmetry helpers (utils/public_function.py:966-1018) ----------------------------------
-def swap_odd_even_bits_8bit(n: Tensor) -> Tensor:
-    return ((n & 0xAA) >> 1) | ((n & 0x55) << 1)
+# ---- spin-flip symmetry helpers (same results as utils/public_function.py:966-1036) --------------------------------
+_DOUBLY = None  # [256] number of doubly occupied spatial orbitals among the four a byte of a packed determinant holds
 
 
-def popcount_8bit(x: Tensor) -> Tensor:
-    t = x - ((x >> 1) & 0x55)
-    t = (t & 0x33) + ((t >> 2) & 0x33)
-    return (t + (t >> 4)) & 0x0F
-
-
-def spin_flip_sign(x: Tensor, sorb: int) -> Tensor:
-    """+1 / -1 for an even / odd number of doubly occupied spatial orbitals."""
-    if x.dtype == torch.uint8:
-        both = x & swap_odd_even_bits_8bit(x)  # two bits per doubly occupied orbital
-        return 2 * ((popcount_8bit(both).sum(dim=-1) & 0b11) == 0).to(torch.int64) - 1
-    assert x.size(1) == sorb
-    idxs = x[:, ::2] + x[:, 1::2] * 2
-    counts = (idxs == 3).sum(dim=1)
-    return 1 - counts % 2 * 2
+def _doubly_table(device) -> Tensor:
+    global _DOUBLY
+    if _DOUBLY is None:
+        _DOUBLY = torch.tensor([bin(b & (b >> 1) & 0x55).count("1") for b in range(256)], dtype=torch.int64)
+    return _DOUBLY.to(device)
 
 
 def spin_flip_onv(x: Tensor, sorb: int) -> Tensor:
-    """swap alpha <-> beta occupations."""
+    """The determinant with alpha and beta occupations exchanged (orbital 2k <-> 2k + 1): packed uint8 determinants or
+    [n, sorb] occupation rows."""
     if x.dtype == torch.uint8:
-        return swap_odd_even_bits_8bit(x)
+        return ((x >> 1) & 0x55) | ((x & 0x55) << 1)
     assert x.size(1) == sorb
-    x1 = torch.empty_like(x)
-    x1[:, ::2], x1[:, 1::2] = x[:, 1::2], x[:, ::2]
-    return x1
+    return x.reshape(x.size(0), sorb // 2, 2).flip(-1).reshape(x.size(0), sorb)
+
+
+def spin_flip_sign(x: Tensor, sorb: int) -> Tensor:
+    """(-1)^(number of doubly occupied spatial orbitals): the sign the alpha <-> beta exchange gives a determinant.
+    Packed uint8 determinants, or [n, sorb] rows with 1 = occupied, 0 = empty."""
+    if x.dtype == torch.uint8:
+        pairs = _doubly_table(x.device)[x.long()].sum(dim=-1)
+    else:
+        assert x.size(1) == sorb
+        pairs = ((x[:, 0::2] == 1) & (x[:, 1::2] == 1)).sum(dim=1)
+    return 1 - 2 * (pairs & 1)
 
 
 class _SpinProjection:
-    """eta = (-1)^(N//2 - S)  (utils/public_function.py:1020-1040)."""
+    """eta = (-1)^(N // 2 - S) of the spin-projected local energies (set once per run with init(N, S))."""
 
-    _eta: Optional[int] = None
+    __slots__ = ("_eta",)
+
+    def __init__(self) -> None:
+        self._eta: Optional[int] = None
 
     def init(self, N: int, S: int) -> None:
-        assert isinstance(N, int) and isinstance(S, int)
-        self._eta = (-1) ** (N // 2 - S)
+        if not (isinstance(N, int) and isinstance(S, int)):
+            raise AssertionError("N and S must be integers")
+        self._eta = -1 if (N // 2 - S) % 2 else 1
 
     @property
     def eta(self) -> int:
         if self._eta is None:
-            raise NotImplementedError
+            raise NotImplementedError("SpinProjection.init(N, S) has not been called")
         return self._eta
 
 

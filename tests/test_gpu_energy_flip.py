@@ -114,3 +114,62 @@ def test_complex128_module_matches_reference_python(env, fused):
     # no use_unique: same numbers (Func without the unique pass)
     e2, _ = _le(env, cr, torch.complex128, fused, use_unique=False)
     np.testing.assert_allclose(e2, c["eloc_simple"], rtol=0, atol=TOL)
+
+
+def test_projected_sample_space_runs_fused(env, monkeypatch):
+    """The SAMPLE_SPACE forms with use_spin_flip / use_multi_psi take the one-kernel path (pynqs_eloc_sample_space[_hash][_flip]):
+    nothing of size batch x ncomb may be materialised."""
+    energy = env["energy"]
+
+    def boom(*a, **k):
+        raise AssertionError("get_comb_hij_fused called: the projected SAMPLE_SPACE form fell back to the materialising path")
+
+    monkeypatch.setattr(energy, "get_comb_hij_fused", boom)
+    for name in ("ss_flip", "ss_flip_c", "ss_multi", "ss_flip_multi", "ss_flip_multi_c"):
+        key, dt, kw = CASES[name]
+        _check(_le(env, env[key], dt, True, **kw(env)), env["d"], name)
+
+
+@pytest.mark.parametrize("sorb,no,nkeys,use_hash", [(40, 5, 300, True), (72, 6, 200, True), (136, 4, 3000, True), (136, 4, 5000, True),
+                                                    (72, 6, 300, False), (40, 5, 300_000, True)])
+def test_spin_flip_kernel_all_filter_levels(sorb, no, nkeys, use_hash):
+    """The partner sum of the projected form (pynqs_eloc_sample_space[_hash]_flip) with one-level / two-level / no filter, sorted-key
+    search, 1-3 ONV words, against the materialising tensor path (the reference's algebra, pinned at sorb 40 by the fixtures above)
+    on sample spaces closed under the alpha <-> beta exchange."""
+    from pynqs_amd import energy, public_function as pf
+    from test_gpu_energy import _excite, _random_walkers
+
+    rng = np.random.default_rng(7000 * sorb + nkeys)
+    dev = torch.device("cuda")
+    n = 16
+    x = _random_walkers(rng, n, sorb, no)
+    pool = np.concatenate([x, _excite(rng, x, sorb, nkeys // 3, True), _excite(rng, x, sorb, nkeys // 3, False), _random_walkers(rng, nkeys, sorb, no)])
+    L = x.shape[1]
+    tb = lambda w: torch.from_numpy(np.ascontiguousarray(w).view(np.uint8).reshape(-1, 8 * L)).to(dev)  # noqa: E731
+    keys = torch.unique(torch.cat([tb(pool), pf.spin_flip_onv(tb(pool), sorb)]), dim=0)
+    wf = torch.from_numpy(rng.standard_normal(keys.size(0)) + 1j * rng.standard_normal(keys.size(0))).to(dev)
+    h1 = rng.standard_normal((sorb, sorb)); h1 = torch.from_numpy((h1 + h1.T).reshape(-1)).to(dev)
+    pair = sorb * (sorb - 1) // 2
+    h2 = torch.from_numpy(rng.standard_normal(pair * (pair + 1) // 2)).to(dev)
+    old_flag = pf.USE_HASH
+    pf.USE_HASH = use_hash
+    try:
+        lut = pf.WavefunctionLUT(keys, wf, sorb, device=dev)
+    finally:
+        pf.USE_HASH = old_flag
+    pf.SpinProjection.init(2 * no, 0)
+    en = torch.tensor(1.7, dtype=torch.float64, device=dev)
+    out = {}
+    for fused in (True, False):
+        old = energy.FUSED
+        energy.FUSED = fused
+        try:
+            e, _, p0, _ = energy.local_energy(tb(x), h1, h2, None, None, sorb, 2 * no, no, no, WF_LUT=lut, use_sample_space=True,
+                                              dtype=torch.complex128, use_spin_flip=True, extra_norm=en)
+        finally:
+            energy.FUSED = old
+        out[fused] = (e.cpu().numpy(), p0.cpu().numpy())
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    scale = max(1.0, float(np.abs(out[False][0]).max()))
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=TOL * scale)
+    pf.SpinProjection.init(30, 0)
