@@ -95,7 +95,8 @@ class GraphedGrad:
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream(dev).wait_stream(side)
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads (RCCL's watchdog) may touch the HIP runtime while this one captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._body()
 
     def _body(self) -> None:

@@ -150,9 +150,9 @@ def test_total_energy_chunks_and_statistics(env):
             assert torch.equal(u, u2)
 
 
-def test_spin_flip_and_multi_psi_paths_agree_with_plain_tensor_algebra(env):
-    """No reference capture exists for the projected forms; check them against a direct evaluation of
-    flip.py:120-139 built from the materialised comb/Hmat."""
+def test_spin_flip_helpers_and_eps0_consistency(env):
+    """Helper forms (packed / occupation rows) agree, and REDUCE with eps = 0 equals SIMPLE for the projected form.  (Parity of the
+    projected and multi-psi local energies themselves against the reference's Python: test_gpu_energy_flip.py.)"""
     from pynqs_amd import C_extension as cx
 
     pf, energy = env["pf"], env["energy"]

@@ -164,7 +164,7 @@ def test_spin_flip_kernel_all_filter_levels(sorb, no, nkeys, use_hash):
         old = energy.FUSED
         energy.FUSED = fused
         try:
-            e, _, p0, _ = energy.local_energy(tb(x), h1, h2, None, None, sorb, 2 * no, no, no, WF_LUT=lut, use_sample_space=True,
+            e, _, p0, _ = energy.local_energy(tb(x), h1, h2, None, lambda x_, func: None, sorb, 2 * no, no, no, WF_LUT=lut, use_sample_space=True,
                                               dtype=torch.complex128, use_spin_flip=True, extra_norm=en)
         finally:
             energy.FUSED = old
