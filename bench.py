@@ -439,7 +439,8 @@ class VmcStep(SampleSpaceFused):
                        0.02 * (torch.rand(H, 2, generator=g, dtype=torch.float64) - 0.5),
                        0.05 * (torch.rand(sorb, 2, generator=g, dtype=torch.float64) - 0.5)).to(dev)
         self.module = m
-        self.nqs = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) if dist.is_initialized() else m
+        # (the DDP wrapper only for the eager estimator: its reducer hooks must not sit on a module whose backward is graph-captured)
+        self.nqs = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) if dist.is_initialized() and not graphed else m
         self.micro_batch = micro_batch
         self.phase_events = []
         # gradient estimator: forward + backward replayed from a HIP graph, then ONE RCCL all-reduce of the flat gradient buffer
@@ -619,6 +620,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'extra'")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL 2.26 prints a five-line version banner on its
+    # first communicator): everything but the final line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -860,7 +867,8 @@ def main():
             extra["fe2s2_eloc_rbm_torch"] = {"error": repr(e)}
         out["extra"] = extra
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
