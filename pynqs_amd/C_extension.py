@@ -147,6 +147,29 @@ def plan_for(h1e: Tensor, h2e: Tensor, sorb: int, device: "torch.device | None" 
     return pl
 
 
+_F64_COPIES: "list[tuple]" = []  # (weakref(h1e), weakref(h2e), versions, h1e as float64, h2e as float64), most recent first
+
+
+def integrals_f64(h1e: Tensor, h2e: Tensor) -> Tuple[Tensor, Tensor]:
+    """float64 copies of float32 integrals (cached per tensor pair like the plans), for the fused local-energy kernels, which
+    exist in float64 only: every float32 value is a float64 value, so the kernels see exactly the caller's numbers and only the
+    accumulation is done in (more than) the precision the reference's float32 path has (cpu_tensor.cpp:249,298 dispatch)."""
+    import weakref
+
+    if h1e.dtype == torch.float64:
+        return h1e, h2e
+    ver = (h1e._version, h2e._version, h1e.data_ptr(), h2e.data_ptr())
+    for i, (r1, r2, v, a, b) in enumerate(_F64_COPIES):
+        if r1() is h1e and r2() is h2e and v == ver:
+            if i:
+                _F64_COPIES.insert(0, _F64_COPIES.pop(i))
+            return a, b
+    a, b = h1e.double(), h2e.double()
+    _F64_COPIES.insert(0, (weakref.ref(h1e), weakref.ref(h2e), ver, a, b))
+    del _F64_COPIES[_MAX_PLANS:]
+    return a, b
+
+
 def get_Num_SinglesDoubles(sorb: int, noA: int, noB: int) -> int:
     """utils/public_function.py:132 / cpp_src/cpu/excitation.cpp:8-16."""
     return int(N.lib().pynqs_num_sd(sorb, noA, noB))

@@ -136,9 +136,10 @@ def _real_rbm_params(ansatz):
     if not (isinstance(m, RealRBM) or getattr(m, "rbm_type", None) == "real"):
         return None
     W, hb, vb = getattr(m, "weights", None), getattr(m, "hidden_bias", None), getattr(m, "visible_bias", None)
-    if W is None or hb is None or vb is None or W.dtype != torch.float64 or not W.is_cuda or W.dim() != 2:
+    if W is None or hb is None or vb is None or W.dtype not in (torch.float64, torch.float32) or not W.is_cuda or W.dim() != 2:
         return None
-    return W.detach(), hb.detach().reshape(-1), vb.detach().reshape(-1)
+    # (float32 parameters are handed to the float64 kernel as they are: an exact conversion)
+    return W.detach().double(), hb.detach().reshape(-1).double(), vb.detach().reshape(-1).double()
 
 
 def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
@@ -148,16 +149,19 @@ def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
 
 def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa=0, nob=0) -> bool:
     return (FUSED and WF_LUT is not None and WF_LUT.sort and not use_spin_raising
-            and sorb % 2 == 0 and h1e.dtype == torch.float64 and WF_LUT.dtype in (torch.float64, torch.complex128)
+            and sorb % 2 == 0 and h1e.dtype in (torch.float64, torch.float32)
+            and WF_LUT.dtype in (torch.float64, torch.complex128, torch.float32, torch.complex64)
             and x.is_cuda and WF_LUT.bra_key.is_cuda)
 
 
 def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[Tensor] = None, flip: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
     """(sum_k H_k t(x'_k) / t(x), t(x), second sum) with t = the table values `wf` (default: WF_LUT's psi), all in ONE kernel pass
     per sum.  flip: also  sum_k H_k eta_m(x'_k) t(flip(x'_k)) / t(x)  (the projected form's partner term, one more pass)."""
+    h1e, h2e = CX.integrals_f64(h1e, h2e)  # float32 integrals: exact up-conversion, the kernels are float64
     plan = CX.plan_for(h1e, h2e, sorb, x.device)
     dev = x.device
-    wf = (WF_LUT.wf_value if wf is None else wf).contiguous()
+    wf = WF_LUT.wf_value if wf is None else wf
+    wf = wf.to(torch.complex128 if wf.dtype.is_complex else torch.float64).contiguous()
     cplx = wf.dtype.is_complex
     n = x.size(0)
     eloc = torch.empty(n, dtype=wf.dtype, device=dev)
@@ -336,13 +340,14 @@ def local_energy(
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 
         # ---- fast path: SIMPLE with a real RBM, amplitude ratios on chip -----------------------------------
-        if (FUSED and FUSED_RBM and not reduce_psi and not use_sample_space and WF_LUT is None and dtype == torch.double and x.is_cuda
-                and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0 and h1e.dtype == torch.float64):
+        if (FUSED and FUSED_RBM and not reduce_psi and not use_sample_space and WF_LUT is None and dtype in (torch.double, torch.float32)
+                and x.is_cuda and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0
+                and h1e.dtype in (torch.float64, torch.float32)):
             prm = _real_rbm_params(ansatz)
             if prm is not None and _rbm_lds_ok(sorb, nele, noa, nob, prm[0].size(0)):
-                eloc, psi0 = CX.eloc_rbm(x, h1e, h2e, CX.RBMTable(*prm), sorb, nele, noa, nob)
+                eloc, psi0 = CX.eloc_rbm(x, *CX.integrals_f64(h1e, h2e), CX.RBMTable(*prm), sorb, nele, noa, nob)
                 t1 = time.time_ns()
-                return eloc, torch.zeros_like(eloc), psi0, ((t1 - t0) / 1e6, 0.0, 0.0)
+                return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 
         if use_multi_psi:
             ansatz_extra = partial(ansatz_batch, func=ansatz.module.extra)

@@ -388,3 +388,33 @@ def test_unique_onv_on_gpu(L, n, distinct):
     assert bool((firsts[1:] > firsts[:-1]).all())
     u2, inv2 = unique_onv(x)
     assert torch.equal(u, u2) and torch.equal(inv, inv2)
+
+
+def test_float32_inputs_take_the_fused_kernels(env, monkeypatch):
+    """float32 integrals / amplitudes (the reference dispatches f32 and f64 everywhere, cpu_tensor.cpp:249,298): the fused
+    SAMPLE_SPACE and SIMPLE-with-RBM kernels run on an exact float64 up-conversion -- results within float32 rounding of the
+    float64 goldens, returned in float32, nothing materialised."""
+    from pynqs_amd.rbm import RealRBM
+
+    d, energy, pf, dev = env["d"], env["energy"], env["pf"], env["dev"]
+    h1f, h2f = env["h1e"].float(), env["h2e"].float()
+    monkeypatch.setattr(energy, "get_comb_hij_fused", lambda *a, **k: (_ for _ in ()).throw(AssertionError("materialising path taken")))
+    # SAMPLE_SPACE, complex64 table
+    keys = torch.from_numpy(d["psi_lut_keys"]).to(dev)
+    wf = torch.from_numpy(d["psi_lut_c"]).to(dev).to(torch.complex64)
+    lut = pf.WavefunctionLUT(keys, wf, 40, device=dev)
+    e, _, p0, _ = energy.local_energy(env["x"], h1f, h2f, None, lambda x_, func: None, 40, 30, 15, 15, dtype=torch.complex64, WF_LUT=lut,
+                                      use_sample_space=True, index=(0, 32))
+    assert e.dtype == torch.complex64 and p0.dtype == torch.complex64
+    np.testing.assert_allclose(e.cpu().numpy(), d["eloc_sample_space_c"], rtol=2e-5, atol=2e-4)
+    # SIMPLE with a float32 RBM
+    torch.set_default_dtype(torch.float32)
+    try:
+        rbm32 = RealRBM(torch.from_numpy(d["W"]).float(), torch.from_numpy(d["hb"]).float(), torch.from_numpy(d["vb"]).float()).to(dev)
+        ab = lambda x, func: pf.ansatz_batch(func, x, 100000, 40, dev, torch.float32)  # noqa: E731
+        e, _, p0, _ = energy.local_energy(env["x"], h1f, h2f, rbm32, ab, 40, 30, 15, 15, dtype=torch.float32)
+    finally:
+        torch.set_default_dtype(torch.float64)
+    assert e.dtype == torch.float32
+    np.testing.assert_allclose(e.cpu().numpy(), d["eloc_simple"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(p0.cpu().numpy(), d["psi_simple"], rtol=2e-4)
