@@ -71,5 +71,23 @@ while time.time() - t0 < budget:
     e2, p2 = O.eloc_sample_space(x, h1, h2, sorb, nele, noA, noB, ks, ws)
     assert np.array_equal(psi0.cpu().numpy(), p2), ("ss psi0", sorb, noA, noB, n)
     assert np.abs(el.cpu().numpy() - e2).max() <= 1e-8 * max(1.0, np.abs(e2).max(), scale), ("ss eloc", sorb, noA, noB, n)
+    # spin-flip-projected SAMPLE_SPACE: the fused partner-sum kernel against the materialising tensor path
+    if co.shape[1] * n <= 400000:
+        kf = torch.unique(torch.cat([lut.bra_key, pf.spin_flip_onv(lut.bra_key, sorb)]), dim=0)
+        wfc = torch.from_numpy(rng.standard_normal(kf.size(0)) + 1j * rng.standard_normal(kf.size(0))).to(dev)
+        lf = pf.WavefunctionLUT(kf, wfc, sorb, device=dev)
+        pf.SpinProjection.init(nele, 0)
+        res = []
+        for fused in (True, False):
+            energy.FUSED = fused
+            try:
+                ef, _, pz, _ = energy.local_energy(G(x), h1e, h2e, None, lambda x_, func: None, sorb, nele, noA, noB, WF_LUT=lf, use_sample_space=True,
+                                                   dtype=torch.complex128, use_spin_flip=True, extra_norm=torch.tensor(1.1, dtype=torch.float64, device=dev))
+            finally:
+                energy.FUSED = True
+            res.append((ef.cpu().numpy(), pz.cpu().numpy()))
+        ok = np.isfinite(res[1][0])
+        assert np.array_equal(res[0][1], res[1][1]), ("flip psi0", sorb, noA, noB, n)
+        assert np.abs(res[0][0][ok] - res[1][0][ok]).max(initial=0.0) <= 1e-8 * max(1.0, np.abs(res[1][0][ok]).max(initial=0.0), scale), ("flip eloc", sorb, noA, noB, n)
     cases += 1
 print(f"fuzz ok: {cases} random systems in {time.time() - t0:.0f} s")
