@@ -8,6 +8,34 @@ import torch
 from torch import Tensor, nn
 
 
+class _SkinnyLinear(torch.autograd.Function):
+    """x @ w.T for x [n, k], w [m, k] with n >> m, k (walkers x orbitals against a few dozen hidden units).  The weight
+    gradient gz.T @ x is an [m, n] x [n, k] product whose reduction runs over the walkers: rocBLAS picks a kernel without
+    split-K for it (two workgroups walk all 8192 rows: 222 us of a 477 us gradient step, profiles/r02_grad_graph_kernels.txt).
+    Here it is a batched product over slabs of rows followed by a sum: the same numbers up to the order of additions."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor) -> Tensor:
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, gz: Tensor):
+        x, w = ctx.saved_tensors
+        gx = gz @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            n = x.size(0)
+            slabs = 1
+            while slabs < 256 and n % (2 * slabs) == 0 and n // (2 * slabs) >= 32:
+                slabs *= 2
+            if slabs > 1:
+                gw = torch.bmm(gz.reshape(slabs, n // slabs, -1).transpose(1, 2), x.reshape(slabs, n // slabs, -1)).sum(0)
+            else:
+                gw = gz.t() @ x
+        return gx, gw
+
+
 class RealRBM(nn.Module):
     def __init__(self, weights: Tensor, hidden_bias: Tensor, visible_bias: Tensor) -> None:
         super().__init__()
@@ -21,7 +49,7 @@ class RealRBM(nn.Module):
         # third of this forward for M ~ 1e6 rows)
         wext = torch.cat([self.weights, self.visible_bias.unsqueeze(0)], 0)
         bext = torch.cat([self.hidden_bias, self.hidden_bias.new_zeros(1)])
-        z = torch.addmm(bext, x, wext.T)
+        z = _SkinnyLinear.apply(x, wext) + bext
         # exp(a.x + sum ln 2cosh theta): the product of rbm.py:205-206 without prod(), whose backward synchronises with the host
         # (it looks for zeros with nonzero()) and therefore cannot be captured in a HIP graph (pynqs_amd.grad.GraphedGrad)
         return (z[:, -1] + (2 * z[:, :-1].cosh()).log().sum(-1)).exp()
@@ -45,7 +73,7 @@ class ComplexRBM(nn.Module):
         # 0.885 ms of a 1.5 ms gradient step for 8192 walkers, profiles/r02_fe2s2_vmc_step_v1.txt; as dgemm it is ~20 us.)
         H = self.params_weights.size(0)
         w = torch.cat([self.params_weights.permute(2, 0, 1).reshape(2 * H, -1), self.params_visible_bias.t()], 0)  # [2H + 2, sorb]
-        z = x.to(w.dtype) @ w.t()
+        z = _SkinnyLinear.apply(x.to(w.dtype), w)
         b = torch.view_as_complex(self.params_hidden_bias)
         theta = torch.complex(z[:, :H], z[:, H:2 * H]) + b
         ax = torch.complex(z[:, 2 * H], z[:, 2 * H + 1])
