@@ -446,6 +446,8 @@ class VmcStep(SampleSpaceFused):
         # gradient estimator: forward + backward replayed from a HIP graph, then ONE RCCL all-reduce of the flat gradient buffer
         # (pynqs_amd.grad.GraphedGrad; mean over the ranks = DistributedDataParallel's convention); --eager-grad: grad() under DDP
         self.graphed = G.GraphedGrad(m, self.n, sorb, torch.complex128, dev) if graphed else None
+        if self.graphed is not None:
+            self.graphed.events = []
 
     def step(self):
         st = torch.cuda.current_stream(self.dev)
@@ -479,9 +481,14 @@ class VmcStep(SampleSpaceFused):
         if not evs:
             return None
         k = len(evs)
-        return {"eloc_kernel_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / k,
-                "stats_allreduce_ms": sum(e[1].elapsed_time(e[2]) for e in evs) / k,
-                "grad_ms": sum(e[2].elapsed_time(e[3]) for e in evs) / k}
+        out = {"eloc_kernel_ms": sum(e[0].elapsed_time(e[1]) for e in evs) / k,
+               "stats_allreduce_ms": sum(e[1].elapsed_time(e[2]) for e in evs) / k,  # moments kernel + packed all-reduce + closing kernel
+               "grad_ms": sum(e[2].elapsed_time(e[3]) for e in evs) / k}
+        if self.graphed is not None and self.graphed.events:
+            ge = self.graphed.events[-k:]
+            out["grad_allreduce_ms"] = sum(a.elapsed_time(b) for a, b in ge) / len(ge)  # part of grad_ms (0 work at N = 1)
+            self.graphed.events = []
+        return out
 
     def cpu_baseline(self, budget_s=15.0):
         """The reference's own CPU extension (oracle/_ref, compiled from its sources where they lie) running the reference's
@@ -668,6 +675,8 @@ def main():
             torch.cuda.synchronize(dev)
         if hasattr(w, "phase_events"):
             w.phase_events = []
+        if getattr(w, "graphed", None) is not None:
+            w.graphed.events = []
 
     def timed(w, warmup, steps):
         preheat(w)
@@ -675,6 +684,8 @@ def main():
             w.step()
         if hasattr(w, "phase_events"):
             w.phase_events = []
+        if getattr(w, "graphed", None) is not None:
+            w.graphed.events = []
         barrier()
         t0 = time.perf_counter()
         events = [w.step() for _ in range(steps)]

@@ -88,6 +88,7 @@ class GraphedGrad:
             o += p.numel()
         self.views = views
         self.loss = torch.zeros(1, dtype=torch.double, device=dev)
+        self.events = None  # set to a list to collect (before, after) events of the gradient all-reduce of every call
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -117,11 +118,18 @@ class GraphedGrad:
             self.pow.copy_(extra_psi_pow)
         self.graph.replay()
         ws = get_world_size()
+        ev = None
+        if self.events is not None:  # caller wants the GPU-timeline split replay | all-reduce
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
         if ws > 1:
             import torch.distributed as dist
 
             dist.all_reduce(self.flat, dist.ReduceOp.SUM)
             self.flat.div_(ws)
+        if ev is not None:
+            ev[1].record()
+            self.events.append(ev)
         for p, v in zip(self.params, self.views):
             p.grad = v
         return all_reduce_packed([self.loss], ws)[0]
