@@ -715,6 +715,12 @@ def main():
             out = {"bound": "valu_f64", "kernel": w.kernel, "achieved": ach, "peak": w.F64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                    "frac": ach / w.F64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "kernel_ms": kern_ms,
                    "algorithmic_flops_per_launch": w.flops_per_walker * w.n}
+            if pmc.get("valu_insts_per_launch") and pmc.get("walkers"):
+                # instruction-issue view: all vector instructions of the launch against the measured issue rate of f64 instructions
+                # (one per 4.4 cycles per SIMD, profiles/r02_valu_peak.txt); the kernel's integer part issues faster, so this is an upper bound
+                gi = pmc["valu_insts_per_launch"] * w.n / pmc["walkers"] / t / 1e9
+                out["valu_issue"] = {"achieved": gi, "peak_f64": 256 * 4 * 2.4 / 4.4, "unit": "G wave64-instr/s", "frac": gi / (256 * 4 * 2.4 / 4.4),
+                                     "source": pmc.get("source")}
         elif getattr(w, "bound", "hbm") == "valu":
             insts = pmc.get("valu_insts_per_launch")
             if insts is not None:
@@ -722,7 +728,8 @@ def main():
             peak = VALU_PEAK_GINST
             ach = insts / t / 1e9 if insts else None
             out = {"bound": "valu", "kernel": w.kernel, "achieved": ach, "peak": peak, "unit": "G wave64-instr/s",
-                   "frac": ach / peak if ach else None, "traffic": traffic, "kernel_ms": kern_ms, "valu_instructions_per_launch": insts,
+                   "frac": ach / peak if ach else None, "frac_of_4cycle_issue": ach / (peak / 2) if ach else None,
+                   "traffic": traffic, "kernel_ms": kern_ms, "valu_instructions_per_launch": insts,
                    "columns_per_s": w.ncomb * w.n / t,
                    "source": pmc.get("source", f"no {os.path.basename(pmc_path)}: instruction count unknown")}
         else:
