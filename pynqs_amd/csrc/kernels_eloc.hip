@@ -400,7 +400,8 @@ struct Candidates {
   }
 };
 
-template <int LEN, bool CPLX, bool TWO, int BLOCK>
+// SWEEP: the doubles are scanned in block sweeps (long rows) instead of rank by rank; the host picks by the alpha-beta class's row length
+template <int LEN, bool CPLX, bool TWO, int BLOCK, bool SWEEP>
 __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
                                                                             uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
                                                                             const double *__restrict__ plan,
@@ -452,13 +453,49 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
   // tiles: 0 = column 0; 1 = this workgroup's share of the singles (blocks of 64 dealt round-robin over the walker's
   // workgroups, as in plan_tiles.h) -- one wave takes them all, so that its singles queue fills; then 256 ranks of one
   // class of doubles each
-  constexpr uint32_t kRanks = 256;
+  // Doubles: block sweeps.  A class is the index space rank = b0 + slow * nfast + u; a wave takes a block of RB whole rows
+  // (RB * nfast <= kScanCols consecutive ranks; rows wider than that are cut into position blocks, RB = 1) and keeps its lanes
+  // FIXED to positions of the block: the Zobrist value of the fast entry, its table index and the row offset are loaded once
+  // per work item; per row block a lane reads the Z value of its row, XORs, asks the filter and parks.  No division, no
+  // fast-table read and no rank arithmetic per column (the rank-by-rank scan spent 16 of its ~42 vector instructions per
+  // 64 columns on stepping (slow, u) by 64 ranks, and 2 of its 4 LDS reads on the fast entry).
+  constexpr int kScanPasses = 6;
+  constexpr uint32_t kScanCols = 64u * kScanPasses;
+  struct ScanClass {
+    uint32_t t0, t1, row0, nrows, nrb, nfb, RB, W, G, ipf, nitems;
+  };
   const uint32_t ncomb = p.nsd + 1;
   const uint32_t lo = chunk * chunk_len, hi = min(lo + chunk_len, ncomb);
   const uint32_t rlo = lo == 0 ? 0 : lo - 1, rhi = hi - 1;
-  const ClassRange gA = class_range<false>(p.d1, p.d2, rlo, rhi, 0u), gB = class_range<false>(p.d2, p.d3, rlo, rhi, 0u),
-                   gO = class_range<false>(p.d3, p.nsd, rlo, rhi, 0u);
-  const uint32_t tA = (gA.npairs + kRanks - 1) / kRanks, tB = (gB.npairs + kRanks - 1) / kRanks, tO = (gO.npairs + kRanks - 1) / kRanks;
+  auto scan_class = [&](uint32_t b0, uint32_t b1, uint32_t nfast, const MagicDiv &dv) {
+    ScanClass c;
+    const uint32_t a0 = max(rlo, b0), a1 = max(a0, min(rhi, b1));
+    c.t0 = a0 - b0; c.t1 = a1 - b0;
+    c.row0 = 0; c.nrows = 0;
+    if (a1 > a0) {
+      c.row0 = mdiv(c.t0, dv);
+      c.nrows = mdiv(c.t1 - 1u, dv) - c.row0 + 1u;
+    }
+    if (nfast > kScanCols) { c.nfb = (nfast + kScanCols - 1) / kScanCols; c.RB = 1; c.W = kScanCols; }
+    else { c.nfb = 1; c.RB = nfast ? kScanCols / nfast : 1u; c.W = c.RB * nfast; }
+    c.nrb = (c.nrows + c.RB - 1u) / c.RB;
+    c.G = min(8u, max(1u, (c.nrb + 7u) / 8u));        // row blocks per work item: ~8 items per class and position block keep the
+                                                       // workgroup's waves balanced, up to 8 row blocks share one lane set-up
+    c.ipf = (c.nrb + c.G - 1u) / c.G;
+    c.nitems = c.ipf * c.nfb;
+    return c;
+  };
+  const ScanClass gA = scan_class(p.d1, p.d2, (uint32_t)p.noAA, p.divNoAA), gB = scan_class(p.d2, p.d3, (uint32_t)p.noBB, p.divNoBB),
+                  gO = scan_class(p.d3, p.nsd, (uint32_t)p.nSa, p.divNSa);
+  // Short rows (nfast < kSweepMin: Fe2S2 has 75 and 105) keep the rank-by-rank scan, 256 consecutive ranks per tile: a block of
+  // several short rows needs the row's Z value per lane again and few, large work items -- measured 0.215 against 0.187 ms for
+  // Fe2S2, while sorb 120 / 184 (nfast 435-2116) gain 20-23 % from the sweeps (18.9 -> 15.1 ms, 13.8 -> 10.6 ms).
+  constexpr uint32_t kRanks = 256;
+  const ClassRange rA = class_range<false>(p.d1, p.d2, rlo, rhi, 0u), rB = class_range<false>(p.d2, p.d3, rlo, rhi, 0u),
+                   rO = class_range<false>(p.d3, p.nsd, rlo, rhi, 0u);
+  constexpr bool swA = SWEEP, swB = SWEEP, swO = SWEEP;  // one mode per launch: two scan loops in one kernel cost Fe2S2 10 %
+  const uint32_t tA = swA ? gA.nitems : (rA.npairs + kRanks - 1) / kRanks, tB = swB ? gB.nitems : (rB.npairs + kRanks - 1) / kRanks,
+                 tO = swO ? gO.nitems : (rO.npairs + kRanks - 1) / kRanks;
   const uint32_t ntiles = 2 + tA + tB + tO;
   for (;;) {
     uint32_t tile = 0;
@@ -498,36 +535,87 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
     }
     tile -= 2;
     const int k = tile < tA ? 0 : (tile < tA + tB ? 1 : 2);
-    const ClassRange g = k == 0 ? gA : (k == 1 ? gB : gO);
-    const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kRanks;
+    const uint32_t item = tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB));
     const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
-    // rank -> (slow, fast) by one division for the lane's first rank, then 64 further per group
-    const uint32_t q64 = mdiv(64u, c.dv), r64 = 64u - q64 * c.nfast;
     const uint32_t nslow = (uint32_t)(k == 0 ? p.nvAA : (k == 1 ? p.nvBB : p.nSb));
-    const uint32_t last = g.npairs - 1;
-    uint32_t slow, u;
-    class_split(g.r_e + min(first + (uint32_t)lane, last), c, slow, u);
-    uint32_t rr[4];
-    bool pass[4];
+    if constexpr (!SWEEP) {
+      // ---- rank-by-rank scan of 256 consecutive ranks: rank -> (slow, fast) by one division for the lane's first rank, then
+      // 64 further per group
+      const ClassRange g = k == 0 ? rA : (k == 1 ? rB : rO);
+      const uint32_t first = item * kRanks;
+      const uint32_t q64 = mdiv(64u, c.dv), r64 = 64u - q64 * c.nfast;
+      const uint32_t last = g.npairs - 1;
+      uint32_t slow, u;
+      class_split(g.r_e + min(first + (uint32_t)lane, last), c, slow, u);
+      uint32_t rr[4];
+      bool pass[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {  // independent and branch-free: the LDS reads of the four groups overlap
-      const uint32_t m = first + 64u * j + (uint32_t)lane;
+      for (int j = 0; j < 4; ++j) {  // independent and branch-free: the LDS reads of the four groups overlap
+        const uint32_t m = first + 64u * j + (uint32_t)lane;
+        uint32_t f = u + c.rot;
+        f = f >= c.nfast ? f - c.nfast : f;
+        rr[j] = TWO ? cand.pack(k, slow, f) : g.r_e + m;
+        // (lanes past the end of the class read a valid but meaningless entry: slow is clamped to the class's last row)
+        const uint32_t z = zx ^ cand.flipped_at(c.off_fast + f) ^ cand.flipped_at(c.off_slow + min(slow, nslow - 1u));
+        pass[j] = (m <= last) & cand.maybe(z);
+        u += r64;
+        slow += q64 + (u >= c.nfast ? 1u : 0u);
+        u = u >= c.nfast ? u - c.nfast : u;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cand.template park<false, 1>(rr[j], pass[j]);
+        if constexpr (!TWO) cand.template pump<false>();
+      }
+      if constexpr (TWO) cand.template pump<false>();
+    } else {
+    // ---- block sweep (long rows)
+    const ScanClass g = k == 0 ? gA : (k == 1 ? gB : gO);
+    const uint32_t fb = item / g.ipf, grp = item - fb * g.ipf;
+    const uint32_t rb0 = grp * g.G, rb1 = min(rb0 + g.G, g.nrb);
+    const uint32_t nfast = c.nfast, RB = g.RB;
+    const uint32_t ub = fb * kScanCols;                                 // first position of this position block
+    const uint32_t W = RB > 1 ? g.W : min(kScanCols, nfast - ub);       // positions per row block
+    const int npass = (int)((W + 63u) >> 6);                            // wave-uniform
+    // lane-fixed part
+    uint32_t zf[kScanPasses], code0[kScanPasses], rj[kScanPasses];
+    bool okq[kScanPasses];
+#pragma unroll
+    for (int j = 0; j < kScanPasses; ++j) {
+      const uint32_t q = 64u * j + (uint32_t)lane;
+      okq[j] = q < W;
+      const uint32_t qq = okq[j] ? q : 0u;
+      rj[j] = RB > 1 ? mdiv(qq, c.dv) : 0u;
+      const uint32_t u = ub + qq - rj[j] * nfast;
       uint32_t f = u + c.rot;
-      f = f >= c.nfast ? f - c.nfast : f;
-      rr[j] = TWO ? cand.pack(k, slow, f) : g.r_e + m;
-      // (lanes past the end of the class read a valid but meaningless entry: slow is clamped to the class's last row)
-      const uint32_t z = zx ^ cand.flipped_at(c.off_fast + f) ^ cand.flipped_at(c.off_slow + min(slow, nslow - 1u));
-      pass[j] = (m <= last) & cand.maybe(z);
-      u += r64;
-      slow += q64 + (u >= c.nfast ? 1u : 0u);
-      u = u >= c.nfast ? u - c.nfast : u;
+      f = f >= nfast ? f - nfast : f;
+      zf[j] = zx ^ cand.flipped_at(c.off_fast + f);
+      code0[j] = TWO ? cand.pack(k, 0u, f) : c.b0 + u;  // parked entry: class | slow << 15 | fast-table index, or the rank
     }
+    for (uint32_t rb = rb0; rb < rb1; ++rb) {
+      const uint32_t srow = g.row0 + rb * RB;
+      const uint32_t flat0 = srow * nfast + ub;  // flat position of the block's first column (wave-uniform)
+      const bool interior = flat0 >= g.t0 && flat0 + W <= g.t1 && srow + RB <= g.row0 + g.nrows;  // wave-uniform
+      uint32_t zs1 = 0;
+      if (RB == 1) zs1 = cand.flipped_at(c.off_slow + min(srow, nslow - 1u));  // one row: the same value for every pass
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      cand.template park<false, 1>(rr[j], pass[j]);
-      if constexpr (!TWO) cand.template pump<false>();
+      for (int j = 0; j < kScanPasses; ++j) {
+        if (j >= npass) break;
+        const uint32_t row = srow + rj[j];
+        const uint32_t zs = RB == 1 ? zs1 : cand.flipped_at(c.off_slow + min(row, nslow - 1u));
+        bool valid = okq[j];
+        if (!interior) {
+          const uint32_t flat = flat0 + 64u * j + (uint32_t)lane;  // rows of a block are consecutive ranks
+          valid = valid && row < g.row0 + g.nrows && flat >= g.t0 && flat < g.t1;
+        }
+        const bool pass = valid & cand.maybe(zf[j] ^ zs);
+        cand.template park<false, 1>(TWO ? (code0[j] | (row << 15)) : code0[j] + row * nfast, pass);
+        if constexpr (!TWO) cand.template pump<false>();
+        else if ((j & 3) == 3) cand.template pump<false>();  // queue 1 holds 320 entries: < 64 left over + four passes
+      }
+      if constexpr (TWO) cand.template pump<false>();
     }
-    if constexpr (TWO) cand.template pump<false>();
+    }
   }
   cand.template flush<false>();
   store_walker_sum<CPLX, BLOCK / 64>(cand.re, cand.im, red, nchunks, walker, acc);
@@ -765,6 +853,9 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   const double *pd = (const double *)plan;
   const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
+  // block sweeps once the rows of the alpha-beta class (nSa positions) are long: sorb 120 / 184 gain 20-23 %, Fe2S2 (75) would lose 12 %
+  static const int sweep_env = getenv("PYNQS_SS_SWEEP") ? atoi(getenv("PYNQS_SS_SWEEP")) : -1;
+  const bool sweep = sweep_env >= 0 ? sweep_env != 0 : p.nSa >= 256;
 #define PYNQS_SS_ARGS dim3((uint32_t)grid), dim3(block), lds, st, bra, p, pl, nchunks, chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0, flip
 #define PYNQS_SS_LAUNCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                            \
@@ -773,16 +864,17 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
       return check_launch("hipFuncSetAttribute");                                                                                \
     hipLaunchKernelGGL((KERNEL), PYNQS_SS_ARGS, ##__VA_ARGS__);                                                                   \
   } while (0)
-#define PYNQS_SS_FILTERED(B)                                                                                      \
-  do {                                                                                                            \
-    if (two_level) {                                                                                              \
-      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, true, B>), fbits, f2bits);  \
-      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, true, B>), fbits, f2bits);              \
-    } else {                                                                                                      \
-      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, false, B>), fbits, f2bits); \
-      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, false, B>), fbits, f2bits);             \
-    }                                                                                                             \
+#define PYNQS_SS_FILTERED2(B, SW)                                                                                      \
+  do {                                                                                                                 \
+    if (two_level) {                                                                                                   \
+      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, true, B, SW>), fbits, f2bits);   \
+      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, true, B, SW>), fbits, f2bits);               \
+    } else {                                                                                                           \
+      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, false, B, SW>), fbits, f2bits);  \
+      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, false, B, SW>), fbits, f2bits);              \
+    }                                                                                                                  \
   } while (0)
+#define PYNQS_SS_FILTERED(B) do { if (sweep) PYNQS_SS_FILTERED2(B, true); else PYNQS_SS_FILTERED2(B, false); } while (0)
   DISPATCH_LEN(len, {
     if (filtered) {  // hash table with its filters
       if constexpr (LEN >= 2) {
@@ -799,6 +891,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
     }
   });
 #undef PYNQS_SS_FILTERED
+#undef PYNQS_SS_FILTERED2
 #undef PYNQS_SS_ARGS
 #undef PYNQS_SS_LAUNCH
   const uint32_t g2 = (uint32_t)((nbatch + kBlock - 1) / kBlock);
