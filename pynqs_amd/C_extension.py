@@ -320,6 +320,24 @@ class HashTable:
     def memory(self) -> int:
         return self.table.numel() * self.table.element_size()
 
+    # the reference's table is an array of buckets (cuda/hashTable.cu); this one is open addressing with one key per slot:
+    # bucketNum = number of slots (a power of two >= 4 * nkeys), bucketSize = 1
+    @property
+    def bucketNum(self) -> int:
+        cap = 64
+        while cap < 4 * max(self.nkeys, 1):
+            cap *= 2
+        return cap
+
+    @property
+    def bucketSize(self) -> int:
+        return 1
+
+    @staticmethod
+    def bitWidth() -> int:
+        """sizeof(key word) in bytes, as the reference's HashTable.bitWidth (libs/C_extension.pyi:385-389)."""
+        return 8
+
     def cleanMemory(self) -> None:
         self.table = None
 

@@ -143,3 +143,41 @@ def test_header_is_valid_c99(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-Wno-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr), str(src)])
     declared = set(re.findall(r"\b(pynqs_[a-z0-9_]+)\s*\(", open(hdr).read()))
     assert declared == set(names)
+
+
+def test_dropin_matches_the_reference_api_surface():
+    """Every name of the reference's `libs.C_extension` (libs/C_extension.pyi; captured as data by tests/golden/make_api_fixture.py)
+    exists in the drop-in module with the same parameter names, order and defaults; stubs of functions outside the local-energy path
+    raise NotImplementedError."""
+    import inspect
+    import json
+    import os
+
+    import pytest
+
+    from pynqs_amd.dropin.libs import C_extension as drop
+
+    api = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c_extension_api.json")))
+    out_of_path = {"MCMC_sample", "mps_vbatch", "permute_sgn", "convert_sites", "constrain_make_charts"}
+    for name, spec in api["functions"].items():
+        assert hasattr(drop, name), name
+        fn = getattr(drop, name)
+        if name in out_of_path:
+            with pytest.raises(NotImplementedError):
+                fn(*([None] * len(spec["params"])))
+            continue
+        sig = inspect.signature(fn)
+        params = list(sig.parameters.values())
+        got = [q.name for q in params]
+        # (the drop-in may add trailing keyword parameters with defaults, never rename or reorder the reference's)
+        assert got[:len(spec["params"])] == spec["params"], (name, got, spec["params"])
+        for q in params[len(spec["params"]):]:
+            assert q.default is not inspect.Parameter.empty, (name, q.name)
+        for pn, dv in spec["defaults"].items():
+            assert sig.parameters[pn].default == dv, (name, pn)
+    for cls, methods in api["classes"].items():
+        assert hasattr(drop, cls), cls
+        for m in methods:
+            assert hasattr(getattr(drop, cls), m), (cls, m)
+    for attr in api["attributes"]:
+        assert isinstance(getattr(drop, attr), int), attr
