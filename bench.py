@@ -641,6 +641,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    # rehearsal of the N > 1 code path on a one-GPU box: PYNQS_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device); never a measurement
+    rehearsal = os.environ.get("PYNQS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -649,7 +654,10 @@ def main():
 
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             # N = 1 runs the same code path as N > 1 (DDP wrapper, RCCL calls on a one-rank communicator)
             import socket
@@ -663,16 +671,26 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if rehearsal:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
     def preheat(w, seconds=0.4):
-        """Untimed: run the step until the GPU has been busy for `seconds` (clock ramp-up), then drop the recorded events."""
+        """Untimed: run the step until the GPU has been busy for about `seconds` (clock ramp-up), then drop the recorded events.
+        The number of steps is agreed between the ranks (a step contains collectives)."""
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            for _ in range(8):
-                w.step()
-            torch.cuda.synchronize(dev)
+        for _ in range(8):
+            w.step()
+        torch.cuda.synchronize(dev)
+        per = max((time.perf_counter() - t0) / 8, 1e-6)
+        n = torch.tensor([min(int(seconds / per), 20000)], dtype=torch.int64, device=dev)
+        if dist is not None and world > 1:
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        for _ in range(int(n.item())):
+            w.step()
+        torch.cuda.synchronize(dev)
         if hasattr(w, "phase_events"):
             w.phase_events = []
         if getattr(w, "graphed", None) is not None:
@@ -764,7 +782,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "shipped Fe2S2 integrals + ci_space walkers (tests/golden fixture)" if args.workload.startswith("fe2s2")
+            "data": ("REHEARSAL (all ranks on one GPU, gloo): not a measurement; " if rehearsal else "") +
+                    "shipped Fe2S2 integrals + ci_space walkers (tests/golden fixture)" if args.workload.startswith("fe2s2")
                     else "synthetic (seeded dense integrals, random walkers)",
             "config": {"workload": wl.name, "sorb": wl.sorb, "nele": wl.nele, "ncomb": wl.ncomb,
                        "walkers_per_gpu": wl.n, "integral_layout": wl.path, "plan_build_ms": wl.plan_build_ms,
@@ -888,7 +907,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 
