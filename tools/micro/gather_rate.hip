@@ -7,24 +7,31 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-// every wave issues `iters` x 8 independent loads; offsets (in elements of W bytes) come from a per-lane table
+// every wave issues `iters` x 8 independent loads (plain C++ loads: the compiler tracks their completion; an earlier version used
+// inline-asm loads, whose results it does not track -- registers were reused while loads were in flight and the W = 4 variant faulted);
+// offsets (in 8-byte elements) come from a per-lane table
+template <int W> struct LoadT;
+template <> struct LoadT<4> { typedef uint32_t type; };
+template <> struct LoadT<8> { typedef uint64_t type; };
+template <> struct LoadT<16> { typedef uint4 type; };
+__device__ __forceinline__ uint64_t fold(uint32_t v) { return v; }
+__device__ __forceinline__ uint64_t fold(uint64_t v) { return v; }
+__device__ __forceinline__ uint64_t fold(uint4 v) { return (uint64_t)v.x + v.w; }
+
 template <int W, int ACTIVE>
 __global__ __launch_bounds__(256) void kload(const char* __restrict__ base, const uint32_t* __restrict__ offs, int iters, uint64_t* out) {
+    typedef typename LoadT<W>::type T;
     const int lane = threadIdx.x & 63;
     uint32_t o[8];
     for (int i = 0; i < 8; ++i) o[i] = offs[(threadIdx.x * 8 + i) & 2047];
     uint64_t acc = 0;
     if (lane < ACTIVE) {
         for (int it = 0; it < iters; ++it) {
+            T v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const char* p = base + (size_t)((o[i] + it * 64u) & 0x3ffffu) * 8u;  // stays inside 2 MiB
-                if constexpr (W == 4) { uint32_t v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p)); acc += v; }
-                if constexpr (W == 8) { uint64_t v; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p)); acc += v; }
-                if constexpr (W == 16) { typedef uint32_t u4 __attribute__((ext_vector_type(4))); u4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p)); acc += v[0] + v[3]; }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(acc));
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const T*>(base + (size_t)((o[i] + it * 64u) & 0x3ffffu) * 8u);  // inside 2 MiB (+ 16 B)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += fold(v[i]);
         }
     }
     if (acc == 0x1234567) out[0] = acc;
@@ -33,15 +40,16 @@ __global__ __launch_bounds__(256) void kload(const char* __restrict__ base, cons
 template <int W>
 __global__ __launch_bounds__(256) void kstore(char* __restrict__ base, int iters) {
     // each wave writes its own contiguous spans: 64 lanes x W bytes per instruction
+    typedef typename LoadT<W>::type T;
     const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    char* p = base + (wave * (size_t)iters * 8) * 64 * W + (size_t)lane * W;
+    T* p = reinterpret_cast<T*>(base + (wave * (size_t)iters * 8) * 64 * W) + lane;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if constexpr (W == 8) { uint64_t v = it + i; asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory"); }
-            if constexpr (W == 16) { typedef uint32_t u4 __attribute__((ext_vector_type(4))); u4 v = {(uint32_t)it, (uint32_t)i, 0u, 1u}; asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory"); }
-            p += 64 * W;
+            T v;
+            if constexpr (W == 16) v = make_uint4((uint32_t)it, (uint32_t)i, 0u, 1u); else v = (T)(it + i);
+            p[(size_t)(it * 8 + i) * 64] = v;
         }
     }
 }
