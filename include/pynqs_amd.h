@@ -177,6 +177,16 @@ int pynqs_rbm_table_build(const double *weights, const double *hidden_bias, cons
                           int nhidden, void *table, void *stream);
 int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                    const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream);
+/* The reference's other RBM amplitudes that share the hidden-unit product (rbm.py:199-211), from the same table:
+ *   PYNQS_RBM_REAL  psi = exp(a.x)  prod_h 2cosh(theta_h)                    eloc, psi double[nbatch]  (= pynqs_eloc_rbm)
+ *   PYNQS_RBM_TANH  psi = tanh(a.x) prod_h 2cosh(theta_h)   (rbm_type "tanh") eloc, psi double[nbatch]
+ *   PYNQS_RBM_PHASE psi = exp(i (a.x + sum_h ln 2cosh(theta_h)))  ("pRBM")   eloc, psi double[nbatch][2] = (re, im)
+ * ("cos" and "complex" are not fused: they run through the module path of pynqs_amd.energy.local_energy.) */
+#define PYNQS_RBM_REAL 0
+#define PYNQS_RBM_TANH 1
+#define PYNQS_RBM_PHASE 2
+int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                           const void *rbm_table, int nhidden, int flavour, double *eloc, double *psi, void *stream);
 
 /* ---- Green's-function Monte-Carlo move: gfmc/walker.py:260-279 (sample_update) in one kernel ---------------
  * green double[n][ncomb] (the fixed-node Green's function row of each walker, >= 0), rand_num double[n] in [0, 1),

@@ -402,12 +402,17 @@ class RBMTable:
         return self.buf.data_ptr()
 
 
+RBM_FLAVOURS = {"real": N.RBM_REAL, "tanh": N.RBM_TANH, "pRBM": N.RBM_PHASE}  # rbm_type (rbm.py:199-211) -> include/pynqs_amd.h
+
+
 def eloc_rbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: RBMTable, sorb: int, nele: int, noA: int, noB: int,
-             want_psi: bool = True) -> Tuple[Tensor, "Tensor | None"]:
-    """SIMPLE local energy with the real-RBM amplitude ratio evaluated on chip (pynqs_eloc_rbm):
-    (eloc float64[n], psi(x) float64[n] or None).  Equivalent to vmc/energy/eloc.py:121-203 with
-    ansatz = RBMWavefunction(rbm_type="real")."""
+             want_psi: bool = True, rbm_type: str = "real") -> Tuple[Tensor, "Tensor | None"]:
+    """SIMPLE local energy with the RBM amplitude ratio evaluated on chip (pynqs_eloc_rbm_flavour):
+    (eloc[n], psi(x)[n] or None), float64 for rbm_type "real" / "tanh", complex128 for "pRBM".  Equivalent to
+    vmc/energy/eloc.py:121-203 with ansatz = RBMWavefunction(rbm_type=...)."""
     _check_onv(bra, "bra", sorb, (2,))
+    if rbm_type not in RBM_FLAVOURS:
+        raise RuntimeError(f"rbm_type {rbm_type!r} has no fused local energy (fused: {sorted(RBM_FLAVOURS)})")
     if table.sorb != sorb:
         raise RuntimeError(f"RBM table was built for sorb = {table.sorb}, not {sorb}")
     if _fdtype(h1e, h2e) != N.PYNQS_F64:
@@ -419,10 +424,12 @@ def eloc_rbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: RBMTable, sorb: int, 
     if plan.device != dev or table.device != dev:
         raise RuntimeError("bra, integrals and RBM table must be on the same device")
     n = x.size(0)
-    eloc = torch.empty(n, dtype=torch.float64, device=dev)
-    psi = torch.empty(n, dtype=torch.float64, device=dev) if want_psi else None
-    N.check(N.lib().pynqs_eloc_rbm(x.data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), table.data_ptr(), table.nhidden,
-                                   eloc.data_ptr(), psi.data_ptr() if want_psi else None, _stream(dev)), "pynqs_eloc_rbm")
+    dt = torch.complex128 if rbm_type == "pRBM" else torch.float64
+    eloc = torch.empty(n, dtype=dt, device=dev)
+    psi = torch.empty(n, dtype=dt, device=dev) if want_psi else None
+    N.check(N.lib().pynqs_eloc_rbm_flavour(x.data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), table.data_ptr(), table.nhidden,
+                                           RBM_FLAVOURS[rbm_type], eloc.data_ptr(), psi.data_ptr() if want_psi else None, _stream(dev)),
+            "pynqs_eloc_rbm")
     if all_cpu and bra.device.type == "cpu":
         return eloc.cpu(), (psi.cpu() if want_psi else None)
     return eloc, psi

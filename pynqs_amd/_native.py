@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYNQS_AMD_LIB") or os.path.join(_HERE, "csrc", "libpynqs_amd.so")
 
 PYNQS_F32, PYNQS_F64 = 0, 1
+RBM_REAL, RBM_TANH, RBM_PHASE = 0, 1, 2
 OK, EINVAL, ELAUNCH, ELENGTH, EOVERFLOW = 0, -1, -2, -3, -4
 
 _i64, _int, _vp, _dbl = C.c_int64, C.c_int, C.c_void_p, C.c_double
@@ -47,6 +48,7 @@ SIGNATURES = {
     "pynqs_rbm_table_bytes": (_i64, [_int, _int]),
     "pynqs_rbm_table_build": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_eloc_rbm": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp]),
+    "pynqs_eloc_rbm_flavour": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "pynqs_gfmc_sample": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "pynqs_moments_workspace": (_i64, []),
     "pynqs_stats_finish": (_int, [_vp, _dbl, _dbl, _vp, _vp]),

@@ -20,6 +20,14 @@
 // The kernel is bound by the f64 vector rate (84 % busy), not by HBM.  When sorb x
 // num_hidden does not fit the LDS the WINDOWED variant streams q' through it (see eloc_rbm_kernel).
 // Matrix elements come from the integral plan exactly as in kernels_plan.hip.
+//
+// FLAVOUR selects the reference's other amplitudes that share the hidden-unit product (rbm.py:199-211):
+//   kRbmReal  psi = exp(a.x)  prod_h 2cosh(theta_h)
+//   kRbmTanh  psi = tanh(a.x) prod_h 2cosh(theta_h)            -- C(o) without a_o; tanh(a.x') = 1 - 2 / (exp(2 a.x') + 1) with
+//             exp(2 a.x') = exp(2 a.x) prod_{o in F} exp(-4 x_o a_o): table products and one division per column
+//   kRbmPhase psi = exp(i (a.x + sum_h ln 2cosh(theta_h)))     -- "pRBM": the phase difference of x' and x IS the logarithm of the
+//             real flavour's ratio, so psi(x')/psi(x) = exp(i ln t) with t from the same running products; E_loc is complex
+// ("cos" and "complex" need complex running products: they take the module path.)
 #include "detcore.h"
 #include "launch.h"
 #include "plan.h"
@@ -79,7 +87,7 @@ static inline RbmBlocks make_rbm_blocks(const SDParams &p) {
 typedef __attribute__((address_space(3))) const double lds_cdouble;  // read through a 32-bit LDS address
 
 struct RbmLds {
-  double *q, *mn, *sh, *Cq, *hs;
+  double *q, *mn, *sh, *Cq, *Aq, *hs;  // Aq [sorb + 2]: exp(-4 x_o a_o) (tanh flavour: exp(2 a.x') = exp(2 a.x) prod over the flipped orbitals)
   uint32_t *rowaddr;  // [sorb + 2]: LDS byte address of an orbital's q row (the dummy's at index sorb)
 };
 
@@ -93,7 +101,7 @@ __host__ __device__ inline size_t rbm_region_bytes(const SDParams &p, uint32_t h
 
 __host__ __device__ inline size_t lds_bytes_rbm(const SDParams &p, const RbmLayout &rl, uint32_t hw) {
   return rbm_q_offset(p) + rbm_region_bytes(p, hw) +
-         8 * (3 * (size_t)rl.Hq + (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 144;  // + red (up to 16 waves), counters
+         8 * (3 * (size_t)rl.Hq + 2 * (size_t)(p.sorb + 2) + (size_t)(p.d1 + 2)) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 144;  // + red (up to 16 waves), counters
 }
 
 __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o >> 1) + ((o & 1u) ? K : 0u); }
@@ -102,7 +110,9 @@ __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o 
 // WINDOWED = true : sorb x num_hidden does not fit: the workgroup streams q' through LDS `hw` hidden units at a time;
 //                   in every round each wave holds the 16 x 64 running products of ONE tile in registers across the
 //                   windows (two barriers per window).
-template <int LEN, bool WINDOWED>
+enum : int { kRbmReal = 0, kRbmTanh = 1, kRbmPhase = 2 };
+
+template <int LEN, bool WINDOWED, int FLAVOUR>
 __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
                                                           RbmBlocks B, uint32_t nchunks, uint32_t hw, const double *__restrict__ plan,
                                                           const double *__restrict__ rbm, double *__restrict__ eloc,
@@ -133,7 +143,8 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
     R.mn = reinterpret_cast<double *>(smem + rbm_q_offset(p) + rbm_region_bytes(p, hw));
     R.sh = R.mn + 2 * Hq;
     R.Cq = R.sh + Hq;
-    R.hs = R.Cq + (sorb + 2);
+    R.Aq = R.Cq + (sorb + 2);
+    R.hs = R.Aq + (sorb + 2);
     R.rowaddr = reinterpret_cast<uint32_t *>(R.hs + (p.d1 + 2));
   }
 #if defined(PYNQS_RBM_STOP) && PYNQS_RBM_STOP == 1
@@ -271,13 +282,28 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
   const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)rbm_q_offset(p), rowB = stride * 8u;
   for (int o = tid; o <= sorb; o += nthreads) {
     R.rowaddr[o] = qbase + (o < sorb ? rbm_row(o, K) : (uint32_t)sorb) * rowB;
-    double c = 1.0;
+    double c = 1.0, da = 1.0;
     if (o < sorb) {
       const double x = bit_of<LEN>(wk.w, o) ? 1.0 : -1.0, a = rbm[rl.offVb + o];
-      c = exp(-2.0 * x * (a + R.Cq[o]));
-      lnpsi += x * a;
+      if constexpr (FLAVOUR == kRbmTanh) {
+        c = exp(-2.0 * x * R.Cq[o]);
+        da = exp(-4.0 * x * a);
+      } else {
+        c = exp(-2.0 * x * (a + R.Cq[o]));
+        lnpsi += x * a;
+      }
     }
     R.Cq[o] = c;
+    if constexpr (FLAVOUR == kRbmTanh) R.Aq[o] = da;
+  }
+  double ax = 0.0, e2ax = 1.0, inv_tanh_ax = 1.0;  // tanh flavour: a.x (wave-uniform: scalar loads), exp(2 a.x), 1 / tanh(a.x)
+  if constexpr (FLAVOUR == kRbmTanh) {
+    for (int o = 0; o < sorb; ++o) {
+      const double a = rbm[rl.offVb + o];
+      ax += bit_of<LEN>(wk.w, o) ? a : -a;
+    }
+    e2ax = exp(2.0 * ax);
+    inv_tanh_ax = 1.0 / tanh(ax);
   }
   __syncthreads();
 #if defined(PYNQS_RBM_STOP) && PYNQS_RBM_STOP == 3
@@ -290,7 +316,23 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
   const double *__restrict__ Vab = plan + pl.offVab;
   const uint32_t my_tiles = B.ntiles > chunk ? (B.ntiles - chunk + nchunks - 1) / nchunks : 0;
   const uint32_t nrounds = (my_tiles + nwaves - 1) / nwaves;  // WINDOWED only
-  double esum = 0.0;
+  double esum = 0.0, esum_im = 0.0;
+  // one column's contribution: h = <x|H|x'>, t = the real flavour's psi(x')/psi(x) (for tanh: without the visible factor),
+  // da = exp(2 (a.x' - a.x))
+  auto add_column = [&](double h, double t, double da) {
+    if constexpr (FLAVOUR == kRbmReal) {
+      esum += h * t;
+    } else if constexpr (FLAVOUR == kRbmTanh) {
+      const double th = 1.0 - 2.0 / fma(e2ax, da, 1.0);  // tanh(a.x'); exp(2 a.x') = inf -> 1, 0 -> -1
+      esum += h * (t * (th * inv_tanh_ax));
+    } else {
+      double sn, cs;
+      sincos(log(t), &sn, &cs);
+      esum += h * cs;
+      esum_im += h * sn;
+      asm volatile("" ::: "memory");  // one column at a time: 16 interleaved log / sincos expansions spill
+    }
+  };
   for (uint32_t round = 0;; ++round) {
     uint32_t lt = 0;
     if constexpr (WINDOWED) {
@@ -381,17 +423,22 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
     if (cls < 4) {
       uint32_t ef[4], es[4];
       entries(ef, es);
-      double cf[4], cs[4];
+      double cf[4], cs[4], af[4], as[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         cf[i] = R.Cq[ef[i] & 0xff] * R.Cq[(ef[i] >> 8) & 0xff];
         cs[i] = cls == 0 ? 1.0 : R.Cq[es[i] & 0xff] * R.Cq[(es[i] >> 8) & 0xff];
+        af[i] = as[i] = 1.0;
+        if constexpr (FLAVOUR == kRbmTanh) {
+          af[i] = R.Aq[ef[i] & 0xff] * R.Aq[(ef[i] >> 8) & 0xff];
+          as[i] = cls == 0 ? 1.0 : R.Aq[es[i] & 0xff] * R.Aq[(es[i] >> 8) & 0xff];
+        }
       }
       if (cls == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t f = 4 * bf + i;
-          if (f < nF) esum += R.hs[1 + f] * (acc[4 * i] * cf[i]);
+          if (f < nF) add_column(R.hs[1 + f], acc[4 * i] * cf[i], af[i]);
         }
       } else {
         const bool opp = cls == 3;
@@ -414,32 +461,48 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
             else par ^= (uint32_t)(a0 < b0) ^ (uint32_t)(a1 < b0) ^ (uint32_t)(a0 < b1) ^ (uint32_t)(a1 < b1);
             const bool ok = 4 * bf + i < nF && 4 * bs + j < nS;
             const double t = (acc[4 * i + j] * cf[i]) * cs[j];
-            if (ok) esum += (par ? -hv[4 * i + j] : hv[4 * i + j]) * t;
+            if (ok) add_column(par ? -hv[4 * i + j] : hv[4 * i + j], t, af[i] * as[j]);
           }
         }
       }
     }
   }
   if (chunk == 0 && tid == 0) esum += R.hs[0];  // x' = x
-  // fixed-order reductions: lanes, then waves
+  // fixed-order reductions: lanes, then waves.  kRbmPhase: eloc / psi hold (re, im) pairs
+  constexpr int kOut = FLAVOUR == kRbmPhase ? 2 : 1;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { esum += __shfl_xor(esum, o); lnpsi += __shfl_xor(lnpsi, o); }
-  if (lane == 0) red[wave] = esum;
-  __syncthreads();
-  if (tid == 0) {
+  for (int o = 32; o > 0; o >>= 1) {
+    esum += __shfl_xor(esum, o);
+    lnpsi += __shfl_xor(lnpsi, o);
+    if constexpr (FLAVOUR == kRbmPhase) esum_im += __shfl_xor(esum_im, o);
+  }
+  auto over_waves = [&](double v) {  // workgroup-uniform calls; the sum is valid in thread 0
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
     double s = 0.0;
-    for (int w = 0; w < nwaves; ++w) s += red[w];
-    if (nchunks == 1) eloc[walker] = s;
-    else atomicAdd(eloc + walker, s);
+    if (tid == 0)
+      for (int w = 0; w < nwaves; ++w) s += red[w];
+    return s;
+  };
+  const double e_re = over_waves(esum);
+  if (tid == 0) {
+    if (nchunks == 1) eloc[kOut * walker] = e_re;
+    else atomicAdd(eloc + kOut * walker, e_re);
+  }
+  if constexpr (FLAVOUR == kRbmPhase) {
+    const double e_im = over_waves(esum_im);
+    if (tid == 0) {
+      if (nchunks == 1) eloc[2 * walker + 1] = e_im;
+      else atomicAdd(eloc + 2 * walker + 1, e_im);
+    }
   }
   if (psi != nullptr && chunk == 0) {  // workgroup-uniform
-    __syncthreads();
-    if (lane == 0) red[wave] = lnpsi;
-    __syncthreads();
+    const double s = over_waves(lnpsi);
     if (tid == 0) {
-      double s = 0.0;
-      for (int w = 0; w < nwaves; ++w) s += red[w];
-      psi[walker] = exp(s);
+      if constexpr (FLAVOUR == kRbmReal) psi[walker] = exp(s);
+      else if constexpr (FLAVOUR == kRbmTanh) psi[walker] = tanh(ax) * exp(s);
+      else sincos(s, &psi[2 * walker + 1], &psi[2 * walker]);
     }
   }
 }
@@ -507,9 +570,10 @@ extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden
   return check_launch("rbm_table_build");
 }
 
-extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
-                              const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream) {
+extern "C" int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                                      const void *rbm_table, int nhidden, int flavour, double *eloc, double *psi, void *stream) {
   pynqs::DeviceScope device_scope_(bra);
+  if (flavour < PYNQS_RBM_REAL || flavour > PYNQS_RBM_PHASE) return set_error(PYNQS_EINVAL, "unknown RBM flavour");
   SDParams p;
   PlanLayout pl;
   RbmLayout rl;
@@ -535,7 +599,8 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   hipStream_t st = (hipStream_t)stream;
-  if (nchunks > 1 && hipMemsetAsync(eloc, 0, 8 * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
+  if (nchunks > 1 && hipMemsetAsync(eloc, 0, (flavour == PYNQS_RBM_PHASE ? 16 : 8) * (size_t)nbatch, st) != hipSuccess)
+    return check_launch("memset");
   const int len = (sorb - 1) / 64 + 1;
   // (3-wave workgroups divide Fe2S2's 9 tiles evenly but leave only 12 waves per CU -- LDS allows 4 workgroups --
   // and were 8 % slower at 80 hidden units; the kernel itself runs with any multiple of 64 threads >= 128)
@@ -555,18 +620,30 @@ extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int
     }
     if (blk_env == 256 || blk_env == 512 || blk_env == 1024) threads = (uint32_t)blk_env;
   }
-#define PYNQS_RBM_LAUNCH(W)                                                                                                     \
-  do {                                                                                                                          \
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN, W>),                       \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)            \
-      return check_launch("hipFuncSetAttribute");                                                                               \
-    hipLaunchKernelGGL((eloc_rbm_kernel<LEN, W>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, rl, B, nchunks, hw, \
-                       (const double *)plan, (const double *)rbm_table, eloc, psi);                                            \
+#define PYNQS_RBM_LAUNCH(W, F)                                                                                                     \
+  do {                                                                                                                             \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN, W, F>),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
+      return check_launch("hipFuncSetAttribute");                                                                                  \
+    hipLaunchKernelGGL((eloc_rbm_kernel<LEN, W, F>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, rl, B, nchunks, hw, \
+                       (const double *)plan, (const double *)rbm_table, eloc, psi);                                               \
+  } while (0)
+#define PYNQS_RBM_FLAVOURS(W)                                      \
+  do {                                                             \
+    if (flavour == PYNQS_RBM_REAL) PYNQS_RBM_LAUNCH(W, kRbmReal);  \
+    else if (flavour == PYNQS_RBM_TANH) PYNQS_RBM_LAUNCH(W, kRbmTanh); \
+    else PYNQS_RBM_LAUNCH(W, kRbmPhase);                           \
   } while (0)
   DISPATCH_LEN(len, {
-    if (windowed) PYNQS_RBM_LAUNCH(true);
-    else PYNQS_RBM_LAUNCH(false);
+    if (windowed) PYNQS_RBM_FLAVOURS(true);
+    else PYNQS_RBM_FLAVOURS(false);
   });
+#undef PYNQS_RBM_FLAVOURS
 #undef PYNQS_RBM_LAUNCH
   return check_launch("eloc_rbm");
+}
+
+extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                              const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream) {
+  return pynqs_eloc_rbm_flavour(bra, nbatch, sorb, nele, noA, noB, plan, rbm_table, nhidden, PYNQS_RBM_REAL, eloc, psi, stream);
 }

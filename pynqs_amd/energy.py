@@ -128,18 +128,20 @@ def _reduce_select(comb_hij: Tensor, eps: float, eps_sample: int) -> Tensor:
 
 
 def _real_rbm_params(ansatz):
-    """(weights [H, sorb], hidden_bias [H], visible_bias [sorb]) if `ansatz` (possibly DDP-wrapped) is a real RBM
-    with the reference's formula (pynqs_amd.rbm.RealRBM, or PyNQS' RBMWavefunction with rbm_type == "real"), else None."""
+    """(weights [H, sorb], hidden_bias [H], visible_bias [sorb], rbm_type) if `ansatz` (possibly DDP-wrapped) is an RBM with real
+    parameters and one of the fused formulas (pynqs_amd.rbm.RealRBM, or PyNQS' RBMWavefunction, rbm_type "real" / "tanh" / "pRBM",
+    rbm.py:199-211), else None."""
     from .rbm import RealRBM
 
     m = getattr(ansatz, "module", ansatz)
-    if not (isinstance(m, RealRBM) or getattr(m, "rbm_type", None) == "real"):
+    kind = getattr(m, "rbm_type", None)
+    if kind not in CX.RBM_FLAVOURS or not (isinstance(m, RealRBM) or hasattr(m, "effective_theta")):
         return None
     W, hb, vb = getattr(m, "weights", None), getattr(m, "hidden_bias", None), getattr(m, "visible_bias", None)
     if W is None or hb is None or vb is None or W.dtype not in (torch.float64, torch.float32) or not W.is_cuda or W.dim() != 2:
         return None
     # (float32 parameters are handed to the float64 kernel as they are: an exact conversion)
-    return W.detach().double(), hb.detach().reshape(-1).double(), vb.detach().reshape(-1).double()
+    return W.detach().double(), hb.detach().reshape(-1).double(), vb.detach().reshape(-1).double(), kind
 
 
 def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
@@ -339,13 +341,15 @@ def local_energy(
             t1 = time.time_ns()
             return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 
-        # ---- fast path: SIMPLE with a real RBM, amplitude ratios on chip -----------------------------------
-        if (FUSED and FUSED_RBM and not reduce_psi and not use_sample_space and WF_LUT is None and dtype in (torch.double, torch.float32)
-                and x.is_cuda and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0
+        # ---- fast path: SIMPLE with an RBM (real parameters), amplitude ratios on chip ----------------------------
+        if (FUSED and FUSED_RBM and not reduce_psi and not use_sample_space and WF_LUT is None and x.is_cuda
+                and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0
                 and h1e.dtype in (torch.float64, torch.float32)):
             prm = _real_rbm_params(ansatz)
-            if prm is not None and _rbm_lds_ok(sorb, nele, noa, nob, prm[0].size(0)):
-                eloc, psi0 = CX.eloc_rbm(x, *CX.integrals_f64(h1e, h2e), CX.RBMTable(*prm), sorb, nele, noa, nob)
+            # the phase flavour (pRBM) is complex-valued; the others need a real `dtype` like the module itself
+            if (prm is not None and dtype in ((torch.complex128, torch.complex64) if prm[3] == "pRBM" else (torch.double, torch.float32))
+                    and _rbm_lds_ok(sorb, nele, noa, nob, prm[0].size(0))):
+                eloc, psi0 = CX.eloc_rbm(x, *CX.integrals_f64(h1e, h2e), CX.RBMTable(*prm[:3]), sorb, nele, noa, nob, rbm_type=prm[3])
                 t1 = time.time_ns()
                 return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 
@@ -357,16 +361,35 @@ def local_energy(
             ansatz_f = partial(ansatz_batch, func=ansatz)
 
         # ---- fast path: REDUCE (deterministic) with on-chip compaction -----------------------------------
-        if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and not (use_spin_raising or use_multi_psi or use_spin_flip)
-                and sorb % 2 == 0 and x.is_cuda):
+        # (also the spin-flip projected and multi-psi forms, flip.py:200-319: their extra factors are evaluated on the kept records only)
+        if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and not use_spin_raising and sorb % 2 == 0 and x.is_cuda):
             row, col, onv, h, counts = reduce_compact(x, h1e, h2e, sorb, nele, noa, nob, eps)
             t2 = time.time_ns()
-            psi = Func(ansatz_f, onv, WF_LUT, use_unique).to(dtype)
-            # psi(x) = amplitude of the kept column 0 of each row; 0 if it was filtered out (as in the reference)
-            psi_x = torch.zeros(batch, dtype=dtype, device=x.device)
             first = col == 0
-            psi_x[row[first]] = psi[first]
-            w = (psi / psi_x[row]) * h.to(_real_dtype(dtype))
+
+            def at_x(v: Tensor) -> Tensor:
+                """value on the kept column 0 of each row; 0 if it was filtered out (as in the reference)"""
+                out = torch.zeros(batch, dtype=dtype, device=x.device)
+                out[row[first]] = v[first]
+                return out
+
+            psi = Func(ansatz_f, onv, WF_LUT, use_unique).to(dtype)
+            psi_x = at_x(psi)
+            t = psi
+            if use_multi_psi:
+                f = Func(ansatz_extra, onv, None, use_unique).to(dtype)
+                t = f * psi
+            if use_spin_flip:
+                onv_flip = spin_flip_onv(onv, sorb)
+                psi_flip = Func(ansatz_f, onv_flip, WF_LUT, use_unique).to(dtype)
+                if use_multi_psi:
+                    psi_flip = Func(ansatz_extra, onv_flip, None, use_unique).to(dtype) * psi_flip
+                t = t + SpinProjection.eta * spin_flip_sign(onv, sorb) * psi_flip
+            if use_multi_psi:
+                t = t * at_x(f).conj()[row]
+            if use_multi_psi or use_spin_flip:
+                t = t / extra_norm**2
+            w = (t / psi_x[row]) * h.to(_real_dtype(dtype))
             # rows are contiguous segments: a segmented sum instead of index_add_ (atomics: 2.7 of 5.0 ms on Fe2S2)
             if w.is_complex():
                 eloc = torch.view_as_complex(torch.segment_reduce(torch.view_as_real(w).contiguous(), "sum", lengths=counts, unsafe=True))

@@ -37,8 +37,14 @@ class _SkinnyLinear(torch.autograd.Function):
 
 
 class RealRBM(nn.Module):
-    def __init__(self, weights: Tensor, hidden_bias: Tensor, visible_bias: Tensor) -> None:
+    """RBM amplitudes with real parameters, rbm.py:199-211: rbm_type "real" exp(a.x) prod 2cosh(theta), "tanh" tanh(a.x) prod
+    2cosh(theta), "pRBM" exp(i (a.x + sum ln 2cosh(theta))) (complex-valued), "cos" prod cos(theta)."""
+
+    def __init__(self, weights: Tensor, hidden_bias: Tensor, visible_bias: Tensor, rbm_type: str = "real") -> None:
         super().__init__()
+        if rbm_type not in ("real", "tanh", "pRBM", "cos"):
+            raise ValueError(f"rbm_type {rbm_type!r}")
+        self.rbm_type = rbm_type
         self.weights = nn.Parameter(weights.clone())            # [num_hidden, sorb]
         self.hidden_bias = nn.Parameter(hidden_bias.clone())    # [num_hidden]
         self.visible_bias = nn.Parameter(visible_bias.clone())  # [sorb]
@@ -50,9 +56,18 @@ class RealRBM(nn.Module):
         wext = torch.cat([self.weights, self.visible_bias.unsqueeze(0)], 0)
         bext = torch.cat([self.hidden_bias, self.hidden_bias.new_zeros(1)])
         z = _SkinnyLinear.apply(x, wext) + bext
+        if self.rbm_type == "cos":
+            c = z[:, :-1].cos()
+            # prod() without its host-synchronising backward: sign and magnitude separately
+            return (1 - 2 * ((c < 0).sum(-1) % 2)).to(c.dtype) * c.abs().log().sum(-1).exp()
+        lncosh = (2 * z[:, :-1].cosh()).log().sum(-1)
+        if self.rbm_type == "tanh":
+            return z[:, -1].tanh() * lncosh.exp()
+        if self.rbm_type == "pRBM":
+            return torch.exp(1j * (z[:, -1] + lncosh))
         # exp(a.x + sum ln 2cosh theta): the product of rbm.py:205-206 without prod(), whose backward synchronises with the host
         # (it looks for zeros with nonzero()) and therefore cannot be captured in a HIP graph (pynqs_amd.grad.GraphedGrad)
-        return (z[:, -1] + (2 * z[:, :-1].cosh()).log().sum(-1)).exp()
+        return (z[:, -1] + lncosh).exp()
 
 
 class ComplexRBM(nn.Module):

@@ -8,6 +8,7 @@ What is captured (all on the shipped Fe2S2 problem, ci_space[:32], fixed-weight 
   eloc_complex_module.npz       SIMPLE / REDUCE (+ LUT, + spin-flip) with a complex128 module (pynqs_amd.rbm.ComplexRBM as the input amplitude)
   grad_fe2s2.npz                vmc/grad/energy_grad.py:118-184 (`grad`) under DistributedDataParallel, world size 1 and 2 (gloo)
   gfmc_fe2s2.npz                gfmc/walker.py:167-235 (_calculate_green_kernel), :260-279 (sample_update), :340-408 (branching, ws 1 and 2)
+  eloc_rbm_flavours.npz         SIMPLE / REDUCE with RBMWavefunction(rbm_type = "tanh" / "pRBM" / "cos") (vmc/ansatz/rbm/rbm.py:199-211)
   sampler_merge.npz             merge_rank_sample (cpp_src/tensor/cpu_tensor.cpp:537-556) and Sampler.gather_scatter_sample
                                 (vmc/sample.py:627-772) run by two gloo ranks, both `use_same_tree` settings
 Only DATA is written: inputs and the reference's outputs.
@@ -177,6 +178,28 @@ def section_eloc(I, out_dir):
     c["eta"], c["extra_norm"] = eta, float(extra_norm)
     np.savez_compressed(f"{out_dir}/eloc_complex_module.npz", **c)
     print("eloc sections done:", {k: v.shape for k, v in out.items() if k.startswith("eloc_")})
+
+
+# --------------------------------------------------------------------------------------------------------------
+def section_rbm_flavours(I, out_dir):
+    """SIMPLE and REDUCE local energies with the reference's other real-parameter RBM amplitudes (rbm.py:199-211: "tanh", "pRBM",
+    "cos"), same weights as eloc_e2e_fe2s2.npz."""
+    from utils.public_function import ansatz_batch
+    from vmc.ansatz.rbm.rbm import RBMWavefunction
+    from vmc.energy.eloc import local_energy
+
+    sorb, nele, noA, noB = I["sorb"], I["nele"], I["noA"], I["noB"]
+    out = dict(x=I["x"].numpy())
+    for kind in ("tanh", "pRBM", "cos"):
+        dt = torch.complex128 if kind == "pRBM" else torch.double
+        m = RBMWavefunction(sorb, alpha=2, rbm_type=kind)
+        m.init(I["hb"].clone(), I["W"].clone(), I["vb"].clone())
+        ab = lambda x, func: ansatz_batch(func, x, 100000, sorb, torch.device("cpu"), dt)  # noqa: E731
+        for tag, kw in (("simple", {}), ("reduce", dict(reduce_psi=True, eps=1e-2, eps_sample=0))):
+            e, _, p, _ = local_energy(I["x"], I["h1e"], I["h2e"], m, ab, sorb, nele, noA, noB, dtype=dt, **kw)
+            out[f"eloc_{tag}_{kind}"], out[f"psi_{tag}_{kind}"] = e.detach().numpy(), p.detach().numpy()
+    np.savez_compressed(f"{out_dir}/eloc_rbm_flavours.npz", **out)
+    print("rbm flavours:", {k: (v.dtype, float(np.abs(v).max())) for k, v in out.items() if k.startswith("eloc_")})
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -389,6 +412,8 @@ def main():
     only = set(a.only.split(",")) if a.only else {"eloc", "dist"}
     if "eloc" in only:
         section_eloc(I, a.out)
+    if "eloc" in only or "flavours" in only:
+        section_rbm_flavours(I, a.out)
     if "dist" in only:
         branch, samp, stats = section_dist(a.scratch, a.out)
         section_gfmc(I, a.out, branch)

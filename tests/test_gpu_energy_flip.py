@@ -130,6 +130,20 @@ def test_projected_sample_space_runs_fused(env, monkeypatch):
         _check(_le(env, env[key], dt, True, **kw(env)), env["d"], name)
 
 
+def test_projected_reduce_runs_compacted(env, monkeypatch):
+    """REDUCE with use_spin_flip / use_multi_psi / a complex module keeps the on-chip compaction (pynqs_reduce_count / _emit): the
+    extra factors f, psi(flip x'), eta_m are evaluated on the kept records, nothing of size batch x ncomb is materialised."""
+    energy = env["energy"]
+
+    def boom(*a, **k):
+        raise AssertionError("get_comb_hij_fused called: the projected REDUCE form fell back to the materialising path")
+
+    monkeypatch.setattr(energy, "get_comb_hij_fused", boom)
+    for name in ("reduce_flip", "reduce_flip_lut", "reduce_multi", "reduce_flip_multi"):
+        key, dt, kw = CASES[name]
+        _check(_le(env, env[key], dt, True, **kw(env)), env["d"], name)
+
+
 @pytest.mark.parametrize("sorb,no,nkeys,use_hash", [(40, 5, 300, True), (72, 6, 200, True), (136, 4, 3000, True), (136, 4, 5000, True),
                                                     (72, 6, 300, False), (40, 5, 300_000, True)])
 def test_spin_flip_kernel_all_filter_levels(sorb, no, nkeys, use_hash):

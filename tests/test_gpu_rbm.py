@@ -132,6 +132,97 @@ def test_windowed_kernel_against_oracle(cx, sorb, noA, noB, H, n):
     np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
 
 
+@pytest.mark.parametrize("kind", ["tanh", "pRBM"])
+def test_flavours_match_reference_python(cx, fe2s2, kind):
+    """rbm_type "tanh" / "pRBM" (rbm.py:199-211) on the fused kernel (pynqs_eloc_rbm_flavour) against the reference's own
+    local_energy with RBMWavefunction(rbm_type=kind) (tests/golden/eloc_rbm_flavours.npz), the few-walker (atomics) path, and through
+    pynqs_amd.energy.local_energy: fused and module path, SIMPLE and REDUCE."""
+    from pynqs_amd import energy, public_function as pf
+    from pynqs_amd.rbm import RealRBM
+
+    d0, d = golden("eloc_e2e_fe2s2.npz"), golden("eloc_rbm_flavours.npz")
+    tab = cx.RBMTable(_dev(d0["W"]), _dev(d0["hb"]), _dev(d0["vb"]))
+    h1e, h2e, x = _dev(fe2s2["h1e"]), _dev(fe2s2["h2e"]), _dev(d["x"])
+    dt = torch.complex128 if kind == "pRBM" else torch.float64
+    e, p = cx.eloc_rbm(x, h1e, h2e, tab, 40, 30, 15, 15, rbm_type=kind)
+    assert e.dtype == dt and p.dtype == dt
+    np.testing.assert_allclose(e.cpu().numpy(), d[f"eloc_simple_{kind}"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(p.cpu().numpy(), d[f"psi_simple_{kind}"], rtol=1e-11)
+    e3, _ = cx.eloc_rbm(x[:3].contiguous(), h1e, h2e, tab, 40, 30, 15, 15, want_psi=False, rbm_type=kind)
+    np.testing.assert_allclose(e3.cpu().numpy(), d[f"eloc_simple_{kind}"][:3], rtol=0, atol=TOL)
+    with pytest.raises(RuntimeError):
+        cx.eloc_rbm(x, h1e, h2e, tab, 40, 30, 15, 15, rbm_type="cos")
+    # the energy layer picks the kernel from the module's rbm_type
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        m = RealRBM(_dev(d0["W"]), _dev(d0["hb"]), _dev(d0["vb"]), rbm_type=kind).cuda()
+        ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, 40, x.device, dt)  # noqa: E731
+        for fused in (True, False):
+            energy.FUSED_RBM = fused
+            el, _, ps, _ = energy.local_energy(x, h1e, h2e, m, ab, 40, 30, 15, 15, dtype=dt)
+            np.testing.assert_allclose(el.cpu().numpy(), d[f"eloc_simple_{kind}"], rtol=0, atol=TOL)
+            np.testing.assert_allclose(ps.cpu().numpy(), d[f"psi_simple_{kind}"], rtol=1e-11)
+        el, _, ps, _ = energy.local_energy(x, h1e, h2e, m, ab, 40, 30, 15, 15, dtype=dt, reduce_psi=True, eps=1e-2, eps_sample=0)
+        np.testing.assert_allclose(el.cpu().numpy(), d[f"eloc_reduce_{kind}"], rtol=0, atol=TOL)
+    finally:
+        energy.FUSED_RBM = True
+        torch.set_default_dtype(old)
+
+
+def test_cos_flavour_takes_the_module_path(cx, fe2s2):
+    """rbm_type "cos" has no fused kernel (complex running products): pynqs_amd.rbm.RealRBM("cos") through the generic path against
+    the reference's RBMWavefunction(rbm_type="cos")."""
+    from pynqs_amd import energy, public_function as pf
+    from pynqs_amd.rbm import RealRBM
+
+    d0, d = golden("eloc_e2e_fe2s2.npz"), golden("eloc_rbm_flavours.npz")
+    h1e, h2e, x = _dev(fe2s2["h1e"]), _dev(fe2s2["h2e"]), _dev(d["x"])
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        m = RealRBM(_dev(d0["W"]), _dev(d0["hb"]), _dev(d0["vb"]), rbm_type="cos").cuda()
+        ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, 40, x.device, torch.double)  # noqa: E731
+        for tag, kw in (("simple", {}), ("reduce", dict(reduce_psi=True, eps=1e-2, eps_sample=0))):
+            el, _, ps, _ = energy.local_energy(x, h1e, h2e, m, ab, 40, 30, 15, 15, **kw)
+            np.testing.assert_allclose(el.cpu().numpy(), d[f"eloc_{tag}_cos"], rtol=0, atol=TOL)
+            np.testing.assert_allclose(ps.cpu().numpy(), d[f"psi_{tag}_cos"], rtol=1e-11)
+    finally:
+        torch.set_default_dtype(old)
+
+
+@pytest.mark.parametrize("sorb,noA,noB,H,n,kind", [(12, 3, 2, 24, 40, "tanh"), (66, 3, 4, 70, 7, "pRBM"), (130, 3, 2, 64, 4, "tanh"),
+                                                   (128, 3, 2, 400, 5, "pRBM"), (66, 5, 5, 700, 4, "tanh")])
+def test_flavours_random_systems(cx, sorb, noA, noB, H, n, kind):
+    """tanh / phase flavours on 1-3 ONV words, resident and windowed kernels, against numpy on the oracle's comb / Hmat
+    (log-domain amplitudes, the formulas of rbm.py:199-211)."""
+    from oracle import oracle
+
+    h1, h2 = synth_integrals(sorb)
+    occ = rand_occ(n, sorb, noA, noB, seed=sorb + H)
+    bra_cpu = oracle.pm01_to_onv(occ, sorb)
+    g = np.random.default_rng(sorb * 11 + H)
+    W = 0.05 * (g.random((H, sorb)) - 0.5)
+    hb = 2.0 * (g.random(H) - 0.5)
+    vb = 0.2 * (g.random(sorb) - 0.5)
+    comb, hm = oracle.comb_hij_fused(bra_cpu, h1, h2, sorb, noA + noB, noA, noB)
+    xs = oracle.onv_to_pm1(comb.reshape(-1, comb.shape[-1]), sorb)
+    th = xs @ W.T + hb
+    lncosh = (np.abs(th) + np.log1p(np.exp(-2.0 * np.abs(th)))).sum(1).reshape(n, -1)
+    ax = (xs @ vb).reshape(n, -1)
+    if kind == "tanh":
+        ratio = np.tanh(ax) / np.tanh(ax[:, :1]) * np.exp(lncosh - lncosh[:, :1])
+    else:
+        ratio = np.exp(1j * ((ax + lncosh) - (ax + lncosh)[:, :1]))
+    e_ref = (hm * ratio).sum(1)
+    tab = cx.RBMTable(_dev(W), _dev(hb), _dev(vb))
+    e, p = cx.eloc_rbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB, rbm_type=kind)
+    scale = max(1.0, float(np.abs(hm).sum(1).max()))
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
+    if kind == "pRBM":
+        np.testing.assert_allclose(p.cpu().numpy(), np.exp(1j * (ax + lncosh)[:, 0]), rtol=0, atol=1e-9)
+
+
 def test_end_to_end_vmc_lowers_the_energy():
     """examples/vmc_rbm_exact_sampling.py: fused E_loc -> statistics kernel -> gradient -> Adam on a sorb-8 problem
     with exact sampling: the variational energy must go down and stay above the exact ground state."""
