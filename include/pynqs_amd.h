@@ -196,6 +196,19 @@ int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int sorb, int ne
 int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const double *rand_num, const uint64_t *comb,
                       int sorb, int64_t *index, double *beta, uint64_t *x_new, void *stream);
 
+/* ---- the whole Green's-function row of gfmc/walker.py:167-235 (_calculate_green_kernel) in ONE kernel for a trial function
+ * that is an RBM with real parameters (flavour PYNQS_RBM_REAL or PYNQS_RBM_TANH; the complex-valued phase flavour has no fixed node):
+ *   r_k = psi(x'_k)/psi(x), h_k = <x|H|x'_k>;  for k >= 1: green[k] = -h_k r_k if h_k r_k < 0 (sign-preserving move) else 0;
+ *   v_sf = sum of the other h_k r_k (sign-flip potential);  green[0] = max(0, lambda - h_0 - v_sf), clamped[x] = 1 if that was < 0;
+ *   eloc[x] = sum_k h_k r_k (unchanged by the fixed-node construction), psi (may be NULL) = psi(x).
+ * green double[nbatch][ncomb] in the reference's column order; neither comb nor the amplitude batch is materialised.
+ *   pynqs_gfmc_sample_rank : pynqs_gfmc_sample for such a row: x_new = the excitation of rank index - 1 of bra[x] (index 0: bra[x]). */
+int pynqs_green_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                    const void *rbm_table, int nhidden, int flavour, double lambda, double *eloc, double *psi, double *green,
+                    uint8_t *clamped, void *stream);
+int pynqs_gfmc_sample_rank(const double *green, int64_t n, const double *rand_num, const uint64_t *bra, int sorb, int nele,
+                           int noA, int noB, int64_t *index, double *beta, uint64_t *x_new, void *stream);
+
 /* ---- statistics: utils/stats/dist_stats.py:18-79 needs sum p O, sum p |O|^2 (and sum p) before its all-reduce -----
  *   pynqs_moments_workspace : [host] bytes of the workspace (device memory, ZERO it once before the first call)
  *   pynqs_weighted_moments  : workspace[0..3] (doubles) = sum_i p_i Re x_i, sum_i p_i Im x_i, sum_i p_i |x_i|^2,

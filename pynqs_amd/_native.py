@@ -50,6 +50,8 @@ SIGNATURES = {
     "pynqs_eloc_rbm": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp]),
     "pynqs_eloc_rbm_flavour": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "pynqs_gfmc_sample": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "pynqs_green_rbm": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _int, _dbl, _vp, _vp, _vp, _vp, _vp]),
+    "pynqs_gfmc_sample_rank": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "pynqs_moments_workspace": (_i64, []),
     "pynqs_stats_finish": (_int, [_vp, _dbl, _dbl, _vp, _vp]),
     "pynqs_weighted_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp]),

@@ -416,6 +416,57 @@ __device__ __forceinline__ void pair_unrank(int q, int &hi, int &lo) {
   lo = q - i * (i - 1) / 2;
 }
 
+// x -> the rank-r single / double excitation of x (excitation.cpp:43-109 incl. the global `idx % noAA` modulo), without LDS tables:
+// for kernels that need ONE excitation per walker (spin_flip_rand, the GFMC move from a column index).
+template <int LEN>
+__device__ __forceinline__ void excite_by_rank(uint64_t (&x)[LEN], uint32_t r, const SDParams &p) {
+  // (slot indices) -> orbitals: slot 2k (+1) = k-th alpha (beta) orbital of [occupied ascending | virtual ascending]
+  auto orbital_of_slot = [&](int slot) -> int {
+    const int beta = slot & 1;
+    int k = slot >> 1;
+    const uint64_t spin = beta ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+    int nocc = 0;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) nocc += __popcll(x[i] & spin);
+    const bool want_occ = k < nocc;
+    if (!want_occ) k -= nocc;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) {
+      uint64_t bits = (want_occ ? x[i] : ~x[i]) & spin;
+      if (i == LEN - 1 && (p.sorb & 63)) bits &= (1ull << (p.sorb & 63)) - 1ull;
+      const int c = __popcll(bits);
+      if (k < c) {
+        for (int t = 0; t < k; ++t) bits &= bits - 1;
+        return i * 64 + __builtin_ctzll(bits);
+      }
+      k -= c;
+    }
+    return 0;
+  };
+  int si, sa, sj = -1, sb = -1;
+  if (r < p.d0) { si = 2 * (int)(r % p.noA); sa = 2 * (int)(r / p.noA + p.noA); }
+  else if (r < p.d1) { const uint32_t t = r - p.d0; si = 2 * (int)(t % p.noB) + 1; sa = 2 * (int)(t / p.noB + p.noB) + 1; }
+  else if (r < p.d3) {
+    const bool beta = r >= p.d2;
+    const uint32_t t = r - (beta ? p.d2 : p.d1);
+    const int npair = beta ? p.noBB : p.noAA, no = beta ? p.noB : p.noA;
+    int h1, h0, v1, v0;
+    pair_unrank((int)(r % npair), h1, h0);  // global rank modulo: excitation.cpp:63,79
+    pair_unrank((int)(t / npair), v1, v0);
+    si = 2 * h1 + beta; sj = 2 * h0 + beta; sa = 2 * (v1 + no) + beta; sb = 2 * (v0 + no) + beta;
+  } else {
+    const uint32_t t = r - p.d3;
+    const uint32_t ia = t % p.nSa, jb = t / p.nSa;
+    si = 2 * (int)(ia % p.noA); sa = 2 * (int)(ia / p.noA + p.noA);
+    sj = 2 * (int)(jb % p.noB) + 1; sb = 2 * (int)(jb / p.noB + p.noB) + 1;
+  }
+  const int oi = orbital_of_slot(si), oa = orbital_of_slot(sa);
+  int oj = 0, ob = 0;
+  if (sj >= 0) { oj = orbital_of_slot(sj); ob = orbital_of_slot(sb); }
+  toggle<LEN>(x, oi); toggle<LEN>(x, oa);
+  if (sj >= 0) { toggle<LEN>(x, oj); toggle<LEN>(x, ob); }
+}
+
 // Builds merged / occv / tables for the workgroup's walker.  All threads of the block must call it;
 // ends with a barrier.  Returns the walker's electron count (length of occv).
 template <int LEN>

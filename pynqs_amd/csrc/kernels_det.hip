@@ -407,54 +407,7 @@ __global__ __launch_bounds__(kBlock) void spin_flip_rand_kernel(const uint64_t *
   // unbiased integer in [0, nsd]: 64-bit multiply-high of a 64-bit hash (bias < 2^-40 for nsd < 2^24)
   const uint64_t h = mix64(mix64(seed) ^ mix64(offset + w));
   const uint32_t r0 = (uint32_t)__umul64hi(h, (uint64_t)p.nsd + 1);
-  if (r0 != 0) {
-    const uint32_t r = r0 - 1;
-    // (slot indices) -> orbitals: slot 2k (+1) = k-th alpha (beta) orbital of [occupied ascending | virtual ascending]
-    auto orbital_of_slot = [&](int slot) -> int {
-      const int beta = slot & 1;
-      int k = slot >> 1;
-      const uint64_t spin = beta ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
-      int nocc = 0;
-#pragma unroll
-      for (int i = 0; i < LEN; ++i) nocc += __popcll(x[i] & spin);
-      const bool want_occ = k < nocc;
-      if (!want_occ) k -= nocc;
-#pragma unroll
-      for (int i = 0; i < LEN; ++i) {
-        uint64_t bits = (want_occ ? x[i] : ~x[i]) & spin;
-        if (i == LEN - 1 && (p.sorb & 63)) bits &= (1ull << (p.sorb & 63)) - 1ull;
-        const int c = __popcll(bits);
-        if (k < c) {
-          for (int t = 0; t < k; ++t) bits &= bits - 1;
-          return i * 64 + __builtin_ctzll(bits);
-        }
-        k -= c;
-      }
-      return 0;
-    };
-    int si, sa, sj = -1, sb = -1;
-    if (r < p.d0) { si = 2 * (int)(r % p.noA); sa = 2 * (int)(r / p.noA + p.noA); }
-    else if (r < p.d1) { const uint32_t t = r - p.d0; si = 2 * (int)(t % p.noB) + 1; sa = 2 * (int)(t / p.noB + p.noB) + 1; }
-    else if (r < p.d3) {
-      const bool beta = r >= p.d2;
-      const uint32_t t = r - (beta ? p.d2 : p.d1);
-      const int npair = beta ? p.noBB : p.noAA, no = beta ? p.noB : p.noA;
-      int h1, h0, v1, v0;
-      pair_unrank((int)(r % npair), h1, h0);  // global rank modulo: excitation.cpp:63,79
-      pair_unrank((int)(t / npair), v1, v0);
-      si = 2 * h1 + beta; sj = 2 * h0 + beta; sa = 2 * (v1 + no) + beta; sb = 2 * (v0 + no) + beta;
-    } else {
-      const uint32_t t = r - p.d3;
-      const uint32_t ia = t % p.nSa, jb = t / p.nSa;
-      si = 2 * (int)(ia % p.noA); sa = 2 * (int)(ia / p.noA + p.noA);
-      sj = 2 * (int)(jb % p.noB) + 1; sb = 2 * (int)(jb / p.noB + p.noB) + 1;
-    }
-    const int oi = orbital_of_slot(si), oa = orbital_of_slot(sa);
-    int oj = 0, ob = 0;
-    if (sj >= 0) { oj = orbital_of_slot(sj); ob = orbital_of_slot(sb); }
-    toggle<LEN>(x, oi); toggle<LEN>(x, oa);
-    if (sj >= 0) { toggle<LEN>(x, oj); toggle<LEN>(x, ob); }
-  }
+  if (r0 != 0) excite_by_rank<LEN>(x, r0 - 1, p);
 #pragma unroll
   for (int i = 0; i < LEN; ++i) out[w * LEN + i] = x[i];
 }

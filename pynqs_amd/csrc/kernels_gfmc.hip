@@ -23,9 +23,11 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
   return v;
 }
 
-template <int LEN>
+// FROM_RANK: there is no comb array (the row came from the fused Green's-function kernel, pynqs_green_rbm): `comb` then holds the
+// n walkers themselves and x_new is the excitation of rank index - 1 of the walker (column 0 = the walker).
+template <int LEN, bool FROM_RANK>
 __global__ __launch_bounds__(kBlock) void gfmc_sample_kernel(const double *__restrict__ gk, int64_t m, uint32_t tile, uint32_t ntiles,
-                                                             const double *__restrict__ rnd, const uint64_t *__restrict__ comb,
+                                                             const double *__restrict__ rnd, const uint64_t *__restrict__ comb, SDParams p,
                                                              int64_t *__restrict__ index, double *__restrict__ beta,
                                                              uint64_t *__restrict__ x_new) {
   __shared__ double tsum[kGfmcMaxTiles];
@@ -100,7 +102,18 @@ __global__ __launch_bounds__(kBlock) void gfmc_sample_kernel(const double *__res
     // weight (never a zero-weight column, which the reference's searchsorted cannot return either)
     if (found < 0) found = last_pos >= 0 ? last_pos : c1 - 1;
     if (lane == 0) index[walker] = found;
-    if (lane < LEN) x_new[walker * LEN + lane] = comb[(walker * m + found) * LEN + lane];
+    if constexpr (FROM_RANK) {
+      if (lane == 0) {
+        uint64_t x[LEN];
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) x[i] = comb[walker * LEN + i];
+        if (found > 0) excite_by_rank<LEN>(x, (uint32_t)(found - 1), p);
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) x_new[walker * LEN + i] = x[i];
+      }
+    } else {
+      if (lane < LEN) x_new[walker * LEN + lane] = comb[(walker * m + found) * LEN + lane];
+    }
   }
 }
 
@@ -108,8 +121,9 @@ __global__ __launch_bounds__(kBlock) void gfmc_sample_kernel(const double *__res
 
 using namespace pynqs;
 
-extern "C" int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const double *rand_num, const uint64_t *comb, int sorb,
-                                 int64_t *index, double *beta, uint64_t *x_new, void *stream) {
+template <bool FROM_RANK>
+static int gfmc_sample_impl(const double *green, int64_t n, int64_t ncomb, const double *rand_num, const uint64_t *comb, int sorb,
+                            const SDParams &p, int64_t *index, double *beta, uint64_t *x_new, void *stream) {
   pynqs::DeviceScope device_scope_(green);
   if (n < 0 || ncomb < 1 || sorb < 1 || sorb > kMaxSorb) return set_error(PYNQS_EINVAL, "bad n / ncomb / sorb");
   if (n == 0) return PYNQS_OK;
@@ -121,9 +135,22 @@ extern "C" int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, 
   const uint32_t ntiles = (uint32_t)((ncomb + tile - 1) / tile);
   const int len = (sorb - 1) / 64 + 1;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_LEN(len, hipLaunchKernelGGL((gfmc_sample_kernel<LEN>), dim3((uint32_t)n), dim3(kBlock), 0, st, green, ncomb, tile, ntiles,
-                                       rand_num, comb, index, beta, x_new));
+  DISPATCH_LEN(len, hipLaunchKernelGGL((gfmc_sample_kernel<LEN, FROM_RANK>), dim3((uint32_t)n), dim3(kBlock), 0, st, green, ncomb, tile, ntiles,
+                                       rand_num, comb, p, index, beta, x_new));
   return check_launch("gfmc_sample");
+}
+
+extern "C" int pynqs_gfmc_sample(const double *green, int64_t n, int64_t ncomb, const double *rand_num, const uint64_t *comb, int sorb,
+                                 int64_t *index, double *beta, uint64_t *x_new, void *stream) {
+  SDParams p = {};
+  return gfmc_sample_impl<false>(green, n, ncomb, rand_num, comb, sorb, p, index, beta, x_new, stream);
+}
+
+extern "C" int pynqs_gfmc_sample_rank(const double *green, int64_t n, const double *rand_num, const uint64_t *bra, int sorb, int nele,
+                                      int noA, int noB, int64_t *index, double *beta, uint64_t *x_new, void *stream) {
+  SDParams p;
+  if (!make_sd_params(sorb, nele, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
+  return gfmc_sample_impl<true>(green, n, (int64_t)p.nsd + 1, rand_num, bra, sorb, p, index, beta, x_new, stream);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -28,6 +28,12 @@
 //   kRbmPhase psi = exp(i (a.x + sum_h ln 2cosh(theta_h)))     -- "pRBM": the phase difference of x' and x IS the logarithm of the
 //             real flavour's ratio, so psi(x')/psi(x) = exp(i ln t) with t from the same running products; E_loc is complex
 // ("cos" and "complex" need complex running products: they take the module path.)
+//
+// GREEN: the fixed-node Green's-function row of a GFMC step (gfmc/walker.py:167-235, _calculate_green_kernel) from the same
+// pass, for the real-valued flavours: with r_k = psi(x'_k)/psi(x) and h_k = <x|H|x'_k>, a move k >= 1 keeps the sign when
+// h_k r_k < 0 (the reference's cos(phase difference + gamma) < 0) and then has weight g_k = -h_k r_k; the others add to the
+// sign-flip potential v_sf = sum h_k r_k on the diagonal: g_0 = max(0, Lambda - h_0 - v_sf).  The row is written in the
+// reference's column order (column = 1 + rank, excitation.cpp:43-109 incl. the `idx % noAA` rotation); E_loc is unchanged.
 #include "detcore.h"
 #include "launch.h"
 #include "plan.h"
@@ -112,11 +118,13 @@ __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o 
 //                   windows (two barriers per window).
 enum : int { kRbmReal = 0, kRbmTanh = 1, kRbmPhase = 2 };
 
-template <int LEN, bool WINDOWED, int FLAVOUR>
+template <int LEN, bool WINDOWED, int FLAVOUR, bool GREEN>
 __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
                                                           RbmBlocks B, uint32_t nchunks, uint32_t hw, const double *__restrict__ plan,
                                                           const double *__restrict__ rbm, double *__restrict__ eloc,
-                                                          double *__restrict__ psi) {
+                                                          double *__restrict__ psi, double lambda, double *__restrict__ green,
+                                                          uint8_t *__restrict__ clamped) {
+  static_assert(!GREEN || FLAVOUR != kRbmPhase, "the fixed-node row needs a real-valued amplitude");
   // no static __shared__ here: with the dynamic region at LDS address 0 the row offsets below are the addresses and
   // the ds_read immediates carry the rest (a static in front costs one v_add per read)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -316,15 +324,21 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
   const double *__restrict__ Vab = plan + pl.offVab;
   const uint32_t my_tiles = B.ntiles > chunk ? (B.ntiles - chunk + nchunks - 1) / nchunks : 0;
   const uint32_t nrounds = (my_tiles + nwaves - 1) / nwaves;  // WINDOWED only
-  double esum = 0.0, esum_im = 0.0;
+  double esum = 0.0, esum_im = 0.0;  // GREEN: esum_im collects the sign-flip potential
+  double *__restrict__ grow = GREEN ? green + (size_t)walker * (p.nsd + 1) : nullptr;
   // one column's contribution: h = <x|H|x'>, t = the real flavour's psi(x')/psi(x) (for tanh: without the visible factor),
-  // da = exp(2 (a.x' - a.x))
-  auto add_column = [&](double h, double t, double da) {
-    if constexpr (FLAVOUR == kRbmReal) {
-      esum += h * t;
-    } else if constexpr (FLAVOUR == kRbmTanh) {
-      const double th = 1.0 - 2.0 / fma(e2ax, da, 1.0);  // tanh(a.x'); exp(2 a.x') = inf -> 1, 0 -> -1
-      esum += h * (t * (th * inv_tanh_ax));
+  // da = exp(2 (a.x' - a.x)), col = the reference's column of x' (GREEN)
+  auto add_column = [&](double h, double t, double da, uint32_t col) {
+    if constexpr (FLAVOUR == kRbmReal || FLAVOUR == kRbmTanh) {
+      double r = t;
+      if constexpr (FLAVOUR == kRbmTanh) r = t * ((1.0 - 2.0 / fma(e2ax, da, 1.0)) * inv_tanh_ax);  // tanh(a.x'): exp(2 a.x') = inf -> 1, 0 -> -1
+      const double hr = h * r;
+      esum += hr;
+      if constexpr (GREEN) {
+        const bool keeps_sign = (r < 0.0) != (h < 0.0);
+        grow[col] = keeps_sign ? -hr : 0.0;
+        esum_im += keeps_sign ? 0.0 : hr;
+      }
     } else {
       double sn, cs;
       sincos(log(t), &sn, &cs);
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t f = 4 * bf + i;
-          if (f < nF) add_column(R.hs[1 + f], acc[4 * i] * cf[i], af[i]);
+          if (f < nF) add_column(R.hs[1 + f], acc[4 * i] * cf[i], af[i], 1u + f);
         }
       } else {
         const bool opp = cls == 3;
@@ -450,6 +464,9 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) hv[4 * i + j] = V[((es[j] >> 17) & mask) * mul + ((ef[i] >> 17) & mask)];
+        // GREEN: column of (fast f, slow s) = 1 + class base + s * nF + u, u = f - rot (mod nF) for the same-spin classes
+        const uint32_t cbase = 1u + (cls == 1 ? p.d1 : (cls == 2 ? p.d2 : p.d3));
+        const uint32_t rot = cls == 1 ? (uint32_t)p.rotA : (cls == 2 ? (uint32_t)p.rotB : 0u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int a0 = ef[i] & 0xff, a1 = (ef[i] >> 8) & 0xff;
@@ -461,7 +478,12 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
             else par ^= (uint32_t)(a0 < b0) ^ (uint32_t)(a1 < b0) ^ (uint32_t)(a0 < b1) ^ (uint32_t)(a1 < b1);
             const bool ok = 4 * bf + i < nF && 4 * bs + j < nS;
             const double t = (acc[4 * i + j] * cf[i]) * cs[j];
-            if (ok) add_column(par ? -hv[4 * i + j] : hv[4 * i + j], t, af[i] * as[j]);
+            uint32_t col = 0;
+            if constexpr (GREEN) {
+              const uint32_t f = 4 * bf + i;
+              col = cbase + (4 * bs + j) * nF + (f >= rot ? f - rot : f + nF - rot);
+            }
+            if (ok) add_column(par ? -hv[4 * i + j] : hv[4 * i + j], t, af[i] * as[j], col);
           }
         }
       }
@@ -474,7 +496,7 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
   for (int o = 32; o > 0; o >>= 1) {
     esum += __shfl_xor(esum, o);
     lnpsi += __shfl_xor(lnpsi, o);
-    if constexpr (FLAVOUR == kRbmPhase) esum_im += __shfl_xor(esum_im, o);
+    if constexpr (FLAVOUR == kRbmPhase || GREEN) esum_im += __shfl_xor(esum_im, o);
   }
   auto over_waves = [&](double v) {  // workgroup-uniform calls; the sum is valid in thread 0
     __syncthreads();
@@ -489,6 +511,14 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
   if (tid == 0) {
     if (nchunks == 1) eloc[kOut * walker] = e_re;
     else atomicAdd(eloc + kOut * walker, e_re);
+  }
+  if constexpr (GREEN) {  // (launched with one workgroup per walker)
+    const double v_sf = over_waves(esum_im);
+    if (tid == 0) {
+      const double k0 = lambda - (R.hs[0] + v_sf);
+      grow[0] = k0 < 0.0 ? 0.0 : k0;
+      clamped[walker] = k0 < 0.0 ? 1 : 0;
+    }
   }
   if constexpr (FLAVOUR == kRbmPhase) {
     const double e_im = over_waves(esum_im);
@@ -570,10 +600,12 @@ extern "C" int pynqs_rbm_table_build(const double *weights, const double *hidden
   return check_launch("rbm_table_build");
 }
 
-extern "C" int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
-                                      const void *rbm_table, int nhidden, int flavour, double *eloc, double *psi, void *stream) {
+static int eloc_rbm_impl(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                         const void *rbm_table, int nhidden, int flavour, double *eloc, double *psi, double lambda, double *green,
+                         uint8_t *clamped, void *stream) {
   pynqs::DeviceScope device_scope_(bra);
   if (flavour < PYNQS_RBM_REAL || flavour > PYNQS_RBM_PHASE) return set_error(PYNQS_EINVAL, "unknown RBM flavour");
+  if (green && (flavour == PYNQS_RBM_PHASE || !clamped)) return set_error(PYNQS_EINVAL, "the Green's-function row needs a real-valued flavour");
   SDParams p;
   PlanLayout pl;
   RbmLayout rl;
@@ -586,7 +618,7 @@ extern "C" int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int s
   const RbmBlocks B = make_rbm_blocks(p);
   // few walkers: cut a walker's tiles over several workgroups (each repeats the per-walker set-up)
   uint32_t nchunks = 1;
-  if (nbatch < 1024) {
+  if (nbatch < 1024 && !green) {  // (the Green's-function row finishes its diagonal in the kernel: one workgroup per walker)
     nchunks = (uint32_t)((1024 + nbatch - 1) / nbatch);
     const uint32_t maxc = B.ntiles / 4 > 0 ? B.ntiles / 4 : 1;
     if (nchunks > maxc) nchunks = maxc;
@@ -620,19 +652,21 @@ extern "C" int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int s
     }
     if (blk_env == 256 || blk_env == 512 || blk_env == 1024) threads = (uint32_t)blk_env;
   }
-#define PYNQS_RBM_LAUNCH(W, F)                                                                                                     \
-  do {                                                                                                                             \
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN, W, F>),                       \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)               \
-      return check_launch("hipFuncSetAttribute");                                                                                  \
-    hipLaunchKernelGGL((eloc_rbm_kernel<LEN, W, F>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, rl, B, nchunks, hw, \
-                       (const double *)plan, (const double *)rbm_table, eloc, psi);                                               \
+#define PYNQS_RBM_LAUNCH(W, F, G)                                                                                                     \
+  do {                                                                                                                                \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_rbm_kernel<LEN, W, F, G>),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                  \
+      return check_launch("hipFuncSetAttribute");                                                                                     \
+    hipLaunchKernelGGL((eloc_rbm_kernel<LEN, W, F, G>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, rl, B, nchunks, hw, \
+                       (const double *)plan, (const double *)rbm_table, eloc, psi, lambda, green, clamped);                          \
   } while (0)
-#define PYNQS_RBM_FLAVOURS(W)                                      \
-  do {                                                             \
-    if (flavour == PYNQS_RBM_REAL) PYNQS_RBM_LAUNCH(W, kRbmReal);  \
-    else if (flavour == PYNQS_RBM_TANH) PYNQS_RBM_LAUNCH(W, kRbmTanh); \
-    else PYNQS_RBM_LAUNCH(W, kRbmPhase);                           \
+#define PYNQS_RBM_FLAVOURS(W)                                                \
+  do {                                                                       \
+    if (green && flavour == PYNQS_RBM_REAL) PYNQS_RBM_LAUNCH(W, kRbmReal, true);  \
+    else if (green) PYNQS_RBM_LAUNCH(W, kRbmTanh, true);                     \
+    else if (flavour == PYNQS_RBM_REAL) PYNQS_RBM_LAUNCH(W, kRbmReal, false); \
+    else if (flavour == PYNQS_RBM_TANH) PYNQS_RBM_LAUNCH(W, kRbmTanh, false); \
+    else PYNQS_RBM_LAUNCH(W, kRbmPhase, false);                              \
   } while (0)
   DISPATCH_LEN(len, {
     if (windowed) PYNQS_RBM_FLAVOURS(true);
@@ -643,7 +677,19 @@ extern "C" int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int s
   return check_launch("eloc_rbm");
 }
 
+extern "C" int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                                      const void *rbm_table, int nhidden, int flavour, double *eloc, double *psi, void *stream) {
+  return eloc_rbm_impl(bra, nbatch, sorb, nele, noA, noB, plan, rbm_table, nhidden, flavour, eloc, psi, 0.0, nullptr, nullptr, stream);
+}
+
 extern "C" int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                               const void *rbm_table, int nhidden, double *eloc, double *psi, void *stream) {
-  return pynqs_eloc_rbm_flavour(bra, nbatch, sorb, nele, noA, noB, plan, rbm_table, nhidden, PYNQS_RBM_REAL, eloc, psi, stream);
+  return eloc_rbm_impl(bra, nbatch, sorb, nele, noA, noB, plan, rbm_table, nhidden, PYNQS_RBM_REAL, eloc, psi, 0.0, nullptr, nullptr, stream);
+}
+
+extern "C" int pynqs_green_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                               const void *rbm_table, int nhidden, int flavour, double lambda, double *eloc, double *psi, double *green,
+                               uint8_t *clamped, void *stream) {
+  if (!green || !clamped) return set_error(PYNQS_EINVAL, "null pointer");
+  return eloc_rbm_impl(bra, nbatch, sorb, nele, noA, noB, plan, rbm_table, nhidden, flavour, eloc, psi, lambda, green, clamped, stream);
 }

@@ -13,10 +13,27 @@ from typing import Callable, Optional, Tuple
 import torch
 from torch import Tensor
 
+from . import C_extension as CX
+from . import _native as N
 from .C_extension import get_comb_hij_fused
 from .distributed import all_gather_varlen, get_rank, get_world_size
-from .energy import Func
-from .public_function import WavefunctionLUT
+from .energy import Func, _rbm_lds_ok, _real_rbm_params
+from .public_function import WavefunctionLUT, get_Num_SinglesDoubles
+
+FUSED_GREEN = True  # trial function = RBM with real parameters ("real" / "tanh"): the whole row in one kernel (pynqs_green_rbm)
+
+
+class CombRows:
+    """What green_kernel returns in place of comb_x when the row came from the fused kernel: the S+D list of every walker is
+    NOT materialised; sample_update turns the chosen column into x' by its rank (pynqs_gfmc_sample_rank).  materialize() gives
+    the [n, ncomb, 8 * len] tensor of the reference for callers that want it."""
+
+    def __init__(self, x: Tensor, sorb: int, nele: int, noa: int, nob: int) -> None:
+        self.x, self.sorb, self.nele, self.noa, self.nob = x, sorb, nele, noa, nob
+        self.shape = (x.size(0), get_Num_SinglesDoubles(sorb, noa, nob) + 1, x.size(1))
+
+    def materialize(self) -> Tensor:
+        return CX.get_comb_tensor(self.x, self.sorb, self.nele, self.noa, self.nob, False)[0]
 
 
 def green_kernel(x: Tensor, Lambda: float, h1e: Tensor, h2e: Tensor, ansatz, ansatz_batch: Callable[..., Tensor], sorb: int,
@@ -28,6 +45,22 @@ def green_kernel(x: Tensor, Lambda: float, h1e: Tensor, h2e: Tensor, ansatz, ans
         assert x.dim() == 2
         batch = x.shape[0]
         device = h1e.device
+        prm = _real_rbm_params(ansatz) if (FUSED_GREEN and WF_LUT is None and dtype == torch.double and x.is_cuda and sorb % 2 == 0
+                                           and h1e.dtype in (torch.float64, torch.float32)) else None
+        if prm is not None and prm[3] in ("real", "tanh") and _rbm_lds_ok(sorb, nele, noa, nob, prm[0].size(0)):
+            # enumeration, matrix elements, amplitude ratios, fixed-node construction and E_loc in one kernel
+            plan = CX.plan_for(*CX.integrals_f64(h1e, h2e), sorb, x.device)
+            table = CX.RBMTable(*prm[:3])
+            xc = x.contiguous()
+            rows = CombRows(xc, sorb, nele, noa, nob)
+            eloc = torch.empty(batch, dtype=torch.float64, device=x.device)
+            gk = torch.empty((batch, rows.shape[1]), dtype=torch.float64, device=x.device)
+            neg = torch.empty(batch, dtype=torch.uint8, device=x.device)
+            if batch:
+                N.check(N.lib().pynqs_green_rbm(xc.data_ptr(), batch, sorb, nele, noa, nob, plan.data_ptr(), table.data_ptr(), table.nhidden,
+                                                CX.RBM_FLAVOURS[prm[3]], float(Lambda), eloc.data_ptr(), None, gk.data_ptr(), neg.data_ptr(),
+                                                torch.cuda.current_stream(x.device).cuda_stream), "pynqs_green_rbm")
+            return eloc, gk, rows, False, neg.bool()
         f = partial(ansatz_batch, func=ansatz)
         comb_x, comb_hij = get_comb_hij_fused(x, h1e, h2e, sorb, nele, noa, nob)
         bra_len = comb_x.shape[2]
@@ -56,10 +89,24 @@ FUSED_SAMPLE = True  # one kernel for sum + cumsum + searchsorted + gather (pynq
 
 def sample_update(x: Tensor, weight: Tensor, comb_x: Tensor, green_kernel: Tensor, rand_num: Optional[Tensor] = None):
     """gfmc/walker.py:260-279: x_new ~ G(. <- x) / beta, weight *= beta."""
+    if isinstance(comb_x, CombRows):
+        if not (green_kernel.is_cuda and green_kernel.dtype == torch.float64 and green_kernel.size(0) > 0):
+            comb_x = comb_x.materialize()
+        else:
+            n = green_kernel.size(0)
+            dev = green_kernel.device
+            if rand_num is None:
+                rand_num = torch.rand((n, 1), dtype=torch.float64, device=dev)
+            gk, rn = green_kernel.contiguous(), rand_num.to(torch.float64).contiguous()
+            index = torch.empty(n, dtype=torch.int64, device=dev)
+            beta = torch.empty((n, 1), dtype=torch.float64, device=dev)
+            x_new = torch.empty_like(comb_x.x)
+            N.check(N.lib().pynqs_gfmc_sample_rank(gk.data_ptr(), n, rn.data_ptr(), comb_x.x.data_ptr(), comb_x.sorb, comb_x.nele, comb_x.noa,
+                                                   comb_x.nob, index.data_ptr(), beta.data_ptr(), x_new.data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream), "pynqs_gfmc_sample_rank")
+            return x_new, weight * beta.squeeze(), beta, int((index != 0).sum().item())
     if (FUSED_SAMPLE and green_kernel.is_cuda and green_kernel.dtype == torch.float64 and green_kernel.dim() == 2
             and comb_x.is_cuda and comb_x.dtype == torch.uint8 and green_kernel.size(0) > 0):
-        from . import _native as N
-
         n, m = green_kernel.shape
         L = comb_x.size(-1) // 8
         dev = green_kernel.device

@@ -9,11 +9,13 @@ from conftest import golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused_green", [True, False])
 @pytest.mark.parametrize("fused_sample", [True, False])
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_green_kernel_and_move_match_reference_python(fe2s2, tag, fused_sample):
+def test_green_kernel_and_move_match_reference_python(fe2s2, tag, fused_sample, fused_green):
     """_calculate_green_kernel (fixed-node effective Hamiltonian, sign-flip potential, clamp of negative diagonal kernels:
-    case b clamps 5 of the 16 walkers) and sample_update with the reference's uniforms."""
+    case b clamps 5 of the 16 walkers) and sample_update with the reference's uniforms.  fused_green: the whole row from
+    pynqs_green_rbm (the trial function is a real RBM) and the move from the column's rank, nothing materialised; else comb + module."""
     from pynqs_amd import gfmc, public_function as pf
     from pynqs_amd.rbm import RealRBM
 
@@ -22,15 +24,20 @@ def test_green_kernel_and_move_match_reference_python(fe2s2, tag, fused_sample):
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     old_dt = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
-    old = gfmc.FUSED_SAMPLE
+    old, old_g = gfmc.FUSED_SAMPLE, gfmc.FUSED_GREEN
     try:
-        gfmc.FUSED_SAMPLE = fused_sample
+        gfmc.FUSED_SAMPLE, gfmc.FUSED_GREEN = fused_sample, fused_green
         rbm = RealRBM(T(e0["W"]), T(e0["hb"]), T(e0["vb"])).to(dev)
         ab = lambda x, func: pf.ansatz_batch(func, x, 100000, 40, dev, torch.double)  # noqa: E731
         x = T(d["x"])
         eloc, gk, comb, stop, mask = gfmc.green_kernel(x, float(d[tag + "_Lambda"]), T(fe2s2["h1e"]), T(fe2s2["h2e"]), rbm, ab, 40, 30, 15, 15,
                                                        torch.double, None, True)
         assert stop is False
+        assert isinstance(comb, gfmc.CombRows) == fused_green
+        if fused_green and tag == "a" and fused_sample:
+            from pynqs_amd import C_extension as cx
+
+            assert np.array_equal(comb.materialize().cpu().numpy(), cx.get_comb_hij_fused(x, T(fe2s2["h1e"]), T(fe2s2["h2e"]), 40, 30, 15, 15)[0].cpu().numpy())
         np.testing.assert_allclose(eloc.cpu().numpy(), d[tag + "_eloc"], rtol=0, atol=1e-8)
         assert np.array_equal(mask.cpu().numpy(), d[tag + "_mask"])
         np.testing.assert_allclose(gk[:4].cpu().numpy(), d[tag + "_gk4"], rtol=1e-11, atol=1e-13)
@@ -42,7 +49,7 @@ def test_green_kernel_and_move_match_reference_python(fe2s2, tag, fused_sample):
         np.testing.assert_allclose(beta.cpu().numpy().reshape(-1), d[tag + "_beta"].reshape(-1), rtol=1e-11)
         assert acc == int(d[tag + "_accept"])
     finally:
-        gfmc.FUSED_SAMPLE = old
+        gfmc.FUSED_SAMPLE, gfmc.FUSED_GREEN = old, old_g
         torch.set_default_dtype(old_dt)
 
 
@@ -68,3 +75,48 @@ def test_merge_rank_sample_matches_reference():
             mu, mc = onv, T(cnt)
         assert np.array_equal(mc.cpu().numpy(), sm[f"tree{t}_r0_all_counts"])
         assert np.array_equal(mu.cpu().numpy(), np.concatenate([sm[f"tree{t}_r{r}_unique_rank"] for r in (0, 1)]))
+
+
+@pytest.mark.parametrize("sorb,noA,noB,H,n,kind", [(12, 3, 2, 24, 40, "real"), (16, 4, 4, 20, 30, "tanh"), (66, 3, 4, 70, 7, "real"),
+                                                   (130, 3, 2, 64, 4, "tanh"), (128, 3, 2, 400, 5, "real")])
+def test_fused_green_row_random_systems(sorb, noA, noB, H, n, kind):
+    """pynqs_green_rbm + pynqs_gfmc_sample_rank (1-3 ONV words, unequal alpha / beta, resident and windowed kernels, amplitudes of
+    both signs for "tanh") against the materialising path of the same module -- which test_green_kernel_and_move_match_reference_python
+    pins to the reference on Fe2S2: row, E_loc, clamp mask, and the move for the same uniforms."""
+    from conftest import rand_occ, synth_integrals
+    from oracle import oracle
+    from pynqs_amd import gfmc, public_function as pf
+    from pynqs_amd.rbm import RealRBM
+
+    dev = torch.device("cuda")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    h1, h2 = synth_integrals(sorb)
+    bra = oracle.pm01_to_onv(rand_occ(n, sorb, noA, noB, seed=3 * sorb + H), sorb)
+    x = T(bra.view(np.uint8).reshape(n, -1))
+    g = np.random.default_rng(sorb * 13 + H)
+    W, hb, vb = 0.05 * (g.random((H, sorb)) - 0.5), 1.0 * (g.random(H) - 0.5), 0.3 * (g.random(sorb) - 0.5)
+    old_dt = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    old_g = gfmc.FUSED_GREEN
+    try:
+        m = RealRBM(T(W), T(hb), T(vb), rbm_type=kind).to(dev)
+        ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, sorb, dev, torch.double)  # noqa: E731
+        out = {}
+        rnd = T(g.random((n, 1)))
+        wgt = T(g.random(n) + 0.5)
+        for fused in (True, False):
+            gfmc.FUSED_GREEN = fused
+            # Lambda between the rows' diagonal kernels: some walkers clamp
+            eloc, gk, comb, _, neg = gfmc.green_kernel(x, 0.0, T(h1), T(h2), m, ab, sorb, noA + noB, noA, noB, torch.double, None, True)
+            x_new, w_new, beta, acc = gfmc.sample_update(x, wgt, comb, gk, rnd)
+            out[fused] = [t.cpu().numpy() for t in (eloc, gk, neg, x_new, w_new, beta)] + [acc]
+        scale = max(1.0, float(np.abs(out[False][1]).sum(1).max()))
+        np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=1e-8 * scale)
+        np.testing.assert_allclose(out[True][1], out[False][1], rtol=1e-9, atol=1e-11 * scale)
+        assert np.array_equal(out[True][2], out[False][2])
+        assert np.array_equal(out[True][3], out[False][3])
+        np.testing.assert_allclose(out[True][4], out[False][4], rtol=1e-10)
+        assert out[True][6] == out[False][6]
+    finally:
+        gfmc.FUSED_GREEN = old_g
+        torch.set_default_dtype(old_dt)

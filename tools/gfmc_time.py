@@ -1,24 +1,29 @@
-"""sample_update (gfmc/walker.py:260-279) on a [8192, 7876] Green's-function matrix: fused kernel vs the torch passes."""
+"""One GFMC step (Green's-function row + move) for Fe2S2 walkers with a real-RBM trial function: fused kernels against the
+materialising path (comb + module).  usage: python tools/gfmc_time.py [n_fused] [n_module]"""
 import os, sys, time
+import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pynqs_amd import gfmc
-n, m = 8192, 7876
-d = torch.device("cuda")
-g = torch.Generator(device=d).manual_seed(1)
-gk = torch.rand(n, m, generator=g, dtype=torch.float64, device=d)
-gk[gk < 0.7] = 0.0
-gk[:, 0] += 1.0
-comb = torch.randint(0, 256, (n, m, 8), generator=g, dtype=torch.uint8, device=d)
-u = torch.rand(n, 1, generator=g, dtype=torch.float64, device=d)
-w = torch.ones(n, dtype=torch.float64, device=d)
-for fused in (True, False):
-    gfmc.FUSED_SAMPLE = fused
-    for _ in range(3):
-        r = gfmc.sample_update(None, w, comb, gk, u)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10):
-        r = gfmc.sample_update(None, w, comb, gk, u)
+from pynqs_amd import gfmc, public_function as pf
+from pynqs_amd.rbm import RealRBM
+d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/fe2s2_inputs.npz"))
+dev = torch.device("cuda")
+torch.set_default_dtype(torch.float64)
+g = torch.Generator().manual_seed(7)
+rbm = RealRBM(0.01 * (torch.rand(80, 40, generator=g) - 0.5), 0.01 * (torch.rand(80, generator=g) - 0.5), 0.1 * (torch.rand(40, generator=g) - 0.5)).to(dev)
+h1, h2 = torch.from_numpy(d["h1e"]).to(dev), torch.from_numpy(d["h2e"]).to(dev)
+ab = lambda x, func: pf.ansatz_batch(func, x, 2_000_000, 40, dev, torch.double)
+for fused, n in ((True, int(sys.argv[1]) if len(sys.argv) > 1 else 8192), (False, int(sys.argv[2]) if len(sys.argv) > 2 else 512)):
+    gfmc.FUSED_GREEN = fused
+    x = torch.from_numpy(np.ascontiguousarray(d["ci_space"][:n])).to(dev)
+    w = torch.ones(n, device=dev)
+    def step():
+        eloc, gk, comb, _, neg = gfmc.green_kernel(x, -100.0, h1, h2, rbm, ab, 40, 30, 15, 15, torch.double, None, True)
+        return gfmc.sample_update(x, w, comb, gk)
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); reps = 5
+    for _ in range(reps):
+        x_new, w_new, beta, acc = step()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 10 * 1e3
-    print(f"fused={fused}: {ms:.3f} ms per step ({n * m * 8 / ms / 1e6:.0f} GB/s of the Green matrix), accepted {r[3]}")
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    print(f"{'fused' if fused else 'comb + module'}: {n} walkers, {ms:.3f} ms per step = {n / ms * 1e3:.3e} walker moves/s (accepted {acc})")
