@@ -68,30 +68,54 @@ __device__ __forceinline__ int sign_below(const uint64_t (&w)[LEN], int n) {
   return par & 1u;
 }
 
+// <x|H|x> of lane `src`'s determinant, by the whole wave: the nele(nele+1)/2 terms (hamiltonian.cpp:34-50: for p ascending h(p,p), then
+// <pq||pq> for the occupied q < p ascending) are gathered 512 at a time into the wave's LDS tile, one term per lane and pass, and lane
+// `src` adds them in the reference's order (bit-identical).  A lane evaluating its diagonal alone spends ~40 instructions and an L2
+// round trip per term while its 63 neighbours wait: 0.28 ms for the 4096 diagonal pairs of a 4096 x 4096 Fe2S2 call (tools/hij_diag_time.py).
+// List entries past the determinant's electron count read as orbital 0, like the reference's zero-initialised olst[MAX_NELE].
+constexpr int kHijDiagTile = 512;
+
 template <int LEN, typename T>
-__device__ T diag_serial(const uint64_t (&x)[LEN], const T *__restrict__ h1e, const T *__restrict__ h2e, int sorb,
-                         int nele) {
-  // p ascending; q < p ascending (hamiltonian.cpp:41-48).  List entries past the determinant's electron
-  // count read as orbital 0, like the reference's zero-initialised olst[MAX_NELE].
+__device__ __forceinline__ T diag_by_wave(const uint64_t (&mine)[LEN], int src, const T *__restrict__ h1e, const T *__restrict__ h2e, int sorb,
+                                          int nele, T *__restrict__ tile, uint8_t *__restrict__ occ) {
+  const int lane = threadIdx.x & 63;
+  uint64_t x[LEN];
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) x[w] = __shfl(mine[w], src);
+  __builtin_amdgcn_wave_barrier();
+  int before = 0;
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) {
+    if ((x[w] >> lane) & 1ull) occ[before + __popcll(x[w] & ((1ull << lane) - 1ull))] = (uint8_t)(64 * w + lane);
+    before += __popcll(x[w]);
+  }
+  for (int k = before + lane; k < nele; k += 64) occ[k] = 0;
+  __builtin_amdgcn_wave_barrier();
+  const int nterms = nele * (nele + 1) / 2;
   T acc = T(0);
-  int wa = 0;
-  uint64_t bits_a = x[0];
-  for (int a = 0; a < nele; ++a) {
-    while (bits_a == 0 && wa < LEN - 1) bits_a = pick<LEN>(x, ++wa);
-    int pa = 0;
-    if (bits_a) { pa = wa * 64 + __builtin_ctzll(bits_a); bits_a &= bits_a - 1; }
-    acc += h1e[(size_t)pa * sorb + pa];
-    int b = 0;
-    for (int wj = 0; wj < LEN && b < a; ++wj) {
-      uint64_t bj = pick<LEN>(x, wj);
-      while (bj && b < a) {
-        const int pb = wj * 64 + __builtin_ctzll(bj);
-        bj &= bj - 1;
-        acc += two_body<T>(h2e, pa, pb, pa, pb);
-        ++b;
+  for (int base = 0; base < nterms; base += kHijDiagTile) {
+    const int end = min(base + kHijDiagTile, nterms);
+    for (int t = base + lane; t < end; t += 64) {
+      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (a * (a + 1) / 2 > t) --a;
+      while ((a + 1) * (a + 2) / 2 <= t) ++a;
+      const int pos = t - a * (a + 1) / 2;
+      const int pa = occ[a];
+      tile[t - base] = pos == 0 ? h1e[(size_t)pa * sorb + pa] : two_body<T>(h2e, pa, occ[pos - 1], pa, occ[pos - 1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == src) {
+      const int cnt = end - base;
+      for (int t = 0; t < cnt; t += 8) {  // eight LDS reads in flight, added in order
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = tile[min(t + u, kHijDiagTile - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (t + u < cnt) acc += v[u];
       }
     }
-    for (; b < a; ++b) acc += two_body<T>(h2e, pa, 0, pa, 0);
+    __builtin_amdgcn_wave_barrier();
   }
   return acc;
 }
@@ -101,8 +125,11 @@ __global__ __launch_bounds__(kBlock) void hij_pairs_kernel(const uint64_t *__res
                                                            const uint64_t *__restrict__ ket, uint64_t m, int ket_is_3d,
                                                            const T *__restrict__ h1e, const T *__restrict__ h2e, int sorb,
                                                            int nele, T *__restrict__ hmat) {
-  const uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n * m) return;
+  __shared__ T dtile[kBlock / 64][kHijDiagTile];
+  __shared__ uint8_t docc[kBlock / 64][192];
+  const uint64_t idx0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool valid = idx0 < n * m;  // (no early exit: the diagonal pairs below are evaluated by whole waves)
+  const uint64_t idx = valid ? idx0 : n * m - 1;
   const uint64_t i = idx / m, j = idx - i * m;
   uint64_t b[LEN], k[LEN];
   const uint64_t *kp = ket + ((ket_is_3d ? i * m : 0) + j) * LEN;
@@ -116,8 +143,14 @@ __global__ __launch_bounds__(kBlock) void hij_pairs_kernel(const uint64_t *__res
     na += __popcll(d & k[w]);
   }
   T val = T(0);
+  uint64_t diag_lanes = __ballot(valid && nc == 0 && na == 0);
+  while (diag_lanes) {  // wave-uniform
+    const int src = __builtin_ctzll(diag_lanes);
+    diag_lanes &= diag_lanes - 1;
+    const T v = diag_by_wave<LEN, T>(b, src, h1e, h2e, sorb, nele, dtile[threadIdx.x >> 6], docc[threadIdx.x >> 6]);
+    if ((int)(threadIdx.x & 63) == src) val = v;
+  }
   if (nc == 0 && na == 0) {
-    val = diag_serial<LEN, T>(b, h1e, h2e, sorb, nele);
   } else if ((nc == 1 && na == 1) || (nc == 2 && na == 2)) {
     int cre[2] = {0, 0}, ann[2] = {0, 0};
     int ic = 0, ia = 0;
@@ -151,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void hij_pairs_kernel(const uint64_t *__res
       val = par ? -v : v;
     }
   }
-  hmat[idx] = val;
+  if (valid) hmat[idx] = val;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -307,7 +340,7 @@ extern "C" int pynqs_comb(const uint64_t *bra, int64_t nbatch, int sorb, int noA
 extern "C" int pynqs_hij(const uint64_t *bra, int64_t n, const uint64_t *ket, int64_t m, int ket_is_3d, const void *h1e,
                          const void *h2e, int dtype, int sorb, int nele, void *hmat, void *stream) {
   pynqs::DeviceScope device_scope_(bra);
-  if (sorb < 1 || sorb > kMaxSorb || n < 0 || m < 0 || nele < 0 || (dtype != PYNQS_F32 && dtype != PYNQS_F64))
+  if (sorb < 1 || sorb > kMaxSorb || n < 0 || m < 0 || nele < 0 || nele > kMaxSorb || (dtype != PYNQS_F32 && dtype != PYNQS_F64))
     return set_error(PYNQS_EINVAL, "bad sorb/n/m/dtype");
   if (n == 0 || m == 0) return PYNQS_OK;
   if (!bra || !ket || !h1e || !h2e || !hmat) return set_error(PYNQS_EINVAL, "null pointer");

@@ -223,13 +223,14 @@ def test_gfmc_step_matches_direct_tensor_algebra(env):
     K = -heff; K[:, 0] += -100.0
     np.testing.assert_allclose(gk.cpu().numpy(), torch.clamp(ratio * K, min=0.0).cpu().numpy() if bool(neg.any()) else (ratio * K).cpu().numpy(),
                                rtol=1e-12, atol=1e-12)
-    assert torch.equal(comb, comb2) and stop is False
+    assert isinstance(comb, gfmc.CombRows)  # (real RBM trial function: the fused row, nothing materialised)
+    assert torch.equal(comb.materialize(), comb2) and stop is False
     # the fixed-node E_loc equals the plain E_loc when psi has no sign structure issue: sum_k ratio*H
     r = torch.full((5, 1), 0.37, dtype=torch.float64, device=x.device)
     x_new, w_new, beta, acc = gfmc.sample_update(x, torch.ones(5, dtype=torch.float64, device=x.device), comb, gk, r)
     cum = gk.cumsum(-1) / gk.sum(-1, keepdim=True)
     idx = (cum < 0.37).sum(-1)
-    assert torch.equal(x_new, comb[torch.arange(5), idx]) and torch.allclose(w_new, gk.sum(-1))
+    assert torch.equal(x_new, comb2[torch.arange(5), idx]) and torch.allclose(w_new, gk.sum(-1))
 
 
 @pytest.mark.parametrize("n,m,L", [(7, 1, 1), (5, 27, 1), (33, 255, 1), (9, 256, 2), (9, 257, 3), (64, 7876, 1), (3, 300_001, 2)])
