@@ -60,6 +60,48 @@ while time.time() - t0 < budget:
     e, p = cx.eloc_rbm(G(x), h1e, h2e, cx.RBMTable(G(W), G(hb), G(vb)), sorb, nele, noA, noB)
     assert np.allclose(p.cpu().numpy(), p_ref, rtol=1e-10, atol=0), ("rbm psi", sorb, noA, noB, n, H)
     assert np.abs(e.cpu().numpy() - e_ref).max() <= 1e-8 * max(1.0, np.abs(e_ref).max(), scale), ("rbm eloc", sorb, noA, noB, n, H)
+    # the other real-parameter flavours (rbm.py:199-211) and the fixed-node Green's-function row, from the oracle's rows in numpy
+    if co.shape[1] * n <= 400000:
+        xs = O.onv_to_pm1(co.reshape(-1, co.shape[-1]), sorb)
+        th = xs @ W.T + hb
+        lncosh = (np.abs(th) + np.log1p(np.exp(-2.0 * np.abs(th)))).sum(1).reshape(n, -1)
+        ax = (xs @ vb).reshape(n, -1)
+        tab = cx.RBMTable(G(W), G(hb), G(vb))
+        r_tanh = np.tanh(ax) / np.tanh(ax[:, :1]) * np.exp(lncosh - lncosh[:, :1])
+        e_t, _ = cx.eloc_rbm(G(x), h1e, h2e, tab, sorb, nele, noA, noB, rbm_type="tanh")
+        ok = np.abs(np.tanh(ax[:, 0])) > 1e-3  # (psi(x) ~ 0: the ratio is ill-conditioned in the reference too)
+        assert np.abs(e_t.cpu().numpy() - (ho * r_tanh).sum(1))[ok].max(initial=0.0) <= 1e-8 * max(1.0, scale * np.abs(r_tanh[ok]).max(initial=0.0)), ("tanh", sorb, noA, noB, n, H)
+        e_p, _ = cx.eloc_rbm(G(x), h1e, h2e, tab, sorb, nele, noA, noB, rbm_type="pRBM")
+        r_ph = np.exp(1j * ((ax + lncosh) - (ax + lncosh)[:, :1]))
+        assert np.abs(e_p.cpu().numpy() - (ho * r_ph).sum(1)).max() <= 1e-8 * scale, ("pRBM", sorb, noA, noB, n, H)
+        from pynqs_amd import _native as N
+        lam = float(np.median(ho[:, 0]))
+        r = np.exp((ax + lncosh) - (ax + lncosh)[:, :1])
+        keep = (ho < 0); keep[:, 0] = False
+        v_sf = np.where(~keep, ho * r, 0.0)[:, 1:].sum(1)
+        g_ref = np.where(keep, -ho * r, 0.0)
+        g_ref[:, 0] = np.maximum(lam - ho[:, 0] - v_sf, 0.0)
+        plan = cx.plan_for(h1e, h2e, sorb, dev)
+        eg = torch.empty(n, dtype=torch.float64, device=dev); gk = torch.empty((n, co.shape[1]), dtype=torch.float64, device=dev)
+        ng = torch.empty(n, dtype=torch.uint8, device=dev)
+        N.check(N.lib().pynqs_green_rbm(G(x).data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), tab.data_ptr(), tab.nhidden, 0, lam, eg.data_ptr(), None,
+                                        gk.data_ptr(), ng.data_ptr(), torch.cuda.current_stream().cuda_stream), "green")
+        assert np.abs(gk.cpu().numpy() - g_ref).max() <= 1e-8 * max(1.0, scale * np.abs(r).max()), ("green row", sorb, noA, noB, n, H)
+        assert np.abs(eg.cpu().numpy() - e_ref).max() <= 1e-8 * max(1.0, np.abs(e_ref).max(), scale), ("green eloc", sorb, noA, noB, n, H)
+        # the move from the column's rank == the reference's comb row
+        u = G(rng.random((n, 1)))
+        xi = torch.empty(n, dtype=torch.int64, device=dev); be = torch.empty((n, 1), dtype=torch.float64, device=dev)
+        xn = torch.empty((n, (sorb - 1) // 64 + 1), dtype=torch.int64, device=dev)
+        N.check(N.lib().pynqs_gfmc_sample_rank(gk.data_ptr(), n, u.data_ptr(), G(x).data_ptr(), sorb, nele, noA, noB, xi.data_ptr(), be.data_ptr(),
+                                               xn.data_ptr(), torch.cuda.current_stream().cuda_stream), "sample_rank")
+        if bool((be > 0).all()):
+            picked = co[np.arange(n), xi.cpu().numpy()]
+            assert np.array_equal(xn.cpu().numpy().view(np.uint64), np.ascontiguousarray(picked).view(np.uint64).reshape(n, -1)), ("rank move", sorb, noA, noB, n, xi.cpu().numpy()[:4])
+    # get_hij_torch, 2-D mode with diagonal pairs (evaluated by whole waves)
+    if n <= 33:
+        kets = np.concatenate([x, co[0][: min(40, co.shape[1])]])
+        hij = cx.get_hij_torch(G(x), G(kets), h1e, h2e, sorb, nele)
+        assert np.array_equal(hij.cpu().numpy(), O.hij(x, kets, h1, h2, sorb, nele)), ("hij 2-D", sorb, noA, noB, n)
     # fused sample-space local energy: table = a random half of the connected determinants of walker 0 plus all walkers
     flat = np.unique(np.concatenate([co[0][rng.random(co.shape[1]) < 0.5], x]), axis=0)
     order = O.sort_keys(flat, sorb) if hasattr(O, "sort_keys") else None
