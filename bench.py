@@ -898,6 +898,38 @@ def main():
                 "value": 8192 / el3, "unit": "local energies/s", "walkers": 8192, "ms_per_step": el3 * 1e3, "mean_eloc": float(e_.mean().item()),
                 "ansatz": "autoregressive Transformer decoder, d_model 32, 6 layers, 8 heads, f64, random weights (stand-in)",
                 "determinant_part_ms": el4 * 1e3}
+            # the reference's other real-parameter RBM amplitudes on the fused kernel, and one GFMC step (fixed-node Green's-function row + move)
+            # with the real RBM as trial function: fused kernels against comb + module
+            from pynqs_amd import C_extension as CXm, gfmc as GF
+
+            xg = torch.from_numpy(np.ascontiguousarray(d["ci_space"][:8192])).to(dev)
+            tab = CXm.RBMTable(rbm.weights.detach(), rbm.hidden_bias.detach(), rbm.visible_bias.detach())
+
+            def _timed(fn, reps):
+                fn(); torch.cuda.synchronize(dev)
+                t0_ = time.perf_counter()
+                for _ in range(reps):
+                    r_ = fn()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0_) / reps, r_
+
+            for kind in ("tanh", "pRBM"):
+                el5, (e5, _) = _timed(lambda: CXm.eloc_rbm(xg, h1g, h2g, tab, sorb, nele, noA, noB, rbm_type=kind), 20)
+                extra[f"fe2s2_eloc_rbm_{kind}"] = {"value": 8192 / el5, "unit": "local energies/s", "walkers": 8192, "ms_per_step": el5 * 1e3,
+                                                   "mean_eloc": [float(e5.mean().real), float(e5.mean().imag) if e5.is_complex() else 0.0]}
+            ab_ = lambda xx, func: pf.ansatz_batch(func, xx, 2_000_000, sorb, dev, torch.double)  # noqa: E731
+            wgt = torch.ones(8192, dtype=torch.float64, device=dev)
+            for tag, nw, fused in (("fe2s2_gfmc_step_rbm_fused", 8192, True), ("fe2s2_gfmc_step_rbm_module", 512, False)):
+                GF.FUSED_GREEN = fused
+
+                def gstep():
+                    el_, gk_, comb_, _, _ = GF.green_kernel(xg[:nw], -100.0, h1g, h2g, rbm, ab_, sorb, nele, noA, noB, torch.double, None, True)
+                    return GF.sample_update(xg[:nw], wgt[:nw], comb_, gk_)
+
+                el6, (_, _, beta_, acc_) = _timed(gstep, 5)
+                extra[tag] = {"value": nw / el6, "unit": "walker moves/s", "walkers": nw, "ms_per_step": el6 * 1e3, "accepted": int(acc_),
+                              "mean_beta": float(beta_.mean().item())}
+            GF.FUSED_GREEN = True
             torch.set_default_dtype(old_default)
             E.FUSED_RBM = old_fused_rbm
         except Exception as e:  # pragma: no cover

@@ -188,6 +188,22 @@ int pynqs_eloc_rbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int 
 int pynqs_eloc_rbm_flavour(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                            const void *rbm_table, int nhidden, int flavour, double *eloc, double *psi, void *stream);
 
+/* ---- SIMPLE method with an RBM with COMPLEX parameters, fully fused (kernels_rbm_complex.hip) -----------------------------
+ * psi(x) = exp(a.x) prod_h 2 cosh(b_h + sum_o W[h][o] x_o) with complex a, b, W: rbm.py:199-211, rbm_type "complex"
+ * (weights double[nhidden][sorb][2], hidden_bias double[nhidden][2], visible_bias double[sorb][2] or NULL: the reference's
+ * params_weights / params_hidden_bias / params_visible_bias, (re, im) pairs).  rbm_type "cos" (prod_h cos(theta_h), real
+ * parameters) is the same function of i*W, i*b up to the constant 2^nhidden: pass log_scale = nhidden * ln 2.
+ *   pynqs_eloc_crbm_supported : [host] 1 if the complex rows of all (orbital, hidden unit) pairs fit the CU's LDS
+ *   pynqs_crbm_table_bytes / _build : re-laid-out parameters in caller-owned memory (rebuild after every update)
+ *   pynqs_eloc_crbm : eloc double[nbatch][2] = sum_x' <x|H|x'> psi(x')/psi(x);  psi double[nbatch][2] (may be NULL) =
+ *                     psi(x) exp(-log_scale). */
+int pynqs_eloc_crbm_supported(int sorb, int nele, int noA, int noB, int nhidden);
+int64_t pynqs_crbm_table_bytes(int sorb, int nhidden);
+int pynqs_crbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb, int nhidden,
+                           void *table, void *stream);
+int pynqs_eloc_crbm(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                    const void *crbm_table, int nhidden, double log_scale, double *eloc, double *psi, void *stream);
+
 /* ---- Green's-function Monte-Carlo move: gfmc/walker.py:260-279 (sample_update) in one kernel ---------------
  * green double[n][ncomb] (the fixed-node Green's function row of each walker, >= 0), rand_num double[n] in [0, 1),
  * comb uint64[n][ncomb][len] (get_comb_hij_fused's first output).  Per walker: beta = sum_k green[k];

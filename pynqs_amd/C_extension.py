@@ -435,6 +435,64 @@ def eloc_rbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: RBMTable, sorb: int, 
     return eloc, psi
 
 
+class CRBMTable:
+    """Device-resident re-layout of an RBM with COMPLEX parameters for the fused SIMPLE local energy (pynqs_crbm_table_build;
+    rbm.py:199-211, rbm_type "complex").  weights [num_hidden, sorb], hidden_bias [num_hidden], visible_bias [sorb] or None:
+    complex128 tensors, or float64 tensors with a trailing (re, im) axis (the reference's params_* layout)."""
+
+    def __init__(self, weights: Tensor, hidden_bias: Tensor, visible_bias: "Tensor | None" = None) -> None:
+        def as_pairs(t: Tensor) -> Tensor:
+            t = t.detach()
+            if t.is_complex():
+                t = torch.view_as_real(t.to(torch.complex128))
+            if t.dtype != torch.float64 or t.size(-1) != 2:
+                raise RuntimeError("complex RBM parameters must be complex128 or float64 (re, im) pairs")
+            return t.contiguous()
+
+        w, hb = as_pairs(weights), as_pairs(hidden_bias).reshape(-1, 2)
+        vb = as_pairs(visible_bias).reshape(-1, 2) if visible_bias is not None else None
+        if w.dim() != 3 or hb.size(0) != w.size(0) or (vb is not None and vb.size(0) != w.size(1)):
+            raise RuntimeError("weights must be [num_hidden, sorb], hidden_bias [num_hidden], visible_bias [sorb]")
+        ts = [w, hb] + ([vb] if vb is not None else [])
+        dev, st, _ = _stage(*ts)
+        self.nhidden, self.sorb, self.device = int(w.size(0)), int(w.size(1)), dev
+        nbytes = N.lib().pynqs_crbm_table_bytes(self.sorb, self.nhidden)
+        if nbytes < 0:
+            raise RuntimeError(f"bad RBM sizes: sorb = {self.sorb}, num_hidden = {self.nhidden}")
+        self.buf = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+        N.check(N.lib().pynqs_crbm_table_build(st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr() if len(st) > 2 else None,
+                                               self.sorb, self.nhidden, self.buf.data_ptr(), _stream(dev)), "crbm_table_build")
+        torch.cuda.current_stream(dev).synchronize()  # the (possibly temporary) parameter copies must outlive the build kernel
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+
+def eloc_crbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: CRBMTable, sorb: int, nele: int, noA: int, noB: int,
+              want_psi: bool = True, log_scale: float = 0.0) -> Tuple[Tensor, "Tensor | None"]:
+    """SIMPLE local energy with the amplitude ratio of a complex-parameter RBM evaluated on chip (pynqs_eloc_crbm):
+    (eloc complex128[n], psi(x) exp(-log_scale) complex128[n] or None)."""
+    _check_onv(bra, "bra", sorb, (2,))
+    if table.sorb != sorb:
+        raise RuntimeError(f"RBM table was built for sorb = {table.sorb}, not {sorb}")
+    if _fdtype(h1e, h2e) != N.PYNQS_F64:
+        raise RuntimeError("the fused RBM local energy is float64 only")
+    plan = plan_for(h1e, h2e, sorb, bra.device)
+    if plan is None:
+        raise RuntimeError("the fused RBM local energy needs an even sorb")
+    dev, (x,), all_cpu = _stage(bra)
+    if plan.device != dev or table.device != dev:
+        raise RuntimeError("bra, integrals and RBM table must be on the same device")
+    n = x.size(0)
+    eloc = torch.empty(n, dtype=torch.complex128, device=dev)
+    psi = torch.empty(n, dtype=torch.complex128, device=dev) if want_psi else None
+    N.check(N.lib().pynqs_eloc_crbm(x.data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), table.data_ptr(), table.nhidden, float(log_scale),
+                                    eloc.data_ptr(), psi.data_ptr() if want_psi else None, _stream(dev)), "pynqs_eloc_crbm")
+    if all_cpu and bra.device.type == "cpu":
+        return eloc.cpu(), (psi.cpu() if want_psi else None)
+    return eloc, psi
+
+
 def spin_flip_rand(bra: Tensor, sorb: int, nele: int, noA: int, noB: int, seed: int, in_place: bool = False) -> Tuple[Tensor, Tensor]:
     """bind.cpp:303-314 -> cpu_tensor.cpp:90-137: one random single/double move (or none) per walker.
     Returns (onv_to_tensor(new walkers), new walkers uint8[n, 8*len]).  The reference's generators are

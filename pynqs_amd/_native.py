@@ -49,6 +49,10 @@ SIGNATURES = {
     "pynqs_rbm_table_build": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_eloc_rbm": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _vp, _vp, _vp]),
     "pynqs_eloc_rbm_flavour": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    "pynqs_eloc_crbm_supported": (_int, [_int, _int, _int, _int, _int]),
+    "pynqs_crbm_table_bytes": (_i64, [_int, _int]),
+    "pynqs_crbm_table_build": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),
+    "pynqs_eloc_crbm": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _dbl, _vp, _vp, _vp]),
     "pynqs_gfmc_sample": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     "pynqs_green_rbm": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _int, _int, _dbl, _vp, _vp, _vp, _vp, _vp]),
     "pynqs_gfmc_sample_rank": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),

@@ -144,6 +144,32 @@ def _real_rbm_params(ansatz):
     return W.detach().double(), hb.detach().reshape(-1).double(), vb.detach().reshape(-1).double(), kind
 
 
+def _complex_rbm_params(ansatz):
+    """((re, im) weights [H, sorb, 2], hidden_bias [H, 2], visible_bias [sorb, 2] or None, log_scale, real_valued) for the fused kernel
+    with complex running products (pynqs_eloc_crbm): an RBM with complex parameters (pynqs_amd.rbm.ComplexRBM, or PyNQS'
+    RBMWavefunction(rbm_type="complex") -- the reference's params_* layout), or rbm_type "cos" with real parameters, which is the same
+    function of i W, i b up to 2^H (cos t = cosh(i t)); else None."""
+    import math
+
+    from .rbm import ComplexRBM, RealRBM
+
+    m = getattr(ansatz, "module", ansatz)
+    kind = getattr(m, "rbm_type", None)
+    if isinstance(m, ComplexRBM) or (kind == "complex" and hasattr(m, "params_weights")):
+        W, hb, vb = m.params_weights, m.params_hidden_bias, getattr(m, "params_visible_bias", None)
+        if W is None or hb is None or not W.is_cuda or W.dtype != torch.float64 or W.size(-1) != 2:
+            return None
+        H = hb.numel() // 2
+        return W.detach().reshape(H, -1, 2), hb.detach().reshape(H, 2), (vb.detach().reshape(-1, 2) if vb is not None else None), 0.0, False
+    if kind == "cos" and (isinstance(m, RealRBM) or hasattr(m, "effective_theta")):
+        W, hb = getattr(m, "weights", None), getattr(m, "hidden_bias", None)
+        if W is None or hb is None or not W.is_cuda or W.dtype not in (torch.float64, torch.float32) or W.dim() != 2:
+            return None
+        W, hb = W.detach().double(), hb.detach().reshape(-1).double()
+        return torch.stack([torch.zeros_like(W), W], -1), torch.stack([torch.zeros_like(hb), hb], -1), None, W.size(0) * math.log(2.0), True
+    return None
+
+
 def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
     """pynqs_eloc_rbm keeps exp(+-4W) of all (orbital, hidden unit) pairs in LDS (160 KiB per workgroup)."""
     return bool(N.lib().pynqs_eloc_rbm_supported(sorb, nele, noa, nob, nhidden))
@@ -350,6 +376,15 @@ def local_energy(
             if (prm is not None and dtype in ((torch.complex128, torch.complex64) if prm[3] == "pRBM" else (torch.double, torch.float32))
                     and _rbm_lds_ok(sorb, nele, noa, nob, prm[0].size(0))):
                 eloc, psi0 = CX.eloc_rbm(x, *CX.integrals_f64(h1e, h2e), CX.RBMTable(*prm[:3]), sorb, nele, noa, nob, rbm_type=prm[3])
+                t1 = time.time_ns()
+                return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
+            cprm = _complex_rbm_params(ansatz) if prm is None else None
+            # complex parameters (complex running products in the kernel); "cos" is real-valued and rides on the same kernel
+            if (cprm is not None and dtype in ((torch.double, torch.float32) if cprm[4] else (torch.complex128, torch.complex64))
+                    and N.lib().pynqs_eloc_crbm_supported(sorb, nele, noa, nob, cprm[0].size(0))):
+                eloc, psi0 = CX.eloc_crbm(x, *CX.integrals_f64(h1e, h2e), CX.CRBMTable(*cprm[:3]), sorb, nele, noa, nob, log_scale=cprm[3])
+                if cprm[4]:
+                    eloc, psi0 = eloc.real, psi0.real
                 t1 = time.time_ns()
                 return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 

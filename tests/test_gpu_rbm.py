@@ -170,9 +170,9 @@ def test_flavours_match_reference_python(cx, fe2s2, kind):
         torch.set_default_dtype(old)
 
 
-def test_cos_flavour_takes_the_module_path(cx, fe2s2):
-    """rbm_type "cos" has no fused kernel (complex running products): pynqs_amd.rbm.RealRBM("cos") through the generic path against
-    the reference's RBMWavefunction(rbm_type="cos")."""
+def test_cos_flavour_on_the_complex_kernel(cx, fe2s2):
+    """rbm_type "cos" = prod_h cos(theta_h) = 2^-H prod_h 2cosh(i theta_h): the kernel with complex running products (pynqs_eloc_crbm),
+    and the module path, against the reference's RBMWavefunction(rbm_type="cos")."""
     from pynqs_amd import energy, public_function as pf
     from pynqs_amd.rbm import RealRBM
 
@@ -183,12 +183,86 @@ def test_cos_flavour_takes_the_module_path(cx, fe2s2):
     try:
         m = RealRBM(_dev(d0["W"]), _dev(d0["hb"]), _dev(d0["vb"]), rbm_type="cos").cuda()
         ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, 40, x.device, torch.double)  # noqa: E731
-        for tag, kw in (("simple", {}), ("reduce", dict(reduce_psi=True, eps=1e-2, eps_sample=0))):
-            el, _, ps, _ = energy.local_energy(x, h1e, h2e, m, ab, 40, 30, 15, 15, **kw)
-            np.testing.assert_allclose(el.cpu().numpy(), d[f"eloc_{tag}_cos"], rtol=0, atol=TOL)
-            np.testing.assert_allclose(ps.cpu().numpy(), d[f"psi_{tag}_cos"], rtol=1e-11)
+        assert energy._complex_rbm_params(m) is not None
+        for fused in (True, False):
+            energy.FUSED_RBM = fused
+            for tag, kw in (("simple", {}), ("reduce", dict(reduce_psi=True, eps=1e-2, eps_sample=0))):
+                el, _, ps, _ = energy.local_energy(x, h1e, h2e, m, ab, 40, 30, 15, 15, **kw)
+                assert el.dtype == torch.float64
+                np.testing.assert_allclose(el.cpu().numpy(), d[f"eloc_{tag}_cos"], rtol=0, atol=TOL)
+                np.testing.assert_allclose(ps.cpu().numpy(), d[f"psi_{tag}_cos"], rtol=1e-11)
+    finally:
+        energy.FUSED_RBM = True
+        torch.set_default_dtype(old)
+
+
+def test_complex_rbm_matches_reference_python(cx, fe2s2):
+    """An RBM with complex128 parameters in the kernel (pynqs_eloc_crbm) against the reference's local_energy driven with the same
+    amplitude as a module (tests/golden/eloc_complex_module.npz: eloc_simple / psi_simple), the few-walker (atomics) path, and the
+    energy layer's choice between kernel and module."""
+    from pynqs_amd import energy, public_function as pf
+    from pynqs_amd.rbm import ComplexRBM
+
+    c = golden("eloc_complex_module.npz")
+    h1e, h2e, x = _dev(fe2s2["h1e"]), _dev(fe2s2["h2e"]), _dev(c["x"])
+    tab = cx.CRBMTable(_dev(c["Wc"]), _dev(c["hbc"]), _dev(c["vbc"]))
+    e, p = cx.eloc_crbm(x, h1e, h2e, tab, 40, 30, 15, 15)
+    assert e.dtype == torch.complex128
+    np.testing.assert_allclose(e.cpu().numpy(), c["eloc_simple"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(p.cpu().numpy(), c["psi_simple"], rtol=1e-11)
+    e3, p3 = cx.eloc_crbm(x[:3].contiguous(), h1e, h2e, tab, 40, 30, 15, 15, want_psi=False)
+    assert p3 is None
+    np.testing.assert_allclose(e3.cpu().numpy(), c["eloc_simple"][:3], rtol=0, atol=TOL)
+    # complex128 tensors instead of (re, im) pairs
+    tab2 = cx.CRBMTable(torch.view_as_complex(_dev(c["Wc"])), torch.view_as_complex(_dev(c["hbc"])), torch.view_as_complex(_dev(c["vbc"])))
+    e2, _ = cx.eloc_crbm(x, h1e, h2e, tab2, 40, 30, 15, 15)
+    np.testing.assert_allclose(e2.cpu().numpy(), e.cpu().numpy(), rtol=0, atol=1e-11)  # (tiles go to whichever wave is free: the order of additions varies)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        m = ComplexRBM(_dev(c["Wc"]), _dev(c["hbc"]), _dev(c["vbc"])).cuda()
+        ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, 40, x.device, torch.complex128)  # noqa: E731
+        calls = []
+        orig = energy.CX.eloc_crbm
+        energy.CX.eloc_crbm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            el, _, ps, _ = energy.local_energy(x, h1e, h2e, m, ab, 40, 30, 15, 15, dtype=torch.complex128)
+        finally:
+            energy.CX.eloc_crbm = orig
+        assert calls, "the complex RBM did not take the fused kernel"
+        np.testing.assert_allclose(el.cpu().numpy(), c["eloc_simple"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(ps.cpu().numpy(), c["psi_simple"], rtol=1e-11)
     finally:
         torch.set_default_dtype(old)
+
+
+@pytest.mark.parametrize("sorb,noA,noB,H,n", [(8, 2, 2, 5, 36), (12, 3, 2, 24, 40), (16, 5, 3, 33, 20), (4, 1, 0, 6, 2), (66, 3, 4, 40, 7),
+                                              (130, 3, 2, 30, 4), (40, 15, 15, 96, 2)])
+def test_complex_rbm_random_systems(cx, sorb, noA, noB, H, n):
+    """pynqs_eloc_crbm on 1-3 ONV words, unequal alpha / beta, theta of both signs of the real part, against numpy on the oracle's
+    comb / Hmat (ratios of prod cosh, complex128)."""
+    from oracle import oracle
+
+    h1, h2 = synth_integrals(sorb)
+    occ = rand_occ(n, sorb, noA, noB, seed=sorb * 3 + H)
+    bra_cpu = oracle.pm01_to_onv(occ, sorb)
+    g = np.random.default_rng(sorb * 17 + H)
+    W = 0.1 * ((g.random((H, sorb)) - 0.5) + 1j * (g.random((H, sorb)) - 0.5))
+    hb = 2.0 * (g.random(H) - 0.5) + 1j * (g.random(H) - 0.5)
+    vb = 0.2 * ((g.random(sorb) - 0.5) + 1j * (g.random(sorb) - 0.5))
+    assert cx.N.lib().pynqs_eloc_crbm_supported(sorb, noA + noB, noA, noB, H) == 1
+    comb, hm = oracle.comb_hij_fused(bra_cpu, h1, h2, sorb, noA + noB, noA, noB)
+    xs = oracle.onv_to_pm1(comb.reshape(-1, comb.shape[-1]), sorb)
+    th = (xs @ W.T + hb).reshape(n, -1, H)
+    ax = (xs @ vb).reshape(n, -1)
+    ratio = np.exp(ax - ax[:, :1]) * np.prod(np.cosh(th) / np.cosh(th[:, :1]), axis=-1)
+    e_ref = (hm * ratio).sum(1)
+    p_ref = np.exp(ax[:, 0]) * np.prod(2 * np.cosh(th[:, 0]), axis=-1)
+    tab = cx.CRBMTable(_dev(W), _dev(hb), _dev(vb))
+    e, p = cx.eloc_crbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
+    scale = max(1.0, float((np.abs(hm) * np.abs(ratio)).sum(1).max()))
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
+    np.testing.assert_allclose(p.cpu().numpy(), p_ref, rtol=1e-10)
 
 
 @pytest.mark.parametrize("sorb,noA,noB,H,n,kind", [(12, 3, 2, 24, 40, "tanh"), (66, 3, 4, 70, 7, "pRBM"), (130, 3, 2, 64, 4, "tanh"),
