@@ -917,6 +917,14 @@ def main():
                 el5, (e5, _) = _timed(lambda: CXm.eloc_rbm(xg, h1g, h2g, tab, sorb, nele, noA, noB, rbm_type=kind), 20)
                 extra[f"fe2s2_eloc_rbm_{kind}"] = {"value": 8192 / el5, "unit": "local energies/s", "walkers": 8192, "ms_per_step": el5 * 1e3,
                                                    "mean_eloc": [float(e5.mean().real), float(e5.mean().imag) if e5.is_complex() else 0.0]}
+            # complex128 parameters in the kernel (alpha = 1, the size of the default step's module)
+            gc = torch.Generator().manual_seed(13)
+            ctab = CXm.CRBMTable((0.02 * (torch.rand(sorb, sorb, 2, generator=gc, dtype=torch.float64) - 0.5)).to(dev),
+                                 (0.02 * (torch.rand(sorb, 2, generator=gc, dtype=torch.float64) - 0.5)).to(dev),
+                                 (0.05 * (torch.rand(sorb, 2, generator=gc, dtype=torch.float64) - 0.5)).to(dev))
+            el5, (e5, _) = _timed(lambda: CXm.eloc_crbm(xg, h1g, h2g, ctab, sorb, nele, noA, noB), 10)
+            extra["fe2s2_eloc_crbm"] = {"value": 8192 / el5, "unit": "local energies/s", "walkers": 8192, "ms_per_step": el5 * 1e3, "num_hidden": sorb,
+                                        "mean_eloc": [float(e5.mean().real), float(e5.mean().imag)]}
             ab_ = lambda xx, func: pf.ansatz_batch(func, xx, 2_000_000, sorb, dev, torch.double)  # noqa: E731
             wgt = torch.ones(8192, dtype=torch.float64, device=dev)
             for tag, nw, fused in (("fe2s2_gfmc_step_rbm_fused", 8192, True), ("fe2s2_gfmc_step_rbm_module", 512, False)):

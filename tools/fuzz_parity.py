@@ -6,7 +6,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O
-from pynqs_amd import C_extension as cx, energy, public_function as pf
+from pynqs_amd import C_extension as cx, energy, public_function as pf, _native as N_
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -74,7 +74,14 @@ while time.time() - t0 < budget:
         e_p, _ = cx.eloc_rbm(G(x), h1e, h2e, tab, sorb, nele, noA, noB, rbm_type="pRBM")
         r_ph = np.exp(1j * ((ax + lncosh) - (ax + lncosh)[:, :1]))
         assert np.abs(e_p.cpu().numpy() - (ho * r_ph).sum(1)).max() <= 1e-8 * scale, ("pRBM", sorb, noA, noB, n, H)
-        from pynqs_amd import _native as N
+        # complex parameters (complex running products), and "cos" = the same kernel on i W, i b
+        if N_.lib().pynqs_eloc_crbm_supported(sorb, nele, noA, noB, H):
+            Wc = W + 1j * 0.2 * (rng.random((H, sorb)) - 0.5); hc = hb + 1j * (rng.random(H) - 0.5); vc = vb + 1j * 0.3 * (rng.random(sorb) - 0.5)
+            thc = (xs @ Wc.T + hc).reshape(n, -1, H)
+            axc = (xs @ vc).reshape(n, -1)
+            r_c = np.exp(axc - axc[:, :1]) * np.prod(np.cosh(thc) / np.cosh(thc[:, :1]), axis=-1)
+            e_c, _ = cx.eloc_crbm(G(x), h1e, h2e, cx.CRBMTable(G(Wc), G(hc), G(vc)), sorb, nele, noA, noB)
+            assert np.abs(e_c.cpu().numpy() - (ho * r_c).sum(1)).max() <= 1e-8 * max(1.0, (np.abs(ho) * np.abs(r_c)).sum(1).max()), ("crbm", sorb, noA, noB, n, H)
         lam = float(np.median(ho[:, 0]))
         r = np.exp((ax + lncosh) - (ax + lncosh)[:, :1])
         keep = (ho < 0); keep[:, 0] = False
@@ -84,7 +91,7 @@ while time.time() - t0 < budget:
         plan = cx.plan_for(h1e, h2e, sorb, dev)
         eg = torch.empty(n, dtype=torch.float64, device=dev); gk = torch.empty((n, co.shape[1]), dtype=torch.float64, device=dev)
         ng = torch.empty(n, dtype=torch.uint8, device=dev)
-        N.check(N.lib().pynqs_green_rbm(G(x).data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), tab.data_ptr(), tab.nhidden, 0, lam, eg.data_ptr(), None,
+        N_.check(N_.lib().pynqs_green_rbm(G(x).data_ptr(), n, sorb, nele, noA, noB, plan.data_ptr(), tab.data_ptr(), tab.nhidden, 0, lam, eg.data_ptr(), None,
                                         gk.data_ptr(), ng.data_ptr(), torch.cuda.current_stream().cuda_stream), "green")
         assert np.abs(gk.cpu().numpy() - g_ref).max() <= 1e-8 * max(1.0, scale * np.abs(r).max()), ("green row", sorb, noA, noB, n, H)
         assert np.abs(eg.cpu().numpy() - e_ref).max() <= 1e-8 * max(1.0, np.abs(e_ref).max(), scale), ("green eloc", sorb, noA, noB, n, H)
@@ -92,7 +99,7 @@ while time.time() - t0 < budget:
         u = G(rng.random((n, 1)))
         xi = torch.empty(n, dtype=torch.int64, device=dev); be = torch.empty((n, 1), dtype=torch.float64, device=dev)
         xn = torch.empty((n, (sorb - 1) // 64 + 1), dtype=torch.int64, device=dev)
-        N.check(N.lib().pynqs_gfmc_sample_rank(gk.data_ptr(), n, u.data_ptr(), G(x).data_ptr(), sorb, nele, noA, noB, xi.data_ptr(), be.data_ptr(),
+        N_.check(N_.lib().pynqs_gfmc_sample_rank(gk.data_ptr(), n, u.data_ptr(), G(x).data_ptr(), sorb, nele, noA, noB, xi.data_ptr(), be.data_ptr(),
                                                xn.data_ptr(), torch.cuda.current_stream().cuda_stream), "sample_rank")
         if bool((be > 0).all()):
             picked = co[np.arange(n), xi.cpu().numpy()]
