@@ -176,7 +176,7 @@ def _rbm_lds_ok(sorb: int, nele: int, noa: int, nob: int, nhidden: int) -> bool:
 
 
 def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa=0, nob=0) -> bool:
-    return (FUSED and WF_LUT is not None and WF_LUT.sort and not use_spin_raising
+    return (FUSED and WF_LUT is not None and WF_LUT.sort
             and sorb % 2 == 0 and h1e.dtype in (torch.float64, torch.float32)
             and WF_LUT.dtype in (torch.float64, torch.complex128, torch.float32, torch.complex64)
             and x.is_cuda and WF_LUT.bra_key.is_cuda)
@@ -341,52 +341,65 @@ def local_energy(
 
         # ---- fast path: SAMPLE_SPACE in one kernel ----------------------------------------------------
         if use_sample_space and _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa, nob):
-            if not (use_multi_psi or use_spin_flip):
-                eloc, psi0, _ = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT)
-            else:
+            f_keys = None
+            if use_multi_psi:  # f on the sample-space keys, once (the reference stores f in the table's dtype, flip.py:392)
+                f_keys = Func(partial(ansatz_batch, func=ansatz.module.extra), WF_LUT.bra_key, None, True).to(WF_LUT.dtype)
+
+            def in_sample_space(h1, h2):
+                """sum over the sample space with the integrals (h1, h2): the energy, and with the S-S+ integrals <S-S+> (eloc.py:377-400)"""
+                if not (use_multi_psi or use_spin_flip):
+                    e1, p0, _ = _sample_space_fused(x, h1, h2, sorb, nele, noa, nob, WF_LUT)
+                    return e1, p0
                 # projected / multi-psi forms (flip.py:322-418, eloc.py:381-392) on the same kernel:
                 #   E_loc = conj(f(x)) [ sum_k H_k (f psi)(x'_k) + eta sum_k H_k eta_m(x'_k) (f psi)(flip x'_k) ] / (N^2 psi(x))
-                # (f psi) is a table over the sample space: f is evaluated once on the keys instead of on every hit
-                wf = WF_LUT.wf_value
-                if use_multi_psi:
-                    f_keys = Func(partial(ansatz_batch, func=ansatz.module.extra), WF_LUT.bra_key, None, True).to(wf.dtype)  # (the reference
-                    wf = wf * f_keys                                                       # stores f in the table's dtype, flip.py:392)
-                e1, t0x, part = _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf, use_spin_flip)
+                # (f psi) is a table over the sample space
+                wf = WF_LUT.wf_value * f_keys if use_multi_psi else WF_LUT.wf_value
+                e1, t0x, part = _sample_space_fused(x, h1, h2, sorb, nele, noa, nob, WF_LUT, wf, use_spin_flip)
                 if use_spin_flip:
                     e1 = e1 + SpinProjection.eta * part
                 if use_multi_psi:
                     # t(x) = f(x) psi(x): back to sum / psi(x) and the reference's factor conj(f(x)); psi(x), f(x) from the table
                     pos, found = WF_LUT.find(x)
                     pos = pos.clamp_min(0)
-                    psi0 = torch.where(found, WF_LUT.wf_value[pos], torch.zeros((), dtype=WF_LUT.dtype, device=x.device))
+                    p0 = torch.where(found, WF_LUT.wf_value[pos], torch.zeros((), dtype=WF_LUT.dtype, device=x.device))
                     f_x = torch.where(found, f_keys[pos], torch.zeros((), dtype=f_keys.dtype, device=x.device))
                     e1 = e1 * f_x * f_x.conj()
                 else:
-                    psi0 = t0x
-                eloc = e1 / extra_norm**2
+                    p0 = t0x
+                return e1 / extra_norm**2, p0
+
+            eloc, psi0 = in_sample_space(h1e, h2e)
+            sloc = in_sample_space(h1e_spin, h2e_spin)[0] if use_spin_raising else torch.zeros_like(eloc)
             t1 = time.time_ns()
-            return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
+            return eloc.to(dtype), sloc.to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 
         # ---- fast path: SIMPLE with an RBM (real parameters), amplitude ratios on chip ----------------------------
         if (FUSED and FUSED_RBM and not reduce_psi and not use_sample_space and WF_LUT is None and x.is_cuda
-                and not (use_spin_raising or use_multi_psi or use_spin_flip) and sorb % 2 == 0
+                and not (use_multi_psi or use_spin_flip) and sorb % 2 == 0
                 and h1e.dtype in (torch.float64, torch.float32)):
             prm = _real_rbm_params(ansatz)
             # the phase flavour (pRBM) is complex-valued; the others need a real `dtype` like the module itself
             if (prm is not None and dtype in ((torch.complex128, torch.complex64) if prm[3] == "pRBM" else (torch.double, torch.float32))
                     and _rbm_lds_ok(sorb, nele, noa, nob, prm[0].size(0))):
-                eloc, psi0 = CX.eloc_rbm(x, *CX.integrals_f64(h1e, h2e), CX.RBMTable(*prm[:3]), sorb, nele, noa, nob, rbm_type=prm[3])
+                table = CX.RBMTable(*prm[:3])
+                eloc, psi0 = CX.eloc_rbm(x, *CX.integrals_f64(h1e, h2e), table, sorb, nele, noa, nob, rbm_type=prm[3])
+                # <S-S+> (eloc.py:173-188): the same kernel with the S-S+ integrals
+                sloc = CX.eloc_rbm(x, *CX.integrals_f64(h1e_spin, h2e_spin), table, sorb, nele, noa, nob, want_psi=False, rbm_type=prm[3])[0] \
+                    if use_spin_raising else torch.zeros_like(eloc)
                 t1 = time.time_ns()
-                return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
+                return eloc.to(dtype), sloc.to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
             cprm = _complex_rbm_params(ansatz) if prm is None else None
             # complex parameters (complex running products in the kernel); "cos" is real-valued and rides on the same kernel
             if (cprm is not None and dtype in ((torch.double, torch.float32) if cprm[4] else (torch.complex128, torch.complex64))
                     and N.lib().pynqs_eloc_crbm_supported(sorb, nele, noa, nob, cprm[0].size(0))):
-                eloc, psi0 = CX.eloc_crbm(x, *CX.integrals_f64(h1e, h2e), CX.CRBMTable(*cprm[:3]), sorb, nele, noa, nob, log_scale=cprm[3])
+                ctable = CX.CRBMTable(*cprm[:3])
+                eloc, psi0 = CX.eloc_crbm(x, *CX.integrals_f64(h1e, h2e), ctable, sorb, nele, noa, nob, log_scale=cprm[3])
+                sloc = CX.eloc_crbm(x, *CX.integrals_f64(h1e_spin, h2e_spin), ctable, sorb, nele, noa, nob, want_psi=False)[0] \
+                    if use_spin_raising else torch.zeros_like(eloc)
                 if cprm[4]:
-                    eloc, psi0 = eloc.real, psi0.real
+                    eloc, sloc, psi0 = eloc.real, sloc.real, psi0.real
                 t1 = time.time_ns()
-                return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
+                return eloc.to(dtype), sloc.to(dtype), psi0.to(dtype), ((t1 - t0) / 1e6, 0.0, 0.0)
 
         if use_multi_psi:
             ansatz_extra = partial(ansatz_batch, func=ansatz.module.extra)

@@ -9,6 +9,8 @@ What is captured (all on the shipped Fe2S2 problem, ci_space[:32], fixed-weight 
   grad_fe2s2.npz                vmc/grad/energy_grad.py:118-184 (`grad`) under DistributedDataParallel, world size 1 and 2 (gloo)
   gfmc_fe2s2.npz                gfmc/walker.py:167-235 (_calculate_green_kernel), :260-279 (sample_update), :340-408 (branching, ws 1 and 2)
   eloc_rbm_flavours.npz         SIMPLE / REDUCE with RBMWavefunction(rbm_type = "tanh" / "pRBM" / "cos") (vmc/ansatz/rbm/rbm.py:199-211)
+  eloc_spin_raising_fe2s2.npz   use_spin_raising (<S-S+> with the integrals of utils/pyscf_helper/operator.py:93-137): SIMPLE / REDUCE / SAMPLE_SPACE
+                                local_energy and total_energy's REDUCE + sample-space form (etot.py:93-142)
   sampler_merge.npz             merge_rank_sample (cpp_src/tensor/cpu_tensor.cpp:537-556) and Sampler.gather_scatter_sample
                                 (vmc/sample.py:627-772) run by two gloo ranks, both `use_same_tree` settings
 Only DATA is written: inputs and the reference's outputs.
@@ -200,6 +202,38 @@ def section_rbm_flavours(I, out_dir):
             out[f"eloc_{tag}_{kind}"], out[f"psi_{tag}_{kind}"] = e.detach().numpy(), p.detach().numpy()
     np.savez_compressed(f"{out_dir}/eloc_rbm_flavours.npz", **out)
     print("rbm flavours:", {k: (v.dtype, float(np.abs(v).max())) for k, v in out.items() if k.startswith("eloc_")})
+
+
+# --------------------------------------------------------------------------------------------------------------
+def section_spin_raising(I, out_dir):
+    """<S-S+> next to the energy (use_spin_raising, eloc.py:173-188,250-310,377-400; etot.py:93-142): the S-S+ integrals of
+    utils/pyscf_helper/operator.py:93-137 (spin_raising) are part of the fixture."""
+    from utils.public_function import WavefunctionLUT, ansatz_batch
+    from utils.pyscf_helper.operator import spin_raising
+    from vmc.ansatz.rbm.rbm import RBMWavefunction
+    from vmc.energy.eloc import local_energy
+    from vmc.energy.etot import total_energy
+
+    sorb, nele, noA, noB = I["sorb"], I["nele"], I["noA"], I["noB"]
+    h1, h2, x, ci = I["h1e"], I["h2e"], I["x"], I["ci"]
+    h1s, h2s = spin_raising(sorb, c1=1.0)
+    rbm = RBMWavefunction(sorb, alpha=2, rbm_type="real"); rbm.init(I["hb"].clone(), I["W"].clone(), I["vb"].clone())
+    ab = lambda x_, func: ansatz_batch(func, x_, 100000, sorb, torch.device("cpu"), torch.double)  # noqa: E731
+    keys = ci[:2048].contiguous()
+    with torch.no_grad():
+        wf = ab(keys, rbm)
+    lut = WavefunctionLUT(keys, wf, sorb, device="cpu")
+    out = dict(x=x.numpy(), h1e_spin=h1s.numpy(), h2e_spin=h2s.numpy(), lut_keys=keys.numpy(), lut_wf=wf.numpy())
+    for tag, kw in (("simple", {}), ("reduce", dict(reduce_psi=True, eps=1e-2, eps_sample=0)),
+                    ("ss", dict(use_sample_space=True, WF_LUT=lut, index=(0, 32)))):
+        e, sl, p, _ = local_energy(x, h1, h2, rbm, ab, sorb, nele, noA, noB, use_spin_raising=True, h1e_spin=h1s, h2e_spin=h2s, **kw)
+        out[f"eloc_{tag}"], out[f"sloc_{tag}"], out[f"psi_{tag}"] = e.detach().numpy(), sl.detach().numpy(), p.detach().numpy()
+    # the production form: REDUCE for the energy, <S-S+> recomputed in the sample space (etot.py:119-142)
+    e, sl, _ = total_energy(x, 16, 100000, h1, h2, rbm, sorb, nele, noA, noB, WF_LUT=lut, use_spin_raising=True, h1e_spin=h1s, h2e_spin=h2s,
+                            reduce_psi=True, eps=1e-2, eps_sample=0)
+    out["eloc_etot_reduce"], out["sloc_etot_reduce"] = e.detach().numpy(), sl.detach().numpy()
+    np.savez_compressed(f"{out_dir}/eloc_spin_raising_fe2s2.npz", **out)
+    print("spin raising:", {k: float(np.abs(v).max()) for k, v in out.items() if k.startswith("sloc_")})
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -414,6 +448,8 @@ def main():
         section_eloc(I, a.out)
     if "eloc" in only or "flavours" in only:
         section_rbm_flavours(I, a.out)
+    if "eloc" in only or "spin" in only:
+        section_spin_raising(I, a.out)
     if "dist" in only:
         branch, samp, stats = section_dist(a.scratch, a.out)
         section_gfmc(I, a.out, branch)

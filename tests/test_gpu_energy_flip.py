@@ -187,3 +187,31 @@ def test_spin_flip_kernel_all_filter_levels(sorb, no, nkeys, use_hash):
     scale = max(1.0, float(np.abs(out[False][0]).max()))
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=0, atol=TOL * scale)
     pf.SpinProjection.init(30, 0)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_spin_raising_matches_reference_python(env, fused):
+    """use_spin_raising: <S-S+> next to the energy (eloc.py:173-188,250-310,377-400) with the reference's own S-S+ integrals
+    (utils/pyscf_helper/operator.py:93-137, part of the fixture), for SIMPLE (fused: the RBM kernel run with both integral sets),
+    REDUCE, SAMPLE_SPACE (fused: a second pass of the one-kernel form) and total_energy's REDUCE + sample-space form (etot.py:93-142)."""
+    energy, pf, T, dev = env["energy"], env["pf"], env["T"], env["dev"]
+    s = golden("eloc_spin_raising_fe2s2.npz")
+    h1s, h2s = T(s["h1e_spin"]), T(s["h2e_spin"])
+    lut = pf.WavefunctionLUT(T(s["lut_keys"]), T(s["lut_wf"]), 40, device=dev)
+    ab = lambda x, func: pf.ansatz_batch(func, x, 100000, 40, dev, torch.double)  # noqa: E731
+    old = energy.FUSED, energy.FUSED_RBM
+    energy.FUSED = energy.FUSED_RBM = fused
+    try:
+        for tag, kw in (("simple", {}), ("reduce", dict(reduce_psi=True, eps=1e-2, eps_sample=0)),
+                        ("ss", dict(use_sample_space=True, WF_LUT=lut, index=(0, 32)))):
+            e, sl, p, _ = energy.local_energy(env["x"], env["h1e"], env["h2e"], env["rbm"], ab, *SYS, use_spin_raising=True, h1e_spin=h1s, h2e_spin=h2s,
+                                              **kw)
+            np.testing.assert_allclose(e.cpu().numpy(), s["eloc_" + tag], rtol=0, atol=TOL)
+            np.testing.assert_allclose(sl.cpu().numpy(), s["sloc_" + tag], rtol=0, atol=TOL)
+            np.testing.assert_allclose(p.cpu().numpy(), s["psi_" + tag], rtol=1e-12)
+        e, sl, _ = energy.total_energy(env["x"], 16, 100000, env["h1e"], env["h2e"], env["rbm"], *SYS, WF_LUT=lut, use_spin_raising=True,
+                                       h1e_spin=h1s, h2e_spin=h2s, reduce_psi=True, eps=1e-2, eps_sample=0)
+        np.testing.assert_allclose(e.cpu().numpy(), s["eloc_etot_reduce"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(sl.cpu().numpy(), s["sloc_etot_reduce"], rtol=0, atol=TOL)
+    finally:
+        energy.FUSED, energy.FUSED_RBM = old
