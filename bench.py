@@ -283,7 +283,7 @@ class SampleSpaceFused(Workload):
         self.dev, self.path, self.kernel = dev, "plan", "eloc_sample_space_filtered_kernel"
         self.bound, self.pmc_name = "valu", f"{tag}_eloc_sample_space"
         self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered; HBM traffic is "
-                              "negligible and the kernel is bound by vector-ALU instruction issue (29-41 instructions per column)")
+                              "negligible and the kernel is bound by vector-ALU instruction issue (see valu_instructions_per_launch: ~1.5 wave64 instructions per column incl. the per-walker set-up and the evaluation of the candidates)")
         self.stats = None
 
     def step(self):
