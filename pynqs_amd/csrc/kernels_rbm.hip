@@ -118,6 +118,25 @@ __device__ __forceinline__ uint32_t rbm_row(uint32_t o, uint32_t K) { return (o 
 //                   windows (two barriers per window).
 enum : int { kRbmReal = 0, kRbmTanh = 1, kRbmPhase = 2 };
 
+// sin and cos of a moderate argument (|x| < 1e5: here the logarithm of an amplitude ratio) without the library's large-argument
+// path, whose code and registers the 16-column epilogue of the phase flavour pays for on every call: x = k pi/2 + r by two fmas
+// (pi/2 split in two doubles), then the fdlibm kernels on |r| <= pi/4 (errors < 1 ulp of the result for these magnitudes).
+__device__ __forceinline__ void sincos_moderate(double x, double &sn, double &cs) {
+  const double k = rint(x * 0.63661977236758134308);  // 2 / pi
+  double r = fma(-k, 1.57079632679489655800e+00, x);
+  r = fma(-k, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                     2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double s0 = fma(r * z, ps, r), c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)k;
+  const double a = (q & 1) ? c0 : s0, b = (q & 1) ? s0 : c0;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
 template <int LEN, bool WINDOWED, int FLAVOUR, bool GREEN>
 __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, RbmLayout rl,
                                                           RbmBlocks B, uint32_t nchunks, uint32_t hw, const double *__restrict__ plan,
@@ -328,23 +347,24 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
   double *__restrict__ grow = GREEN ? green + (size_t)walker * (p.nsd + 1) : nullptr;
   // one column's contribution: h = <x|H|x'>, t = the real flavour's psi(x')/psi(x) (for tanh: without the visible factor),
   // da = exp(2 (a.x' - a.x)), col = the reference's column of x' (GREEN)
-  auto add_column = [&](double h, double t, double da, uint32_t col) {
+  // (branch-free but for the GREEN store: a branch per column keeps the 16 divisions / logarithms of a block from overlapping --
+  // the phase flavour ran 1.70 ms with `if (ok) add_column(...)`, 1.12 ms without)
+  auto add_column = [&](bool ok, double h, double t, double da, uint32_t col) {
     if constexpr (FLAVOUR == kRbmReal || FLAVOUR == kRbmTanh) {
       double r = t;
       if constexpr (FLAVOUR == kRbmTanh) r = t * ((1.0 - 2.0 / fma(e2ax, da, 1.0)) * inv_tanh_ax);  // tanh(a.x'): exp(2 a.x') = inf -> 1, 0 -> -1
-      const double hr = h * r;
+      const double hr = ok ? h * r : 0.0;
       esum += hr;
       if constexpr (GREEN) {
         const bool keeps_sign = (r < 0.0) != (h < 0.0);
-        grow[col] = keeps_sign ? -hr : 0.0;
+        if (ok) grow[col] = keeps_sign ? -hr : 0.0;
         esum_im += keeps_sign ? 0.0 : hr;
       }
     } else {
       double sn, cs;
-      sincos(log(t), &sn, &cs);
-      esum += h * cs;
-      esum_im += h * sn;
-      asm volatile("" ::: "memory");  // one column at a time: 16 interleaved log / sincos expansions spill
+      sincos_moderate(log(ok ? t : 1.0), sn, cs);
+      esum += (ok ? h : 0.0) * cs;
+      esum_im += (ok ? h : 0.0) * sn;
     }
   };
   for (uint32_t round = 0;; ++round) {
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t f = 4 * bf + i;
-          if (f < nF) add_column(R.hs[1 + f], acc[4 * i] * cf[i], af[i], 1u + f);
+          add_column(f < nF, R.hs[1 + min(f, nF - 1)], acc[4 * i] * cf[i], af[i], 1u + f);
         }
       } else {
         const bool opp = cls == 3;
@@ -483,7 +503,22 @@ __global__ __launch_bounds__(1024, 4) void eloc_rbm_kernel(const uint64_t *__res
               const uint32_t f = 4 * bf + i;
               col = cbase + (4 * bs + j) * nF + (f >= rot ? f - rot : f + nF - rot);
             }
-            if (ok) add_column(par ? -hv[4 * i + j] : hv[4 * i + j], t, af[i] * as[j], col);
+            if constexpr (FLAVOUR == kRbmPhase) {
+              // branch-free first pass: the phase ln t and the signed matrix element in place (0 for the padding columns of the block)
+              acc[4 * i + j] = log(ok ? t : 1.0);
+              hv[4 * i + j] = ok ? (par ? -hv[4 * i + j] : hv[4 * i + j]) : 0.0;
+            } else {
+              add_column(ok, par ? -hv[4 * i + j] : hv[4 * i + j], t, af[i] * as[j], col);
+            }
+          }
+        }
+        if constexpr (FLAVOUR == kRbmPhase) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            double sn, cs;
+            sincos_moderate(acc[k], sn, cs);
+            esum += hv[k] * cs;
+            esum_im += hv[k] * sn;
           }
         }
       }
