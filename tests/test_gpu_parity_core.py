@@ -215,3 +215,33 @@ def test_tensor_to_onv_aligned_and_unaligned_rows(sorb):
     flat[3:] = torch.from_numpy(occ).cuda().reshape(-1)
     got2 = cx.tensor_to_onv(flat[3:].view(257, sorb), sorb)  # storage offset 3: not 8-byte aligned
     assert np.array_equal(got2.cpu().numpy(), want)
+
+
+def test_get_hij_on_the_list_just_enumerated_takes_the_plan_kernel(cx, fe2s2):
+    """The reference's REDUCE / SAMPLE_SPACE code calls get_comb_tensor(x) and then get_hij_torch(x, comb_x) (eloc.py:243-252,370-378):
+    that pair of tensor objects is recognised and answered by the fused plan kernel (Hmat only); a copy of the list, a list written to
+    afterwards, or another bra go through the generic pair kernel.  All bit-identical, f64 and f32."""
+    import torch
+
+    dev = torch.device("cuda")
+    x = torch.from_numpy(np.ascontiguousarray(fe2s2["ci_space"][:64])).to(dev)
+    for dt in (torch.float64, torch.float32):
+        h1, h2 = torch.from_numpy(fe2s2["h1e"]).to(dev).to(dt), torch.from_numpy(fe2s2["h2e"]).to(dev).to(dt)
+        comb, _ = cx.get_comb_tensor(x, 40, 30, 15, 15)
+        assert cx._is_last_comb(x, comb, 40, 30) == (15, 15)
+        fast = cx.get_hij_torch(x, comb, h1, h2, 40, 30)
+        copy = comb.clone()
+        assert cx._is_last_comb(x, copy, 40, 30) is None
+        slow = cx.get_hij_torch(x, copy, h1, h2, 40, 30)
+        assert torch.equal(fast, slow)
+        _, hm = cx.get_comb_hij_fused(x, h1, h2, 40, 30, 15, 15)
+        assert torch.equal(fast, hm)
+    comb, _ = cx.get_comb_tensor(x, 40, 30, 15, 15)
+    comb[3, 5, 0] ^= 3  # written to: no longer "the list of x"
+    assert cx._is_last_comb(x, comb, 40, 30) is None
+    h1, h2 = torch.from_numpy(fe2s2["h1e"]).to(dev), torch.from_numpy(fe2s2["h2e"]).to(dev)
+    got = cx.get_hij_torch(x, comb, h1, h2, 40, 30)
+    assert torch.equal(got, cx.get_hij_torch(x, comb.clone(), h1, h2, 40, 30)) and not torch.equal(got, hm.double())
+    y = x.clone()
+    comb, _ = cx.get_comb_tensor(x, 40, 30, 15, 15)
+    assert cx._is_last_comb(y, comb, 40, 30) is None
