@@ -410,7 +410,7 @@ def local_energy(
 
         # ---- fast path: REDUCE (deterministic) with on-chip compaction -----------------------------------
         # (also the spin-flip projected and multi-psi forms, flip.py:200-319: their extra factors are evaluated on the kept records only)
-        if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and not use_spin_raising and sorb % 2 == 0 and x.is_cuda):
+        if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and sorb % 2 == 0 and x.is_cuda):
             row, col, onv, h, counts = reduce_compact(x, h1e, h2e, sorb, nele, noa, nob, eps)
             t2 = time.time_ns()
             first = col == 0
@@ -437,14 +437,23 @@ def local_energy(
                 t = t * at_x(f).conj()[row]
             if use_multi_psi or use_spin_flip:
                 t = t / extra_norm**2
-            w = (t / psi_x[row]) * h.to(_real_dtype(dtype))
-            # rows are contiguous segments: a segmented sum instead of index_add_ (atomics: 2.7 of 5.0 ms on Fe2S2)
-            if w.is_complex():
-                eloc = torch.view_as_complex(torch.segment_reduce(torch.view_as_real(w).contiguous(), "sum", lengths=counts, unsafe=True))
+            ratio = t / psi_x[row]
+
+            def row_sums(wv: Tensor) -> Tensor:
+                # rows are contiguous segments: a segmented sum instead of index_add_ (atomics: 2.7 of 5.0 ms on Fe2S2)
+                if wv.is_complex():
+                    return torch.view_as_complex(torch.segment_reduce(torch.view_as_real(wv).contiguous(), "sum", lengths=counts, unsafe=True))
+                return torch.segment_reduce(wv, "sum", lengths=counts, unsafe=True)
+
+            eloc = row_sums(ratio * h.to(_real_dtype(dtype)))
+            if use_spin_raising:
+                # <S-S+> over the same kept columns (eloc.py:250-310): its matrix elements for the (x, x') pairs of the records
+                h_spin = get_hij_torch(x[row].contiguous(), onv.unsqueeze(1), h1e_spin, h2e_spin, sorb, nele).reshape(-1)
+                sloc = row_sums(ratio * h_spin.to(_real_dtype(dtype)))
             else:
-                eloc = torch.segment_reduce(w, "sum", lengths=counts, unsafe=True)
+                sloc = torch.zeros_like(eloc)
             t3 = time.time_ns()
-            return eloc.to(dtype), torch.zeros_like(eloc).to(dtype), psi_x, ((t2 - t0) / 1e6, 0.0, (t3 - t2) / 1e6)
+            return eloc.to(dtype), sloc.to(dtype), psi_x, ((t2 - t0) / 1e6, 0.0, (t3 - t2) / 1e6)
 
         # ---- fast path: semi-stochastic REDUCE (eps_sample > 0) with the selection done on chip ------------------------
         if (FUSED and FUSED_SAMPLED and reduce_psi and not use_sample_space and eps_sample > 0
