@@ -314,3 +314,51 @@ def test_end_to_end_vmc_lowers_the_energy():
     assert hist[-1] < hist[0] - 0.05
     assert min(hist) >= e0 - 1e-9
     assert hist[-1] - e0 < 0.6 * (hist[0] - e0)
+
+
+def test_complex_rbm_edge_cases(cx):
+    """Rows beyond the LDS: the C entry refuses (no silent wrong answer) and the energy layer takes the module path; empty batches;
+    the Green's-function row refuses the complex-valued phase flavour."""
+    from oracle import oracle
+    from pynqs_amd import _native as N, energy, public_function as pf
+    from pynqs_amd.rbm import ComplexRBM
+
+    sorb, noA, noB, H, n = 66, 2, 2, 700, 3
+    assert N.lib().pynqs_eloc_crbm_supported(sorb, noA + noB, noA, noB, H) == 0
+    h1, h2 = synth_integrals(sorb)
+    bra = oracle.pm01_to_onv(rand_occ(n, sorb, noA, noB, seed=5), sorb)
+    g = np.random.default_rng(5)
+    W = 0.02 * (g.random((H, sorb, 2)) - 0.5); hb = 0.5 * (g.random((H, 2)) - 0.5); vb = 0.1 * (g.random((sorb, 2)) - 0.5)
+    tab = cx.CRBMTable(_dev(W), _dev(hb), _dev(vb))
+    x = _dev(bra.view(np.uint8).reshape(n, -1))
+    with pytest.raises(RuntimeError, match="LDS"):
+        cx.eloc_crbm(x, _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        m = ComplexRBM(_dev(W), _dev(hb), _dev(vb)).cuda()
+        ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, sorb, x.device, torch.complex128)  # noqa: E731
+        el, _, ps, _ = energy.local_energy(x, _dev(h1), _dev(h2), m, ab, sorb, noA + noB, noA, noB, dtype=torch.complex128)
+    finally:
+        torch.set_default_dtype(old)
+    comb, hm = oracle.comb_hij_fused(bra, h1, h2, sorb, noA + noB, noA, noB)
+    xs = oracle.onv_to_pm1(comb.reshape(-1, comb.shape[-1]), sorb)
+    Wc, hc, vc = W[..., 0] + 1j * W[..., 1], hb[:, 0] + 1j * hb[:, 1], vb[:, 0] + 1j * vb[:, 1]
+    th = (xs @ Wc.T + hc).reshape(n, -1, H)
+    ax = (xs @ vc).reshape(n, -1)
+    ratio = np.exp(ax - ax[:, :1]) * np.exp((np.log(2 * np.cosh(th)) - np.log(2 * np.cosh(th[:, :1]))).sum(-1))
+    np.testing.assert_allclose(el.cpu().numpy(), (hm * ratio).sum(1), rtol=0, atol=1e-8 * max(1.0, float(np.abs(hm).sum(1).max())))
+    # empty batch
+    small = cx.CRBMTable(_dev(W[:8, :8]), _dev(hb[:8]), None)
+    e0, p0 = cx.eloc_crbm(torch.empty((0, 8), dtype=torch.uint8, device="cuda"), _dev(synth_integrals(8)[0]), _dev(synth_integrals(8)[1]), small, 8, 4, 2, 2)
+    assert e0.shape == (0,) and p0.shape == (0,) and e0.dtype == torch.complex128
+    # the fixed-node row needs a real-valued amplitude
+    h1s, h2s = synth_integrals(8)
+    plan = cx.plan_for(_dev(h1s), _dev(h2s), 8, torch.device("cuda"))
+    rt = cx.RBMTable(_dev(np.zeros((4, 8))), _dev(np.zeros(4)), None)
+    xb = _dev(oracle.pm01_to_onv(rand_occ(2, 8, 2, 2, seed=1), 8).view(np.uint8).reshape(2, -1))
+    out = torch.empty(2, dtype=torch.float64, device="cuda"); gk = torch.empty((2, 200), dtype=torch.float64, device="cuda")
+    flag = torch.empty(2, dtype=torch.uint8, device="cuda")
+    rc = N.lib().pynqs_green_rbm(xb.data_ptr(), 2, 8, 4, 2, 2, plan.data_ptr(), rt.data_ptr(), 4, N.RBM_PHASE, 0.0, out.data_ptr(), None, gk.data_ptr(),
+                                 flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == N.EINVAL
