@@ -5,6 +5,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pynqs_amd import C_extension as cx, energy, public_function as pf
+from oracle import oracle as O
 d = np.load("tests/golden/fe2s2_inputs.npz")
 dev = torch.device("cuda")
 h1e, h2e = torch.from_numpy(d["h1e"]).to(dev), torch.from_numpy(d["h2e"]).to(dev)
@@ -30,5 +31,10 @@ for logk in (14, 16, 17, 18, 19, 20, 22):
         e = f()[0]
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 10
-    print(f"keys 2^{logk} ({keys.size(0)}): {ms:.3f} ms per 8192 walkers = {n / ms * 1e3:.3e} E_loc/s", flush=True)
+    # parity of the first 8 walkers against the CPU oracle on the same (sorted) table
+    e_ref, _ = O.eloc_sample_space(d["ci_space"][:8].copy(), d["h1e"], d["h2e"], 40, 30, 15, 15,
+                                   lut.bra_key.cpu().numpy(), lut.wf_value.cpu().numpy())
+    err = float(np.abs(e[:8].cpu().numpy() - e_ref).max())
+    assert err < 1e-8, err
+    print(f"keys 2^{logk} ({keys.size(0)}): {ms:.3f} ms per 8192 walkers = {n / ms * 1e3:.3e} E_loc/s   (max |dE| vs oracle on 8 walkers {err:.1e})", flush=True)
     del lut, keys, wf
