@@ -22,7 +22,13 @@ for logk in (14, 16, 17, 18, 19, 20, 22):
         occ.scatter_(1, 2 * idx + s, 1)
     keys = torch.unique(torch.cat([cx.tensor_to_onv(occ.to(dev), 40), x, connected[: min(K // 4, connected.size(0))]]), dim=0)
     wf = torch.rand(keys.size(0), dtype=torch.float64, device=dev) + 0.1
-    lut = pf.WavefunctionLUT(keys, wf, 40, device=dev)
+    import time
+    lut = pf.WavefunctionLUT(keys, wf, 40, device=dev); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        lut = pf.WavefunctionLUT(keys, wf, 40, device=dev)
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) / 3 * 1e3
     f = lambda: energy.local_energy(x, h1e, h2e, None, None, 40, 30, 15, 15, WF_LUT=lut, use_sample_space=True)
     f(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,5 +42,5 @@ for logk in (14, 16, 17, 18, 19, 20, 22):
                                    lut.bra_key.cpu().numpy(), lut.wf_value.cpu().numpy())
     err = float(np.abs(e[:8].cpu().numpy() - e_ref).max())
     assert err < 1e-8, err
-    print(f"keys 2^{logk} ({keys.size(0)}): {ms:.3f} ms per 8192 walkers = {n / ms * 1e3:.3e} E_loc/s   (max |dE| vs oracle on 8 walkers {err:.1e})", flush=True)
+    print(f"keys 2^{logk} ({keys.size(0)}): {ms:.3f} ms per 8192 walkers = {n / ms * 1e3:.3e} E_loc/s   (max |dE| vs oracle on 8 walkers {err:.1e}); table build (sort + hash + filters) {build_ms:.2f} ms", flush=True)
     del lut, keys, wf
