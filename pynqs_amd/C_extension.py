@@ -531,6 +531,46 @@ def eloc_crbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: CRBMTable, sorb: int
     return eloc, psi
 
 
+# ---- two ansatz-side helpers of the reference module (outside the local-energy path) so that its autoregressive
+# ansaetze (BDG-RNN / MPS-RNN: permute_sgn; symmetry masks of the AR samplers: constrain_make_charts) import AND run on the drop-in.
+# Plain tensor algebra on the inputs' device: they are called once per forward on [nbatch, sorb] inputs.
+_CHARTS = None
+
+
+def constrain_make_charts(sym_idex: Tensor) -> Tensor:
+    """cpu_tensor.cpp:558-588: 9-entry lookup of the symmetry-constraint charts, double[nbatch, 4] (the parameter name is the
+    reference's, libs/C_extension.pyi:278); indices outside {10, 6, 14, 9, 5, 13, 11, 7, 15} give zeros (the reference reads a
+    default-constructed map entry there)."""
+    sym_index = sym_idex
+    global _CHARTS
+    if _CHARTS is None:
+        t = torch.zeros((16, 4), dtype=torch.float64)
+        for k, row in zip((10, 6, 14, 9, 5, 13, 11, 7, 15), ((1, 0, 0, 0), (0, 0, 1, 0), (1, 0, 1, 0), (0, 1, 0, 0), (0, 0, 0, 1), (0, 1, 0, 1),
+                                                             (1, 1, 0, 0), (0, 0, 1, 1), (1, 1, 1, 1))):
+            t[k] = torch.tensor(row, dtype=torch.float64)
+        _CHARTS = t
+    idx = sym_index.reshape(-1).long()
+    inside = (idx >= 0) & (idx < 16)
+    out = _CHARTS.to(idx.device)[idx.clamp(0, 15)]
+    return torch.where(inside.unsqueeze(1), out, torch.zeros_like(out))
+
+
+def permute_sgn(image2: Tensor, onstate: Tensor, sorb: int) -> Tensor:
+    """cpu_tensor.cpp:356-380 -> onstate.cpp:195-226: fermionic sign of re-ordering the orbitals into the sequence `image2` for the
+    occupation vectors onstate[nbatch, sorb] (0 / 1): (-1)^(number of pairs of occupied orbitals whose order image2 inverts) --
+    the reference counts the same pairs while it moves the orbitals one by one.  Returns double[nbatch] of +1 / -1."""
+    if image2.numel() != sorb and onstate.size(-1) != sorb:
+        raise ValueError("Dim error")  # std::length_error
+    if onstate.size(0) == 0:
+        return torch.zeros(0, dtype=torch.float64, device=onstate.device)
+    order = image2.reshape(-1).long().to(onstate.device)
+    occ = (onstate.reshape(onstate.size(0), -1)[:, order] != 0).to(torch.float64)  # occupations in the new order
+    pos = torch.arange(order.numel(), device=order.device)
+    inverted = ((pos.unsqueeze(1) < pos.unsqueeze(0)) & (order.unsqueeze(1) > order.unsqueeze(0))).to(torch.float64)  # [p, q]: p before q, labels reversed
+    pairs = ((occ @ inverted) * occ).sum(1)
+    return (1 - 2 * (pairs.long() & 1)).to(torch.float64)
+
+
 def spin_flip_rand(bra: Tensor, sorb: int, nele: int, noA: int, noB: int, seed: int, in_place: bool = False) -> Tuple[Tensor, Tensor]:
     """bind.cpp:303-314 -> cpu_tensor.cpp:90-137: one random single/double move (or none) per walker.
     Returns (onv_to_tensor(new walkers), new walkers uint8[n, 8*len]).  The reference's generators are

@@ -11,6 +11,7 @@ What is captured (all on the shipped Fe2S2 problem, ci_space[:32], fixed-weight 
   eloc_rbm_flavours.npz         SIMPLE / REDUCE with RBMWavefunction(rbm_type = "tanh" / "pRBM" / "cos") (vmc/ansatz/rbm/rbm.py:199-211)
   eloc_spin_raising_fe2s2.npz   use_spin_raising (<S-S+> with the integrals of utils/pyscf_helper/operator.py:93-137): SIMPLE / REDUCE / SAMPLE_SPACE
                                 local_energy and total_energy's REDUCE + sample-space form (etot.py:93-142)
+  ansatz_helpers.npz            permute_sgn / constrain_make_charts of the compiled reference extension
   sampler_merge.npz             merge_rank_sample (cpp_src/tensor/cpu_tensor.cpp:537-556) and Sampler.gather_scatter_sample
                                 (vmc/sample.py:627-772) run by two gloo ranks, both `use_same_tree` settings
 Only DATA is written: inputs and the reference's outputs.
@@ -419,6 +420,22 @@ def section_gfmc(I, out_dir, branch):
     print("gfmc done; accept:", out["a_accept"], out["b_accept"], "clamped:", int(out["a_mask"].sum()), int(out["b_mask"].sum()))
 
 
+def section_helpers(mod, out_dir):
+    """The two ansatz-side helpers the drop-in also provides: permute_sgn (cpu_tensor.cpp:356, onstate.cpp:195) and
+    constrain_make_charts (cpu_tensor.cpp:558), run on the reference's compiled extension."""
+    g = torch.Generator().manual_seed(91)
+    out = {}
+    for sorb in (8, 40):
+        perms = torch.stack([torch.randperm(sorb, generator=g) for _ in range(6)] + [torch.arange(sorb)])
+        occ = (torch.rand(50, sorb, generator=g) < 0.5).long()
+        out[f"perm_{sorb}"], out[f"occ_{sorb}"] = perms.numpy(), occ.numpy()
+        out[f"sgn_{sorb}"] = np.stack([mod.permute_sgn(p.contiguous(), occ, sorb).numpy() for p in perms])
+    idx = torch.tensor([10, 6, 14, 9, 5, 13, 11, 7, 15, 15, 5, 10], dtype=torch.int64)
+    out["chart_idx"], out["charts"] = idx.numpy(), mod.constrain_make_charts(idx).numpy()
+    np.savez_compressed(f"{out_dir}/ansatz_helpers.npz", **out)
+    print("helpers done:", out["sgn_40"].shape, out["charts"].shape)
+
+
 def section_merge(mod, out_dir, samp, stats):
     out = dict(samp)
     # merge_rank_sample on its own: three "ranks" with overlapping determinants
@@ -450,6 +467,8 @@ def main():
         section_rbm_flavours(I, a.out)
     if "eloc" in only or "spin" in only:
         section_spin_raising(I, a.out)
+    if "eloc" in only or "helpers" in only:
+        section_helpers(mod, a.out)
     if "dist" in only:
         branch, samp, stats = section_dist(a.scratch, a.out)
         section_gfmc(I, a.out, branch)

@@ -158,7 +158,7 @@ def test_dropin_matches_the_reference_api_surface():
     from pynqs_amd.dropin.libs import C_extension as drop
 
     api = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c_extension_api.json")))
-    out_of_path = {"MCMC_sample", "mps_vbatch", "permute_sgn", "convert_sites", "constrain_make_charts"}
+    out_of_path = {"MCMC_sample", "mps_vbatch", "convert_sites"}
     for name, spec in api["functions"].items():
         assert hasattr(drop, name), name
         fn = getattr(drop, name)
@@ -181,3 +181,25 @@ def test_dropin_matches_the_reference_api_surface():
             assert hasattr(getattr(drop, cls), m), (cls, m)
     for attr in api["attributes"]:
         assert isinstance(getattr(drop, attr), int), attr
+
+
+def test_ansatz_side_helpers_match_the_reference_extension():
+    """permute_sgn (cpu_tensor.cpp:356 -> onstate.cpp:195) and constrain_make_charts (cpu_tensor.cpp:558): plain tensor algebra in the
+    drop-in (the reference's autoregressive ansaetze call them), against outputs of the compiled reference extension
+    (tests/golden/ansatz_helpers.npz)."""
+    import numpy as np
+    import torch
+
+    from conftest import golden
+    from pynqs_amd.dropin.libs import C_extension as drop
+
+    d = golden("ansatz_helpers.npz")
+    for sorb in (8, 40):
+        occ = torch.from_numpy(d[f"occ_{sorb}"])
+        for perm, ref in zip(d[f"perm_{sorb}"], d[f"sgn_{sorb}"]):
+            got = drop.permute_sgn(torch.from_numpy(perm), occ, sorb)
+            assert got.dtype == torch.float64 and np.array_equal(got.numpy(), ref)
+    assert drop.permute_sgn(torch.arange(8), torch.zeros((0, 8), dtype=torch.int64), 8).shape == (0,)
+    got = drop.constrain_make_charts(torch.from_numpy(d["chart_idx"]))
+    assert got.dtype == torch.float64 and np.array_equal(got.numpy(), d["charts"])
+    assert drop.constrain_make_charts(torch.zeros(0, dtype=torch.int64)).shape == (0, 4)
