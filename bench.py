@@ -282,18 +282,33 @@ class SampleSpaceFused(Workload):
         self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
         self.dev, self.path, self.kernel = dev, "plan", "eloc_sample_space_filtered_kernel"
         self.bound, self.pmc_name = "valu", f"{tag}_eloc_sample_space"
+        # the same choice pynqs_amd.energy.local_energy makes: walk the table (work ~ walkers x keys) or the excitation lists (~ walkers x ncomb)
+        from pynqs_amd import energy as E_
+
+        self.key_major = E_._key_major(nk, sorb, noA, noB)
+        if self.key_major:
+            self.kernel, self.pmc_name = "eloc_sample_space_keys_kernel", f"{tag}_eloc_sample_space_keys"
         self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered; HBM traffic is "
                               "negligible and the kernel is bound by vector-ALU instruction issue (see valu_instructions_per_launch: ~1.5 wave64 instructions per column incl. the per-walker set-up and the evaluation of the candidates)")
         self.stats = None
+
+    def launch_eloc(self, st):
+        """the fused SAMPLE_SPACE local energy: key-major or column-major, the choice pynqs_amd.energy.local_energy makes"""
+        if self.key_major:
+            keys = self.lut.bra_key
+            return self.lib.pynqs_eloc_sample_space_keys(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB, self.plan.data_ptr(),
+                                                         keys.data_ptr(), keys.size(0), self.lut.wf_value.data_ptr(), 1, 0, self.eloc.data_ptr(),
+                                                         self.psi0.data_ptr(), st.cuda_stream)
+        ht = self.lut.hashtable
+        return self.lib.pynqs_eloc_sample_space_hash(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
+                                                     self.plan.data_ptr(), ht.table.data_ptr(), ht.nkeys, self.lut.wf_value.data_ptr(), 1,
+                                                     self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
 
     def step(self):
         st = torch.cuda.current_stream(self.dev)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        ht = self.lut.hashtable
-        rc = self.lib.pynqs_eloc_sample_space_hash(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
-                                                   self.plan.data_ptr(), ht.table.data_ptr(), ht.nkeys, self.lut.wf_value.data_ptr(), 1,
-                                                   self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
+        rc = self.launch_eloc(st)
         e1.record(st)
         self.N.check(rc, "pynqs_eloc_sample_space")
         # <E_loc>, variance: one packed all-reduce over the ranks (RCCL), no barrier
@@ -453,10 +468,7 @@ class VmcStep(SampleSpaceFused):
         st = torch.cuda.current_stream(self.dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record(st)
-        ht = self.lut.hashtable
-        rc = self.lib.pynqs_eloc_sample_space_hash(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB,
-                                                   self.plan.data_ptr(), ht.table.data_ptr(), ht.nkeys, self.lut.wf_value.data_ptr(), 1,
-                                                   self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
+        rc = self.launch_eloc(st)
         ev[1].record(st)
         self.N.check(rc, "pynqs_eloc_sample_space")
         from pynqs_amd.distributed import get_world_size

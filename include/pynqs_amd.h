@@ -150,6 +150,17 @@ int pynqs_eloc_sample_space_hash_flip(const uint64_t *bra, int64_t nbatch, int s
                                       const void *plan, const void *table, int64_t nkeys, const double *wf,
                                       int wf_is_complex, const double *psi0, double *out, void *stream);
 
+/* ---- SAMPLE_SPACE local energy, key-major (kernels_eloc_keys.hip): the same sum as pynqs_eloc_sample_space -- vmc/energy/eloc.py:326-401,
+ * psi(x') from the table of the sample space, 0 outside it -- computed by walking the TABLE: every key within a double excitation of
+ * the walker (popcount(x ^ key) <= 4) contributes <x|H|key> psi(key), evaluated from the two bit patterns.  Work per walker is nkeys
+ * instead of ncomb: the entry for large orbital spaces (ncomb ~ sorb^4) and for small tables.
+ *   keys uint64[nkeys][len] in ANY order (no sorting, no hash table), nkeys < 2^27; wf double[nkeys] or complex double[nkeys][2].
+ *   flip = 0: eloc[x] = sum / psi(x), psi0[x] (OUTPUT) = psi(x) = the table value of the key equal to x, 0 if there is none;
+ *   flip = 1: the projected form's partner sum (flip.py:322-418): eloc[x] = sum_x' <x|H|x'> eta_m(x') psi(flip x') / psi0[x], psi0 INPUT. */
+int pynqs_eloc_sample_space_keys(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                                 const uint64_t *keys, int64_t nkeys, const double *wf, int wf_is_complex, int flip, double *eloc,
+                                 double *psi0, void *stream);
+
 /* ---- duplicates among determinants, without a sort (`Func`, vmc/energy/flip.py:44-50: torch.unique(dim=0,
  * return_inverse=True) on the x' that reach the ansatz).  first[i] = smallest j with onv[j] == onv[i] (int32[n]);
  * the rows with first[i] == i are the distinct determinants in order of first appearance.  Deterministic.

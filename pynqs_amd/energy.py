@@ -182,6 +182,24 @@ def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi
             and x.is_cuda and WF_LUT.bra_key.is_cuda)
 
 
+# SAMPLE_SPACE: walk the table (key-major, pynqs_eloc_sample_space_keys: work ~ walkers x keys) or the excitation lists (column-major,
+# pynqs_eloc_sample_space[_hash]: work ~ walkers x ncomb)?  By measurement the key-major kernel wins while the table has
+# fewer than SS_KEYS_RATIO x ncomb keys (Fe2S2, ncomb 7876: crossover at ~1.3e4 keys; sorb 120 with 6.5e4 keys: 30x faster).  SS_KEYS = True / False (or PYNQS_SS_KEYS=1 / 0) forces one of them.
+SS_KEYS: Optional[bool] = None
+SS_KEYS_RATIO = 1.0
+
+
+def _key_major(nkeys: int, sorb: int, noa: int, nob: int) -> bool:
+    import os
+
+    if nkeys >= 1 << 27:
+        return False
+    force = SS_KEYS if SS_KEYS is not None else {"1": True, "0": False}.get(os.environ.get("PYNQS_SS_KEYS", ""), None)
+    if force is not None:
+        return force
+    return nkeys <= SS_KEYS_RATIO * (get_Num_SinglesDoubles(sorb, noa, nob) + 1)
+
+
 def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[Tensor] = None, flip: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
     """(sum_k H_k t(x'_k) / t(x), t(x), second sum) with t = the table values `wf` (default: WF_LUT's psi), all in ONE kernel pass
     per sum.  flip: also  sum_k H_k eta_m(x'_k) t(flip(x'_k)) / t(x)  (the projected form's partner term, one more pass)."""
@@ -198,6 +216,15 @@ def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[
     st = torch.cuda.current_stream(dev).cuda_stream
     ht = getattr(WF_LUT, "hashtable", None)
     lib = N.lib()
+    if _key_major(WF_LUT.bra_key.size(0), sorb, noa, nob):
+        keys = WF_LUT.bra_key
+        rc = lib.pynqs_eloc_sample_space_keys(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0), wf.data_ptr(),
+                                              int(cplx), 0, eloc.data_ptr(), psi0.data_ptr(), st)
+        if rc == 0 and flip:
+            rc = lib.pynqs_eloc_sample_space_keys(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0),
+                                                  wf.data_ptr(), int(cplx), 1, part.data_ptr(), psi0.data_ptr(), st)
+        N.check(rc, "pynqs_eloc_sample_space_keys")
+        return eloc, psi0, part
     if ht is not None:  # 1-2 probes per x' instead of log2(nkeys) dependent ones
         rc = lib.pynqs_eloc_sample_space_hash(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
                                               ht.nkeys, wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)

@@ -215,3 +215,60 @@ def test_spin_raising_matches_reference_python(env, fused):
         np.testing.assert_allclose(sl.cpu().numpy(), s["sloc_etot_reduce"], rtol=0, atol=TOL)
     finally:
         energy.FUSED, energy.FUSED_RBM = old
+
+
+@pytest.mark.parametrize("key_major", [True, False])
+def test_sample_space_kernels_key_major_and_column_major(env, key_major):
+    """The two fused SAMPLE_SPACE kernels -- walking the table (pynqs_eloc_sample_space_keys) or the excitation lists
+    (pynqs_eloc_sample_space[_hash][_flip]) -- forced in turn (the energy layer otherwise picks by table size against ncomb):
+    every projected / multi-psi / complex sample-space fixture, <S-S+>, and random 1-3-word systems with and without hits."""
+    energy, pf, T, dev = env["energy"], env["pf"], env["T"], env["dev"]
+    old = energy.SS_KEYS
+    energy.SS_KEYS = key_major
+    try:
+        for name in ("ss_flip", "ss_flip_c", "ss_multi", "ss_flip_multi", "ss_flip_multi_c"):
+            key, dt, kw = CASES[name]
+            _check(_le(env, env[key], dt, True, **kw(env)), env["d"], name)
+        s = golden("eloc_spin_raising_fe2s2.npz")
+        lut = pf.WavefunctionLUT(T(s["lut_keys"]), T(s["lut_wf"]), 40, device=dev)
+        ab = lambda x, func: pf.ansatz_batch(func, x, 100000, 40, dev, torch.double)  # noqa: E731
+        e, sl, p, _ = energy.local_energy(env["x"], env["h1e"], env["h2e"], env["rbm"], ab, *SYS, use_spin_raising=True, h1e_spin=T(s["h1e_spin"]),
+                                          h2e_spin=T(s["h2e_spin"]), use_sample_space=True, WF_LUT=lut, index=(0, 32))
+        np.testing.assert_allclose(e.cpu().numpy(), s["eloc_ss"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(sl.cpu().numpy(), s["sloc_ss"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(p.cpu().numpy(), s["psi_ss"], rtol=1e-12)
+        for args in ((40, 5, 300, True), (72, 6, 200, True), (136, 4, 3000, True), (72, 6, 300, False)):
+            test_spin_flip_kernel_all_filter_levels(*args)
+    finally:
+        energy.SS_KEYS = old
+
+
+def test_key_major_kernel_edge_cases(env):
+    """pynqs_eloc_sample_space_keys: unsorted keys, walkers that are not in the table (psi(x) = 0: E_loc is inf / nan as in the
+    reference's division), a number of walkers that does not fill the last wave, a table of one key."""
+    from pynqs_amd import C_extension as cx, _native as N
+
+    dev = env["dev"]
+    x = env["x"][:13].contiguous()
+    keys = torch.cat([env["x"][5:32], env["x"][:3]]).contiguous()  # unsorted; walkers 3, 4 are missing
+    wf = torch.rand(keys.size(0), dtype=torch.float64, device=dev) + 0.5
+    plan = cx.plan_for(env["h1e"], env["h2e"], 40, dev)
+    e = torch.empty(13, dtype=torch.float64, device=dev); p0 = torch.empty(13, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    N.check(N.lib().pynqs_eloc_sample_space_keys(x.data_ptr(), 13, 40, 30, 15, 15, plan.data_ptr(), keys.data_ptr(), keys.size(0), wf.data_ptr(), 0, 0,
+                                                 e.data_ptr(), p0.data_ptr(), st), "keys")
+    comb, hm = cx.get_comb_hij_fused(x, env["h1e"], env["h2e"], 40, 30, 15, 15)
+    table = {bytes(k.cpu().numpy().tobytes()): float(v) for k, v in zip(keys, wf)}
+    psi = torch.tensor([[table.get(bytes(c.cpu().numpy().tobytes()), 0.0) for c in row] for row in comb[:, :, :8]], dtype=torch.float64, device=dev)
+    want0 = psi[:, 0]
+    assert torch.equal(p0, want0) and float(p0[3]) == 0.0 and float(p0[4]) == 0.0
+    with np.errstate(all="ignore"):
+        want = ((hm * psi).sum(1) / want0).cpu().numpy()
+    got = e.cpu().numpy()
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=0, atol=TOL)
+    assert not np.isfinite(got[~ok]).any() and (~ok).sum() == 2
+    one = keys[:1].contiguous()
+    N.check(N.lib().pynqs_eloc_sample_space_keys(x.data_ptr(), 13, 40, 30, 15, 15, plan.data_ptr(), one.data_ptr(), 1, wf.data_ptr(), 0, 0,
+                                                 e.data_ptr(), p0.data_ptr(), st), "keys")
+    assert int((p0 != 0).sum()) == 1  # only the walker equal to that key (x[5]) has psi(x) != 0

@@ -14,7 +14,7 @@ x = torch.from_numpy(d["ci_space"][:n].copy()).to(dev)
 g = torch.Generator(device="cpu").manual_seed(5)
 comb, _ = cx.get_comb_tensor(x[:256].contiguous(), 40, 30, 15, 15)
 connected = comb.reshape(-1, 8)[torch.randperm(comb.size(0) * comb.size(1), generator=g)[:200_000].to(dev)]
-for logk in (14, 16, 17, 18, 19, 20, 22):
+for logk in (10, 12, 13, 14, 16, 17, 18, 19, 20, 22):
     K = 1 << logk
     occ = torch.zeros((K, 40), dtype=torch.uint8)
     for s in (0, 1):
@@ -30,17 +30,21 @@ for logk in (14, 16, 17, 18, 19, 20, 22):
     torch.cuda.synchronize()
     build_ms = (time.perf_counter() - t0) / 3 * 1e3
     f = lambda: energy.local_energy(x, h1e, h2e, None, None, 40, 30, 15, 15, WF_LUT=lut, use_sample_space=True)
-    f(); torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(10):
-        e = f()[0]
-    b.record(); torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 10
+    times = {}
+    for mode in (False, True):  # column-major (filter first), key-major
+        energy.SS_KEYS = mode
+        f(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            e = f()[0]
+        b.record(); torch.cuda.synchronize()
+        times[mode] = a.elapsed_time(b) / 10
+    ms = times[False]
     # parity of the first 8 walkers against the CPU oracle on the same (sorted) table
     e_ref, _ = O.eloc_sample_space(d["ci_space"][:8].copy(), d["h1e"], d["h2e"], 40, 30, 15, 15,
                                    lut.bra_key.cpu().numpy(), lut.wf_value.cpu().numpy())
     err = float(np.abs(e[:8].cpu().numpy() - e_ref).max())
     assert err < 1e-8, err
-    print(f"keys 2^{logk} ({keys.size(0)}): {ms:.3f} ms per 8192 walkers = {n / ms * 1e3:.3e} E_loc/s   (max |dE| vs oracle on 8 walkers {err:.1e}); table build (sort + hash + filters) {build_ms:.2f} ms", flush=True)
+    print(f"keys 2^{logk} ({keys.size(0)}): column-major {ms:.3f} ms, key-major {times[True]:.3f} ms per 8192 walkers   (key-major: max |dE| vs oracle on 8 walkers {err:.1e}); table build (sort + hash + filters) {build_ms:.2f} ms", flush=True)
     del lut, keys, wf
