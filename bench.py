@@ -288,8 +288,12 @@ class SampleSpaceFused(Workload):
         self.key_major = E_._key_major(nk, sorb, noA, noB)
         if self.key_major:
             self.kernel, self.pmc_name = "eloc_sample_space_keys_kernel", f"{tag}_eloc_sample_space_keys"
-        self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered; HBM traffic is "
-                              "negligible and the kernel is bound by vector-ALU instruction issue (see valu_instructions_per_launch: ~1.5 wave64 instructions per column incl. the per-walker set-up and the evaluation of the candidates)")
+            self.roofline_note = ("key-major kernel: the table is walked instead of the excitation lists (work ~ walkers x keys, not walkers x ncomb); "
+                                  "popcount(x ^ key) <= 4 decides per pair, the few keys within a double excitation are evaluated from the bit patterns; "
+                                  "bound by vector-ALU instruction issue, HBM traffic negligible")
+        if not self.key_major:
+            self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered; HBM traffic is "
+                                  "negligible and the kernel is bound by vector-ALU instruction issue (see valu_instructions_per_launch: ~1.5 wave64 instructions per column incl. the per-walker set-up and the evaluation of the candidates)")
         self.stats = None
 
     def launch_eloc(self, st):
