@@ -98,10 +98,15 @@ def test_reduce_compaction_is_exact(env):
         assert torch.equal(counts, keep.sum(1))
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, "keys", False])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_sample_space_matches_reference_python(env, fused, cplx):
+    """fused True: the column-major kernel (excitation lists against the table), "keys": the key-major kernel (the table against the
+    walkers), False: the reference's tensor algebra."""
     d, energy = env["d"], env["energy"]
+    old_keys = energy.SS_KEYS
+    energy.SS_KEYS = fused == "keys"
+    fused = bool(fused)
     keys = torch.from_numpy(d["psi_lut_keys"]).to(env["dev"])
     wf = torch.from_numpy(d["psi_lut_c" if cplx else "psi_lut"]).to(env["dev"])
     lut = env["pf"].WavefunctionLUT(keys, wf, 40, device=env["dev"])
@@ -111,6 +116,7 @@ def test_sample_space_matches_reference_python(env, fused, cplx):
         eloc, _, psi, _ = _le(env, WF_LUT=lut, use_sample_space=True, index=(0, 32), dtype=torch.complex128 if cplx else torch.double)
     finally:
         energy.FUSED = old
+        energy.SS_KEYS = old_keys
     sfx = "_c" if cplx else ""
     np.testing.assert_allclose(eloc.cpu().numpy(), d["eloc_sample_space" + sfx], rtol=0, atol=TOL)
     np.testing.assert_allclose(psi.cpu().numpy(), d["psi_sample_space" + sfx], rtol=1e-14)
@@ -329,7 +335,8 @@ def _excite(rng, words, sorb, count, singles):
 @pytest.mark.parametrize("sorb,no,nkeys,use_hash", [(40, 5, 150, True), (40, 5, 200, True), (72, 6, 150, True), (72, 6, 200, True),
                                                     (136, 4, 3000, True), (136, 4, 5000, True), (40, 5, 300_000, True),
                                                     (40, 5, 200, False), (136, 4, 3000, False)])
-def test_sample_space_kernel_filter_levels(sorb, no, nkeys, use_hash):
+@pytest.mark.parametrize("key_major", [False, True])
+def test_sample_space_kernel_filter_levels(sorb, no, nkeys, use_hash, key_major):
     """The fused SAMPLE_SPACE kernel with its candidate filters (Zobrist hash in LDS; second level in global memory
     when the first has < 6 bits per key: 200 and 5000 keys here, 150 and 3000 keys take the one-level kernel), without
     them, and with the sorted-key search, against the oracle, on sample spaces that hold the walkers, singles and doubles of them, and unrelated determinants."""
@@ -360,8 +367,12 @@ def test_sample_space_kernel_filter_levels(sorb, no, nkeys, use_hash):
     finally:
         pf.USE_HASH = old_flag
     assert (lut.hashtable is not None) == use_hash
-    e, _, p0, _ = energy.local_energy(tb(x), torch.from_numpy(h1).to(dev), torch.from_numpy(h2).to(dev), None, None, sorb, 2 * no, no, no,
-                                      WF_LUT=lut, use_sample_space=True, dtype=torch.complex128)
+    old_keys, energy.SS_KEYS = energy.SS_KEYS, key_major  # the column-major kernels with their filters, or the key-major kernel on the same tables
+    try:
+        e, _, p0, _ = energy.local_energy(tb(x), torch.from_numpy(h1).to(dev), torch.from_numpy(h2).to(dev), None, None, sorb, 2 * no, no, no,
+                                          WF_LUT=lut, use_sample_space=True, dtype=torch.complex128)
+    finally:
+        energy.SS_KEYS = old_keys
     e_ref, p_ref = O.eloc_sample_space(x.view(np.uint8).reshape(n, 8 * L), h1, h2, sorb, 2 * no, no, no, lut.bra_key.cpu().numpy(),
                                        lut.wf_value.cpu().numpy())
     np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
