@@ -12,8 +12,8 @@
 //     a time, all lanes busy (kernels_eloc.hip's scheme);
 //   - evaluation: holes = (x ^ y) & x, particles = (x ^ y) & y; degree, spin sectors, orbitals by ctz / clz; the matrix element from
 //     the integral plan with the indices the excitation tables would have produced (detcore.h: build_walker_tables) and the same sign
-//     rules (plan_dev.h: finish_double); singles add their nele terms from the walker's occupied list in LDS; <x|H|x> is computed once
-//     per wave and walker;
+//     rules (plan_dev.h: finish_double); singles add their nele terms from the walker's occupied list in LDS; <x|H|x> is computed by the
+//     wave that meets the key equal to x, when it meets it;
 //   - the keys need not be sorted and no hash table is involved; psi(x) is the table value of the key equal to x (0 if x is not in S).
 // flip: the projected form's partner sum (flip.py:322-418): sum_{x'} <x|H|x'> eta_m(x') psi(flip x') -- the key y stands for x' = flip(y).
 #include "detcore.h"
@@ -78,8 +78,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
   constexpr int W = kKeysWalkers, NW = kBlock / 64;
   __shared__ uint64_t xs[NW][W][LEN];
   __shared__ uint8_t occ[NW][W][192];
-  __shared__ double hdiag[NW][W];
-  __shared__ uint32_t queue[NW][2][kKeysQueue];  // [0]: doubles and the walker itself, [1]: singles (popcount(x ^ y) == 2)
+  __shared__ uint32_t queue[NW][2][kKeysQueue];  // [0]: doubles (popcount(x ^ y) == 4), [1]: singles (== 2)
   __shared__ uint64_t qkeys[NW][2][kKeysQueue][LEN];  // the parked determinant itself (x' = the key, or its spin-flip partner): the
                                                        // evaluation then has ONE memory round trip (integral and psi together)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,28 +105,29 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
     if (!valid) nocc[w] = 0;  // (no <x|H|x> for the padding walkers: their "orbitals" lie outside the plan)
   }
   __builtin_amdgcn_wave_barrier();
-  {
+  // <x|H|x> of the wave's walker w, by the whole wave, when (and where) the key equal to x turns up: once per walker over the whole
+  // grid -- computed up front in every workgroup it cost sorb 184 (4278 terms per walker) a third of the kernel.
+  // The nocc (nocc + 1) / 2 terms h(p,p), <pq||pq> (q < p) are dealt over the lanes: independent loads, one round trip per 64 terms.
+  auto diagonal = [&](int w) -> double {
     const double *__restrict__ D1 = plan + pl.offD1;
     const double *__restrict__ D2 = plan + pl.offD2;
+    double s = 0.0;
+    int no = 0;
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-      // the nocc (nocc + 1) / 2 terms h(p,p), <pq||pq> (q < p) dealt over the lanes: independent loads, one round trip per 64 terms
-      double s = 0.0;
-      const int nterms = nocc[w] * (nocc[w] + 1) / 2;
-      for (int t = lane; t < nterms; t += 64) {
-        int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (a * (a + 1) / 2 > t) --a;
-        while ((a + 1) * (a + 2) / 2 <= t) ++a;
-        const int pos = t - a * (a + 1) / 2;
-        const uint32_t pa = occ[wave][w][a];
-        s += pos == 0 ? D1[pa] : D2[pa * (uint32_t)sorb + occ[wave][w][pos - 1]];
-      }
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-      if (lane == 0) hdiag[wave][w] = s;
+    for (int i = 0; i < LEN; ++i) no += __popcll(xs[wave][w][i]);
+    const int nterms = no * (no + 1) / 2;
+    for (int t = lane; t < nterms; t += 64) {
+      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (a * (a + 1) / 2 > t) --a;
+      while ((a + 1) * (a + 2) / 2 <= t) ++a;
+      const int pos = t - a * (a + 1) / 2;
+      const uint32_t pa = occ[wave][w][a];
+      s += pos == 0 ? D1[pa] : D2[pa * (uint32_t)sorb + occ[wave][w][pos - 1]];
     }
-  }
-  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    return s;
+  };
 
   double are[W], aim[W];
 #pragma unroll
@@ -163,15 +163,8 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
         nh += __popcll(hx[i]); np += __popcll(py[i]);
         nha += __popcll(hx[i] & 0x5555555555555555ull); npa += __popcll(py[i] & 0x5555555555555555ull);
       }
-      if (nh == np && nha == npa && (S == 1 ? nh == 1 : (nh == 0 || nh == 2))) {
-        if (S == 0 && nh == 0) {
-          h = hdiag[wave][w];
-          if (!flip) {
-            double *__restrict__ out = psi0 + (CPLX ? 2 : 1) * (wbase + w);
-            if constexpr (CPLX) { out[0] = wf[2 * k]; out[1] = wf[2 * k + 1]; }
-            else out[0] = wf[k];
-          }
-        } else if (S == 1) {
+      if (nh == np && nha == npa && nh == (S == 1 ? 1 : 2)) {
+        if (S == 1) {
           const int ho = lowest_bit<LEN>(hx), q = lowest_bit<LEN>(py);
           const uint32_t K = (uint32_t)pl.K;
           const uint32_t pq = (((ho & 1) ? K : 0u) + ((uint32_t)ho >> 1)) * K + ((uint32_t)q >> 1);
@@ -269,7 +262,23 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
         // were loaded as 0 and a walker has more than four electrons, walkers past the batch's end are all-ones patterns)
         if (__ballot(cnt <= 4)) {  // (wave-uniform)
           const uint32_t code = ((uint32_t)w << 28) | minus | (uint32_t)k;
-          park(Doubles{}, code, y[u], in && (cnt == 4 || cnt == 0));
+          if (__ballot(in && cnt == 0)) {  // the key equal to the walker itself (keys are distinct: one lane, once per walker and launch)
+            const double hd = diagonal(w);
+            if (in && cnt == 0) {
+              double vr, vi = 0.0;
+              if constexpr (CPLX) { vr = wf[2 * k]; vi = wf[2 * k + 1]; }
+              else vr = wf[k];
+              const double hh = minus ? -hd : hd;
+              are[w] = fma(hh, vr, are[w]);
+              if constexpr (CPLX) aim[w] = fma(hh, vi, aim[w]);
+              if (!flip) {
+                double *__restrict__ out = psi0 + (CPLX ? 2 : 1) * (wbase + w);
+                out[0] = vr;
+                if constexpr (CPLX) out[1] = vi;
+              }
+            }
+          }
+          park(Doubles{}, code, y[u], in && cnt == 4);
           park(Singles{}, code, y[u], in && cnt == 2);
         }
       }
