@@ -184,7 +184,7 @@ def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi
 
 # SAMPLE_SPACE: walk the table (key-major, pynqs_eloc_sample_space_keys: work ~ walkers x keys) or the excitation lists (column-major,
 # pynqs_eloc_sample_space[_hash]: work ~ walkers x ncomb)?  By measurement the key-major kernel wins while the table has
-# fewer than SS_KEYS_RATIO x ncomb keys (Fe2S2, ncomb 7876: crossover at ~1.3e4 keys; sorb 120 with 6.5e4 keys: 30x faster).  SS_KEYS = True / False (or PYNQS_SS_KEYS=1 / 0) forces one of them.
+# fewer than SS_KEYS_RATIO x ncomb keys (Fe2S2, ncomb 7876: crossover at ~1.3e4 keys; sorb 120 with 6.5e4 keys: 50x faster).  SS_KEYS = True / False (or PYNQS_SS_KEYS=1 / 0) forces one of them.
 SS_KEYS: Optional[bool] = None
 SS_KEYS_RATIO = 1.0
 
