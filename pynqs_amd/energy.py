@@ -184,9 +184,9 @@ def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi
 
 # SAMPLE_SPACE: walk the table (key-major, pynqs_eloc_sample_space_keys: work ~ walkers x keys) or the excitation lists (column-major,
 # pynqs_eloc_sample_space[_hash]: work ~ walkers x ncomb)?  By measurement the key-major kernel wins while the table has
-# fewer than SS_KEYS_RATIO x ncomb keys (Fe2S2, ncomb 7876: crossover at ~1.3e4 keys; sorb 120 with 6.5e4 keys: 50x faster).  SS_KEYS = True / False (or PYNQS_SS_KEYS=1 / 0) forces one of them.
+# fewer than SS_KEYS_RATIO[words] x ncomb keys (Fe2S2, ncomb 7876: crossover at ~1.3e4 keys; sorb 120 with 6.5e4 keys: 50x faster).  SS_KEYS = True / False (or PYNQS_SS_KEYS=1 / 0) forces one of them.
 SS_KEYS: Optional[bool] = None
-SS_KEYS_RATIO = 1.0
+SS_KEYS_RATIO = {1: 1.0, 2: 2.5, 3: 1.5}  # by ONV words: measured seconds per column / seconds per (walker, key) pair of the two kernels
 
 
 def _key_major(nkeys: int, sorb: int, noa: int, nob: int) -> bool:
@@ -197,7 +197,7 @@ def _key_major(nkeys: int, sorb: int, noa: int, nob: int) -> bool:
     force = SS_KEYS if SS_KEYS is not None else {"1": True, "0": False}.get(os.environ.get("PYNQS_SS_KEYS", ""), None)
     if force is not None:
         return force
-    return nkeys <= SS_KEYS_RATIO * (get_Num_SinglesDoubles(sorb, noa, nob) + 1)
+    return nkeys <= SS_KEYS_RATIO[(sorb - 1) // 64 + 1] * (get_Num_SinglesDoubles(sorb, noa, nob) + 1)
 
 
 def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[Tensor] = None, flip: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
