@@ -53,6 +53,15 @@ def _stage(*ts: Tensor):
     return dev, [t if t.device == dev else t.to(dev) for t in ts], all_cpu
 
 
+def _ver(t: Tensor) -> int:
+    """version counter of a tensor (bumped by in-place writes); tensors created under torch.inference_mode() have none: -1, which
+    callers treat as "cannot be tracked" (no reuse of cached plans / lists for such tensors)"""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -126,7 +135,7 @@ def plan_for(h1e: Tensor, h2e: Tensor, sorb: int, device: "torch.device | None" 
 
     if sorb % 2 or sorb < 2:
         return None
-    ver = (h1e._version, h2e._version, h1e.data_ptr(), h2e.data_ptr())
+    ver = (_ver(h1e), _ver(h2e), h1e.data_ptr(), h2e.data_ptr())
     for i, (r1, r2, v, s, pl) in enumerate(_PLANS):
         if r1() is h1e and r2() is h2e and v == ver and s == sorb and (device is None or device.type != "cuda" or pl.device == device
                                                                        or h1e.device.type == "cuda"):
@@ -158,7 +167,7 @@ def integrals_f64(h1e: Tensor, h2e: Tensor) -> Tuple[Tensor, Tensor]:
 
     if h1e.dtype == torch.float64:
         return h1e, h2e
-    ver = (h1e._version, h2e._version, h1e.data_ptr(), h2e.data_ptr())
+    ver = (_ver(h1e), _ver(h2e), h1e.data_ptr(), h2e.data_ptr())
     for i, (r1, r2, v, a, b) in enumerate(_F64_COPIES):
         if r1() is h1e and r2() is h2e and v == ver:
             if i:
@@ -226,8 +235,8 @@ def _remember_comb(comb: Tensor, bra: Tensor, sorb: int, nele: int, noA: int, no
     global _last_comb
     import weakref
 
-    _last_comb = (weakref.ref(comb), comb.data_ptr(), comb._version, weakref.ref(bra), bra.data_ptr(), bra._version, sorb, nele, noA, noB) \
-        if comb.is_cuda and bra.is_cuda else None
+    _last_comb = (weakref.ref(comb), comb.data_ptr(), _ver(comb), weakref.ref(bra), bra.data_ptr(), _ver(bra), sorb, nele, noA, noB) \
+        if comb.is_cuda and bra.is_cuda and _ver(comb) >= 0 and _ver(bra) >= 0 else None
 
 
 def _is_last_comb(bra: Tensor, ket: Tensor, sorb: int, nele: int):
@@ -235,7 +244,7 @@ def _is_last_comb(bra: Tensor, ket: Tensor, sorb: int, nele: int):
     c = _last_comb
     if c is None or not REUSE_COMB or c[0]() is not ket or c[3]() is not bra:
         return None
-    if (ket.data_ptr(), ket._version, bra.data_ptr(), bra._version, sorb, nele) != (c[1], c[2], c[4], c[5], c[6], c[7]):
+    if (ket.data_ptr(), _ver(ket), bra.data_ptr(), _ver(bra), sorb, nele) != (c[1], c[2], c[4], c[5], c[6], c[7]):
         return None
     return c[8], c[9]
 

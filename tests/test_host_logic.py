@@ -203,3 +203,17 @@ def test_ansatz_side_helpers_match_the_reference_extension():
     got = drop.constrain_make_charts(torch.from_numpy(d["chart_idx"]))
     assert got.dtype == torch.float64 and np.array_equal(got.numpy(), d["charts"])
     assert drop.constrain_make_charts(torch.zeros(0, dtype=torch.int64)).shape == (0, 4)
+
+
+def test_tensors_without_version_counters_are_not_tracked():
+    """Plans and the last S+D list are cached by tensor identity + version counter; tensors created under torch.inference_mode()
+    have no counter (reading it raises): they count as untrackable instead of breaking the call."""
+    import torch
+
+    from pynqs_amd import C_extension as cx
+
+    with torch.inference_mode():
+        t = torch.zeros(4)
+    assert cx._ver(t) == -1 and cx._ver(torch.zeros(4)) == 0
+    cx._remember_comb(t, t, 8, 4, 2, 2)  # CPU tensors: nothing is remembered, nothing raises
+    assert cx._is_last_comb(t, t, 8, 4) is None
