@@ -509,7 +509,10 @@ class CRBMTable:
         self.buf = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
         N.check(N.lib().pynqs_crbm_table_build(st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr() if len(st) > 2 else None,
                                                self.sorb, self.nhidden, self.buf.data_ptr(), _stream(dev)), "crbm_table_build")
-        torch.cuda.current_stream(dev).synchronize()  # the (possibly temporary) parameter copies must outlive the build kernel
+        if any(a.device != dev for a in ts):
+            torch.cuda.current_stream(dev).synchronize()  # staging copies of host parameters must outlive the build kernel
+        # (device-side temporaries -- contiguous / view_as_real copies -- are freed in stream order: the caching allocator hands their
+        # memory only to later work on the same stream)
 
     def data_ptr(self) -> int:
         return self.buf.data_ptr()
