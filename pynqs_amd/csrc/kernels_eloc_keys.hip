@@ -252,14 +252,23 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
       const int64_t k = k0 + 64 * u + lane;
       const bool in = k < k_hi;
       const uint32_t minus = flip && spin_flip_ket_keys<LEN>(y[u]) ? (1u << 27) : 0u;  // y <- x' = flip(key); eta_m(x') = eta_m(key)
+      // the cheap test (spin sectors and hole / particle balance are checked by the evaluation): xor, popcount and, for the W walkers
+      // of a key together, one minimum and ONE wave-wide question -- a branch per (walker, key group) cost more than the popcounts.
+      // (Keys past the chunk's end were loaded as 0 and a walker has more than four electrons; walkers past the batch's end are
+      // all-ones patterns.)
+      int cnts_w[W], least = 1 << 20;
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        int cnt = 0;
+        int c = 0;
 #pragma unroll
-        for (int i = 0; i < LEN; ++i) cnt += __popcll(x[w][i] ^ y[u][i]);
-        // (the cheap test; spin sectors and hole / particle balance are checked by the evaluation)
-        // five vector instructions per (walker, key) on the common path: xor, popcount, one comparison (keys past the chunk's end
-        // were loaded as 0 and a walker has more than four electrons, walkers past the batch's end are all-ones patterns)
+        for (int i = 0; i < LEN; ++i) c += __popcll(x[w][i] ^ y[u][i]);
+        cnts_w[w] = c;
+        least = min(least, c);
+      }
+      if (!__ballot(least <= 4)) continue;  // (wave-uniform)
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const int cnt = cnts_w[w];
         if (__ballot(cnt <= 4)) {  // (wave-uniform)
           const uint32_t code = ((uint32_t)w << 28) | minus | (uint32_t)k;
           if (__ballot(in && cnt == 0)) {  // the key equal to the walker itself (keys are distinct: one lane, once per walker and launch)
