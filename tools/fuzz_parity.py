@@ -30,6 +30,7 @@ def walkers(n, sorb, noA, noB):
 
 
 t0, cases = time.time(), 0
+last_report = t0
 while time.time() - t0 < budget:
     sorb = int(rng.choice([4, 6, 8, 10, 12, 14, 16, 20, 24, 30, 36, 40, 66, 70, 130]))
     K = sorb // 2
@@ -139,4 +140,7 @@ while time.time() - t0 < budget:
         assert np.array_equal(res[0][1], res[1][1]), ("flip psi0", sorb, noA, noB, n)
         assert np.abs(res[0][0][ok] - res[1][0][ok]).max(initial=0.0) <= 1e-8 * max(1.0, np.abs(res[1][0][ok]).max(initial=0.0), scale), ("flip eloc", sorb, noA, noB, n)
     cases += 1
+    if time.time() - last_report > 60:  # (a GPU run that stays silent for minutes is taken to be hung)
+        last_report = time.time()
+        print(f"... {cases} systems after {last_report - t0:.0f} s", flush=True)
 print(f"fuzz ok: {cases} random systems in {time.time() - t0:.0f} s")
