@@ -104,9 +104,11 @@ struct LookupSink {
 // Sum of a workgroup's per-lane partial sums into acc[walker]: lanes (xor butterfly), then waves, in a fixed order.
 // (Which tile a wave gets is dynamic, so the order of the additions inside a lane, and with it the last bits of the
 // sum, can vary from run to run; with more than one chunk per walker the chunks meet through float atomics.)
+// With one chunk per walker the workgroup holds the whole sum and divides by psi(x) itself (psi0: written by this workgroup's
+// column-0 lane before the barrier below, or the caller's input in the flip form); with several chunks eloc_divide_kernel follows.
 template <bool CPLX, int NW>
 __device__ __forceinline__ void store_walker_sum(double re, double im, double (*red)[NW], uint32_t nchunks, uint64_t walker,
-                                                 double *__restrict__ acc) {
+                                                 double *__restrict__ acc, const double *psi0) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -119,8 +121,14 @@ __device__ __forceinline__ void store_walker_sum(double re, double im, double (*
     double sr = 0.0, si = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { sr += red[0][w]; si += red[1][w]; }
     if (nchunks == 1) {
-      if constexpr (CPLX) { acc[2 * walker] = sr; acc[2 * walker + 1] = si; }
-      else acc[walker] = sr;
+      // (another wave of this workgroup stored psi0 before the barrier above: read it at device scope, not through a line this CU
+      // may still hold from before)
+      if constexpr (CPLX) {
+        const double br = __hip_atomic_load(psi0 + 2 * walker, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double bi = __hip_atomic_load(psi0 + 2 * walker + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), d = br * br + bi * bi;
+        acc[2 * walker] = (sr * br + si * bi) / d;
+        acc[2 * walker + 1] = (si * br - sr * bi) / d;
+      } else acc[walker] = sr / __hip_atomic_load(psi0 + walker, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       if constexpr (CPLX) { atomicAdd(acc + 2 * walker, sr); atomicAdd(acc + 2 * walker + 1, si); }
       else atomicAdd(acc + walker, sr);
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_kernel(const uint64_
   const int nocc = build_walker_tables<LEN>(wk, p, L);  // ends with a barrier
   LookupSink<LEN, CPLX, HASH> sink{keys, nkeys, wf, psi0 + (CPLX ? 2 : 1) * walker, 0.0, 0.0, flip};
   visit_tiles<LEN, double, LookupSink<LEN, CPLX, HASH>, false>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
-  store_walker_sum<CPLX, kBlock / 64>(sink.re, sink.im, red, nchunks, walker, acc);
+  store_walker_sum<CPLX, kBlock / 64>(sink.re, sink.im, red, nchunks, walker, acc, psi0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
     }
   }
   cand.template flush<false>();
-  store_walker_sum<CPLX, BLOCK / 64>(cand.re, cand.im, red, nchunks, walker, acc);
+  store_walker_sum<CPLX, BLOCK / 64>(cand.re, cand.im, red, nchunks, walker, acc, psi0);
 }
 
 // Insert key i of the sorted key array: claim a slot by CAS on its index word, then write the key words
@@ -894,9 +902,11 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
 #undef PYNQS_SS_FILTERED2
 #undef PYNQS_SS_ARGS
 #undef PYNQS_SS_LAUNCH
-  const uint32_t g2 = (uint32_t)((nbatch + kBlock - 1) / kBlock);
-  if (wf_is_complex) hipLaunchKernelGGL((eloc_divide_kernel<true>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
-  else hipLaunchKernelGGL((eloc_divide_kernel<false>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
+  if (nchunks > 1) {  // (one chunk per walker: the kernel divided by psi(x) itself)
+    const uint32_t g2 = (uint32_t)((nbatch + kBlock - 1) / kBlock);
+    if (wf_is_complex) hipLaunchKernelGGL((eloc_divide_kernel<true>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
+    else hipLaunchKernelGGL((eloc_divide_kernel<false>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
+  }
   return check_launch("eloc_sample_space");
 }
 
