@@ -104,6 +104,13 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
     }
     if (!valid) nocc[w] = 0;  // (no <x|H|x> for the padding walkers: their "orbitals" lie outside the plan)
   }
+  uint32_t fx[W];  // 32-bit folds of the walkers (scalar)
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    fx[w] = 0;
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) fx[w] ^= (uint32_t)x[w][i] ^ (uint32_t)(x[w][i] >> 32);
+  }
   __builtin_amdgcn_wave_barrier();
   // <x|H|x> of the wave's walker w, by the whole wave, when (and where) the key equal to x turns up: once per walker over the whole
   // grid -- computed up front in every workgroup it cost sorb 184 (4278 terms per walker) a third of the kernel.
@@ -252,23 +259,28 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
       const int64_t k = k0 + 64 * u + lane;
       const bool in = k < k_hi;
       const uint32_t minus = flip && spin_flip_ket_keys<LEN>(y[u]) ? (1u << 27) : 0u;  // y <- x' = flip(key); eta_m(x') = eta_m(key)
-      // the cheap test (spin sectors and hole / particle balance are checked by the evaluation): xor, popcount and, for the W walkers
-      // of a key together, one minimum and ONE wave-wide question -- a branch per (walker, key group) cost more than the popcounts.
-      // (Keys past the chunk's end were loaded as 0 and a walker has more than four electrons; walkers past the batch's end are
-      // all-ones patterns.)
-      int cnts_w[W], least = 1 << 20;
+      // the cheap test (spin sectors and hole / particle balance are checked by the evaluation).  Common path: the 32-bit FOLD of a
+      // determinant (XOR of its 32-bit quarters): folding never increases a Hamming distance, so fold(x) ^ fold(y) with more than four
+      // bits set rules the pair out -- one xor and one popcount per (walker, key) whatever the word count, and for the W walkers of a
+      // key together one minimum and ONE wave-wide question (a branch per (walker, key group) cost more than the popcounts).
+      // Unrelated determinants differ in tens of bits and their folds in ~16 +- 3.  (Keys past the chunk's end were loaded as 0;
+      // walkers past the batch's end are all-ones patterns: whatever their folds say, the full comparison below rejects them.)
+      uint32_t fy = 0;
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) fy ^= (uint32_t)y[u][i] ^ (uint32_t)(y[u][i] >> 32);
+      int folded[W], least = 1 << 20;
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < LEN; ++i) c += __popcll(x[w][i] ^ y[u][i]);
-        cnts_w[w] = c;
-        least = min(least, c);
+        folded[w] = __popc(fx[w] ^ fy);
+        least = min(least, folded[w]);
       }
       if (!__ballot(least <= 4)) continue;  // (wave-uniform)
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        const int cnt = cnts_w[w];
+        if (!__ballot(folded[w] <= 4)) continue;  // (wave-uniform)
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) cnt += __popcll(x[w][i] ^ y[u][i]);
         if (__ballot(cnt <= 4)) {  // (wave-uniform)
           const uint32_t code = ((uint32_t)w << 28) | minus | (uint32_t)k;
           if (__ballot(in && cnt == 0)) {  // the key equal to the walker itself (keys are distinct: one lane, once per walker and launch)
