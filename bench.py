@@ -824,7 +824,7 @@ def main():
         for name, nw, steps in (("fe2s2_dropin", args.walkers, 2000), ("fe2s2_eloc_sample_space", args.walkers, 1000), ("fe2s2_eloc_rbm", args.walkers, 500),
                                 ("syn56_eloc_rbm", 4096, 200), ("syn120_dropin", 64, 500), ("syn184_dropin", 16, 200),
                                 ("syn120_eloc_sample_space", args.walkers, 10), ("syn120_eloc_rbm", 512, 10),
-                                ("syn184_eloc_sample_space", 1024, 5), ("syn184_eloc_rbm", 128, 3)):
+                                ("syn184_eloc_sample_space", args.walkers, 10), ("syn184_eloc_rbm", 128, 3)):
             try:
                 w2 = make_workload(name, nw, rank, dev, args.path)
                 el2, k2 = timed(w2, max(2, steps // 10), steps)
