@@ -186,7 +186,7 @@ def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi
 # pynqs_eloc_sample_space[_hash]: work ~ walkers x ncomb)?  By measurement the key-major kernel wins while the table has
 # fewer than SS_KEYS_RATIO[words] x ncomb keys (Fe2S2, ncomb 7876: crossover at ~1.3e4 keys; sorb 120 with 6.5e4 keys: 50x faster).  SS_KEYS = True / False (or PYNQS_SS_KEYS=1 / 0) forces one of them.
 SS_KEYS: Optional[bool] = None
-SS_KEYS_RATIO = {1: 1.5, 2: 3.5, 3: 2.0}  # by ONV words: measured seconds per column / seconds per (walker, key) pair of the two kernels
+SS_KEYS_RATIO = {1: 1.5, 2: 16.0, 3: 16.0}  # by ONV words, from the sweeps in profiles/r02_*_sample_space_vs_table_size.txt (multi-word: key-major won 11x even at 3.5 x ncomb keys)
 
 
 def _key_major(nkeys: int, sorb: int, noa: int, nob: int) -> bool:
