@@ -285,7 +285,7 @@ class SampleSpaceFused(Workload):
         # the same choice pynqs_amd.energy.local_energy makes: walk the table (work ~ walkers x keys) or the excitation lists (~ walkers x ncomb)
         from pynqs_amd import energy as E_
 
-        self.key_major = E_._key_major(nk, sorb, noA, noB)
+        self.key_major = E_.choose_sample_space_kernel(self.x, sorb, nele, noA, noB, self.plan, self.lut, self.lut.wf_value, True)
         if self.key_major:
             self.kernel, self.pmc_name = "eloc_sample_space_keys_kernel", f"{tag}_eloc_sample_space_keys"
             self.roofline_note = ("key-major kernel: the table is walked instead of the excitation lists (work ~ walkers x keys, not walkers x ncomb); "

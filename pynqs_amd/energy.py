@@ -186,10 +186,17 @@ def _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi
 # pynqs_eloc_sample_space[_hash]: work ~ walkers x ncomb)?  By measurement the key-major kernel wins while the table has
 # fewer than SS_KEYS_RATIO[words] x ncomb keys (Fe2S2, ncomb 7876: crossover at ~1.3e4 keys; sorb 120 with 6.5e4 keys: 50x faster).  SS_KEYS = True / False (or PYNQS_SS_KEYS=1 / 0) forces one of them.
 SS_KEYS: Optional[bool] = None
-SS_KEYS_RATIO = {1: 1.5, 2: 16.0, 3: 16.0}  # by ONV words, from the sweeps in profiles/r02_*_sample_space_vs_table_size.txt (multi-word: key-major won 11x even at 3.5 x ncomb keys)
+# (words of a determinant) -> (key-major below this many x ncomb keys, column-major above this many, ratio used when probing is off):
+# between the two the cost depends on how many keys lie within a double excitation of a walker (a CAS-like table is dense in them, a
+# table of samples is not), so the first call at a new (system, table size) times both kernels on up to 1024 walkers and remembers the
+# winner (profiles/r02_*_sample_space_vs_table_size.txt: sorb 56, sparse table: key-major wins up to 30 x ncomb; Fe2S2's CAS table: up to
+# 1.7 x ncomb; sorb 120 / 184: at every size tried).
+SS_KEYS_ZONE = {1: (0.75, 64.0, 1.5), 2: (16.0, 256.0, 16.0), 3: (16.0, 256.0, 16.0)}
+SS_AUTOTUNE = True
+_SS_CHOICE: dict = {}
 
 
-def _key_major(nkeys: int, sorb: int, noa: int, nob: int) -> bool:
+def _key_major(nkeys: int, sorb: int, noa: int, nob: int, probe: Optional[Callable[[], bool]] = None, tag=()) -> bool:
     import os
 
     if nkeys >= 1 << 27:
@@ -197,7 +204,71 @@ def _key_major(nkeys: int, sorb: int, noa: int, nob: int) -> bool:
     force = SS_KEYS if SS_KEYS is not None else {"1": True, "0": False}.get(os.environ.get("PYNQS_SS_KEYS", ""), None)
     if force is not None:
         return force
-    return nkeys <= SS_KEYS_RATIO[(sorb - 1) // 64 + 1] * (get_Num_SinglesDoubles(sorb, noa, nob) + 1)
+    ncomb = get_Num_SinglesDoubles(sorb, noa, nob) + 1
+    lo, hi, ratio = SS_KEYS_ZONE[(sorb - 1) // 64 + 1]
+    if nkeys <= lo * ncomb:
+        return True
+    if nkeys >= hi * ncomb:
+        return False
+    if probe is None or not SS_AUTOTUNE:
+        return nkeys <= ratio * ncomb
+    key = (sorb, noa, nob, (4 * nkeys).bit_length(), tag)  # table sizes in steps of sqrt(2)... of 2 with two guard bits: [2^k/4 steps]
+    if key not in _SS_CHOICE:
+        _SS_CHOICE[key] = bool(probe())
+    return _SS_CHOICE[key]
+
+
+def _launch_sample_space(key_major: bool, x, n, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx, flip, eloc, psi0, part, st) -> None:
+    lib = N.lib()
+    ht = getattr(WF_LUT, "hashtable", None)
+    if key_major:
+        keys = WF_LUT.bra_key
+        rc = lib.pynqs_eloc_sample_space_keys(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0), wf.data_ptr(),
+                                              int(cplx), 0, eloc.data_ptr(), psi0.data_ptr(), st)
+        if rc == 0 and flip:
+            rc = lib.pynqs_eloc_sample_space_keys(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0),
+                                                  wf.data_ptr(), int(cplx), 1, part.data_ptr(), psi0.data_ptr(), st)
+        N.check(rc, "pynqs_eloc_sample_space_keys")
+        return
+    if ht is not None:  # 1-2 probes per x' instead of log2(nkeys) dependent ones
+        rc = lib.pynqs_eloc_sample_space_hash(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
+                                              ht.nkeys, wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+        if rc == 0 and flip:
+            rc = lib.pynqs_eloc_sample_space_hash_flip(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
+                                                       ht.nkeys, wf.data_ptr(), int(cplx), psi0.data_ptr(), part.data_ptr(), st)
+    else:
+        rc = lib.pynqs_eloc_sample_space(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
+                                         WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
+        if rc == 0 and flip:
+            rc = lib.pynqs_eloc_sample_space_flip(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
+                                                  WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), psi0.data_ptr(), part.data_ptr(), st)
+    N.check(rc, "pynqs_eloc_sample_space")
+
+
+def choose_sample_space_kernel(x, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx) -> bool:
+    """True: key-major (walk the table), False: column-major (walk the excitation lists).  Clear cases by the table size against ncomb;
+    in between the two kernels are timed once on up to 1024 of the walkers and the result is remembered per (system, table-size bucket)."""
+    dev = x.device
+
+    def probe() -> bool:
+        m = min(x.size(0), 1024)
+        xs = x[:m].contiguous()
+        e = torch.empty(m, dtype=wf.dtype, device=dev)
+        p0 = torch.empty(m, dtype=wf.dtype, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        t = {}
+        for mode in (True, False):
+            _launch_sample_space(mode, xs, m, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx, False, e, p0, None, stream.cuda_stream)  # warm
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for _ in range(3):
+                _launch_sample_space(mode, xs, m, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx, False, e, p0, None, stream.cuda_stream)
+            b.record(stream)
+            b.synchronize()
+            t[mode] = a.elapsed_time(b)
+        return t[True] <= t[False]
+
+    return _key_major(WF_LUT.bra_key.size(0), sorb, noa, nob, probe, (bool(cplx), x.size(0) >= 1024))
 
 
 def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[Tensor] = None, flip: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
@@ -214,30 +285,8 @@ def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[
     psi0 = torch.empty(n, dtype=wf.dtype, device=dev)
     part = torch.empty(n, dtype=wf.dtype, device=dev) if flip else None
     st = torch.cuda.current_stream(dev).cuda_stream
-    ht = getattr(WF_LUT, "hashtable", None)
-    lib = N.lib()
-    if _key_major(WF_LUT.bra_key.size(0), sorb, noa, nob):
-        keys = WF_LUT.bra_key
-        rc = lib.pynqs_eloc_sample_space_keys(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0), wf.data_ptr(),
-                                              int(cplx), 0, eloc.data_ptr(), psi0.data_ptr(), st)
-        if rc == 0 and flip:
-            rc = lib.pynqs_eloc_sample_space_keys(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0),
-                                                  wf.data_ptr(), int(cplx), 1, part.data_ptr(), psi0.data_ptr(), st)
-        N.check(rc, "pynqs_eloc_sample_space_keys")
-        return eloc, psi0, part
-    if ht is not None:  # 1-2 probes per x' instead of log2(nkeys) dependent ones
-        rc = lib.pynqs_eloc_sample_space_hash(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
-                                              ht.nkeys, wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
-        if rc == 0 and flip:
-            rc = lib.pynqs_eloc_sample_space_hash_flip(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), ht.table.data_ptr(),
-                                                       ht.nkeys, wf.data_ptr(), int(cplx), psi0.data_ptr(), part.data_ptr(), st)
-    else:
-        rc = lib.pynqs_eloc_sample_space(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
-                                         WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), eloc.data_ptr(), psi0.data_ptr(), st)
-        if rc == 0 and flip:
-            rc = lib.pynqs_eloc_sample_space_flip(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), WF_LUT.bra_key.data_ptr(),
-                                                  WF_LUT.bra_key.size(0), wf.data_ptr(), int(cplx), psi0.data_ptr(), part.data_ptr(), st)
-    N.check(rc, "pynqs_eloc_sample_space")
+    key_major = choose_sample_space_kernel(x, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx)
+    _launch_sample_space(key_major, x, n, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx, flip, eloc, psi0, part, st)
     return eloc, psi0, part
 
 

@@ -272,3 +272,28 @@ def test_key_major_kernel_edge_cases(env):
     N.check(N.lib().pynqs_eloc_sample_space_keys(x.data_ptr(), 13, 40, 30, 15, 15, plan.data_ptr(), one.data_ptr(), 1, wf.data_ptr(), 0, 0,
                                                  e.data_ptr(), p0.data_ptr(), st), "keys")
     assert int((p0 != 0).sum()) == 1  # only the walker equal to that key (x[5]) has psi(x) != 0
+
+
+def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2):
+    """A table of 2.3 x ncomb keys (Fe2S2's whole CI space) is neither clearly small nor clearly large: the first call times both
+    kernels on the walkers at hand, remembers the winner for that (system, table-size bucket), and the energies match the oracle
+    whichever it was."""
+    from oracle import oracle as O
+
+    energy, pf, T, dev = env["energy"], env["pf"], env["T"], env["dev"]
+    keys = T(fe2s2["ci_space"])
+    g = torch.Generator().manual_seed(3)
+    wf = (torch.rand(keys.size(0), generator=g, dtype=torch.float64) + 0.2).to(dev)
+    lut = pf.WavefunctionLUT(keys, wf, 40, device=dev)
+    assert energy.SS_KEYS is None and energy.SS_AUTOTUNE
+    energy._SS_CHOICE.clear()
+    x = T(fe2s2["ci_space"][:96])
+    e, _, p0, _ = energy.local_energy(x, env["h1e"], env["h2e"], None, None, *SYS, WF_LUT=lut, use_sample_space=True)
+    assert len(energy._SS_CHOICE) == 1 and isinstance(next(iter(energy._SS_CHOICE.values())), bool)
+    e2, _, _, _ = energy.local_energy(x, env["h1e"], env["h2e"], None, None, *SYS, WF_LUT=lut, use_sample_space=True)
+    assert len(energy._SS_CHOICE) == 1  # remembered
+    e_ref, p_ref = O.eloc_sample_space(fe2s2["ci_space"][:96].copy(), fe2s2["h1e"], fe2s2["h2e"], 40, 30, 15, 15, lut.bra_key.cpu().numpy(),
+                                       lut.wf_value.cpu().numpy())
+    np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL)
+    np.testing.assert_allclose(e2.cpu().numpy(), e_ref, rtol=0, atol=TOL)
