@@ -274,7 +274,7 @@ def test_key_major_kernel_edge_cases(env):
     assert int((p0 != 0).sum()) == 1  # only the walker equal to that key (x[5]) has psi(x) != 0
 
 
-def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2):
+def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2, monkeypatch):
     """A table of 2.3 x ncomb keys (Fe2S2's whole CI space) is neither clearly small nor clearly large: the first call times both
     kernels on the walkers at hand, remembers the winner for that (system, table-size bucket), and the energies match the oracle
     whichever it was."""
@@ -285,6 +285,7 @@ def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2
     g = torch.Generator().manual_seed(3)
     wf = (torch.rand(keys.size(0), generator=g, dtype=torch.float64) + 0.2).to(dev)
     lut = pf.WavefunctionLUT(keys, wf, 40, device=dev)
+    monkeypatch.delenv("PYNQS_SS_KEYS", raising=False)
     assert energy.SS_KEYS is None and energy.SS_AUTOTUNE
     energy._SS_CHOICE.clear()
     x = T(fe2s2["ci_space"][:96])
