@@ -210,8 +210,8 @@ def _key_major(nkeys: int, sorb: int, noa: int, nob: int, probe: Optional[Callab
         return True
     if nkeys >= hi * ncomb:
         return False
-    if probe is None or not SS_AUTOTUNE or torch.cuda.is_current_stream_capturing():  # (a probe synchronises: not inside a graph capture)
-        return nkeys <= ratio * ncomb
+    if probe is None or not SS_AUTOTUNE or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return nkeys <= ratio * ncomb  # (a probe synchronises: never inside a graph capture)
     key = (sorb, noa, nob, (4 * nkeys).bit_length(), tag)  # table sizes in steps of sqrt(2)... of 2 with two guard bits: [2^k/4 steps]
     if key not in _SS_CHOICE:
         _SS_CHOICE[key] = bool(probe())
