@@ -10,11 +10,16 @@ spin-flip-projected and multi-psi variants (vmc/energy/flip.py).
 What differs is where the work happens (all on the MI355X, through pynqs_amd.C_extension / the C ABI):
   * enumeration and <x|H|x'> always come from the fused kernel (the reference's SIMPLE/REDUCE call the
     unfused pair get_comb_tensor + get_hij_torch, whose outputs are bit-identical to the fused call);
-  * SAMPLE_SPACE without spin-flip / multi-psi / spin-raising runs as ONE kernel
-    (pynqs_eloc_sample_space): enumerate, matrix element, table lookup and contraction, nothing materialised;
-  * REDUCE with eps_sample == 0 compacts the kept columns on chip (pynqs_reduce_count/emit) instead of
-    writing the whole (batch, ncomb) comb/Hmat and filtering afterwards.
-`FUSED = False` forces the generic tensor path everywhere (used by the tests to cross-check the fast paths).
+  * SAMPLE_SPACE (also its spin-flip projected, multi-psi and <S-S+> forms) runs as ONE kernel per sum, nothing materialised, in one
+    of two forms chosen per call (choose_sample_space_kernel): over the walker's excitation lists with a filter in front
+    (pynqs_eloc_sample_space[_hash]), or over the TABLE (pynqs_eloc_sample_space_keys: work ~ walkers x keys instead of walkers x ncomb,
+    the form for large orbital spaces);
+  * SIMPLE with an RBM ansatz (real parameters: rbm_type real / tanh / pRBM; complex parameters; cos) evaluates the amplitude ratios
+    inside the kernel (pynqs_eloc_rbm[_flavour], pynqs_eloc_crbm);
+  * REDUCE compacts the kept columns on chip (pynqs_reduce_count / _emit, and pynqs_reduce_sample for eps_sample > 0) instead of
+    writing the whole (batch, ncomb) comb / Hmat and filtering afterwards; the projected / multi-psi / <S-S+> factors are evaluated on
+    the kept records.
+`FUSED = False` (and FUSED_RBM / FUSED_SAMPLED) force the generic tensor path (used by the tests to cross-check the fast paths).
 """
 from __future__ import annotations
 
