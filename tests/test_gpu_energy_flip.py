@@ -298,3 +298,34 @@ def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2
     np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
     np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL)
     np.testing.assert_allclose(e2.cpu().numpy(), e_ref, rtol=0, atol=TOL)
+
+
+def test_fused_sample_space_accepts_the_reference_lut_class_shape(env):
+    """With the one-line change of INTEGRATION.md the tables handed to local_energy are the REFERENCE's WavefunctionLUT objects: sorted
+    keys, values, `sort`, `dtype` -- no hash table (USE_HASH = False there) and no `find`.  A stand-in with exactly those attributes
+    must take the fused kernels, all variants."""
+    energy, d = env["energy"], env["d"]
+
+    class RefShapedLUT:  # the attribute surface of utils/public_function.py:749-868
+        def __init__(self, lut):
+            self.sort, self.sorb = True, lut.sorb
+            self._bra_key, self._wf_value = lut.bra_key, lut.wf_value
+
+        bra_key = property(lambda self: self._bra_key)
+        wf_value = property(lambda self: self._wf_value)
+        dtype = property(lambda self: self._wf_value.dtype)
+
+        def lookup(self, onv):
+            raise AssertionError("the fused path must not call lookup()")
+
+    for name in ("ss_flip", "ss_multi", "ss_flip_multi_c"):
+        key, dt, kw = CASES[name]
+        k = kw(env)
+        k["WF_LUT"] = RefShapedLUT(k["WF_LUT"])
+        for mode in (True, False):
+            old = energy.SS_KEYS
+            energy.SS_KEYS = mode
+            try:
+                _check(_le(env, env[key], dt, True, **k), d, name)
+            finally:
+                energy.SS_KEYS = old
