@@ -236,6 +236,16 @@ class _SpinProjection:
     @property
     def eta(self) -> int:
         if self._eta is None:
+            # inside a PyNQS process that imports pynqs_amd.energy (one-line change) the run initialises PyNQS' own
+            # instance (utils/public_function.py:1017-1036): follow it instead of asking for a second init
+            import sys
+
+            host = getattr(sys.modules.get("utils.public_function"), "SpinProjection", None)
+            if host is not None and host is not self:
+                try:
+                    return int(host.eta)
+                except NotImplementedError:
+                    pass
             raise NotImplementedError("SpinProjection.init(N, S) has not been called")
         return self._eta
 

@@ -217,3 +217,30 @@ def test_tensors_without_version_counters_are_not_tracked():
     assert cx._ver(t) == -1 and cx._ver(torch.zeros(4)) == 0
     cx._remember_comb(t, t, 8, 4, 2, 2)  # CPU tensors: nothing is remembered, nothing raises
     assert cx._is_last_comb(t, t, 8, 4) is None
+
+
+def test_spin_projection_follows_the_host_programs_instance():
+    """With pynqs_amd.energy imported into a PyNQS process the run calls PyNQS' own SpinProjection.init (utils/public_function.py:1017-1036);
+    an uninitialised pynqs_amd instance reads eta from there."""
+    import sys
+    import types
+
+    import pytest
+
+    from pynqs_amd import public_function as pf
+
+    mine = pf._SpinProjection()
+    with pytest.raises(NotImplementedError):
+        mine.eta
+    host = types.ModuleType("utils.public_function")
+    host.SpinProjection = pf._SpinProjection()
+    sys.modules["utils.public_function"] = host
+    try:
+        with pytest.raises(NotImplementedError):
+            mine.eta  # the host's is not initialised either
+        host.SpinProjection.init(30, 1)
+        assert mine.eta == host.SpinProjection.eta == (-1) ** (15 - 1)
+        mine.init(30, 0)
+        assert mine.eta == -1  # its own initialisation wins
+    finally:
+        del sys.modules["utils.public_function"]
