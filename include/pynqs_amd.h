@@ -283,6 +283,64 @@ int pynqs_reduce_sample(const uint64_t *bra, int64_t nbatch, int sorb, int nele,
                         const double *walker_scale, uint64_t seed, int32_t *s_col, uint64_t *s_onv, void *s_h,
                         void *stream);
 
+/* ---- REDUCE front end in ONE launch (kernels_reduce_onepass.hip): vmc/energy/eloc.py:205-324 (_reduce_psi) + `Func`
+ * (vmc/energy/flip.py:29-63) + onv_to_tensor, i.e. everything between the walkers and the ansatz' forward:
+ *   - every column of a walker's row is enumerated once; |<x|H|x'>| >= eps is kept (eloc.py:297-298, 258-262);
+ *   - eps_sample > 0 (eloc.py:263-296): the sub-eps |H| are summed per tile in LDS, the N = eps_sample draws of
+ *     torch.multinomial are drawn over the tiles inside the kernel (counter-based generator, `seed`), and only the tiles
+ *     that received draws are enumerated a second time for the draws inside them; a column drawn c times carries the
+ *     weight (c / N) sign(H) S, S = sum of the row's sub-eps |H| (the same distribution as the reference's);
+ *   - every record's x' is looked up in the wave-function table (if one is given) and otherwise inserted into a
+ *     de-duplication hash table in the same pass; the first occurrence of a determinant gets the next row of the
+ *     DISTINCT list and writes its +1/-1 row (the ansatz' input, onv_to_tensor's layout) there.
+ * No host round trip: output space is a fixed-capacity segment per (walker, chunk) -- `fixed` slots with a fixed
+ * position per column for column 0, the singles and the unpaired doubles (slot = -1 in rec_col when not kept), then the
+ * kept doubles compacted in tile order (decoupled look-back in LDS, reproducible), then N slots per walker for the draws.
+ * Capacities are the caller's; what was NEEDED comes back in seg_count / counters, so that an overflow is detected (and
+ * the call repeated with larger buffers) without anything having been read back in between.
+ *
+ *   pynqs_reduce_onepass_geometry : [host] out[0] = segments (nbatch * chunks), out[1] = fixed slots per segment,
+ *                                   out[2] = bytes of the de-duplication table for `dedup_slots` slots of this sorb
+ *                                   (dedup_slots passed in out[2] on entry), out[3] = 1 if the fused form exists for
+ *                                   this system (LDS budget), else 0
+ *   pynqs_reduce_onepass          : the launch (memsets of the de-duplication table and counters included)
+ *   pynqs_reduce_contract         : eloc[x] = sum_records w A(x') / A(x) (divide = 1) or sum_records w A(x') (divide = 0) and
+ *                                   psi_x[x] = A(x), from the records (io->rec_w / srec_w: any weights in the records' slot
+ *                                   layout) and the values A of the distinct list (psi_unique) and of the table (psi_table);
+ *                                   one wave per walker, fixed order of additions.
+ * Record link: >= 0 slot of the de-duplication table (its row number is stored in the slot), <= -2 : table position
+ * -(link + 2) of the wave-function table, -1 : no amplitude (capacity overflow). */
+typedef struct pynqs_reduce_io {
+  int64_t cap_doubles;  /* in: compacted slots per segment after the fixed ones */
+  int64_t cap_unique;   /* in: rows of uniq_onv / uniq_pm1 */
+  int64_t dedup_slots;  /* in: power of two >= 2 * cap_unique */
+  int32_t *rec_col;     /* [segments][fixed + cap_doubles] column of the record, -1 = empty slot */
+  void *rec_w;          /* T, same shape: <x|H|x'> */
+  uint64_t *rec_onv;    /* same shape x len (may be NULL) */
+  int32_t *rec_link;    /* same shape */
+  int32_t *seg_count;   /* [segments] kept doubles of the segment (may exceed cap_doubles: overflow) */
+  int32_t *srec_col;    /* [nbatch][eps_sample]: drawn records (eps_sample > 0), -1 = unused slot */
+  void *srec_w;         /* T: (c / N) sign(H) S */
+  uint64_t *srec_onv;   /* may be NULL */
+  int32_t *srec_link;
+  double *row_sum;      /* [nbatch] S (may be NULL) */
+  void *dedup_table;    /* out[2] bytes from the geometry call */
+  uint64_t *uniq_onv;   /* [cap_unique][len] distinct determinants, order of first insertion */
+  void *uniq_pm1;       /* [cap_unique][sorb] +1/-1 rows, element type pm1_dtype (may be NULL) */
+  int32_t pm1_dtype;    /* PYNQS_F32 / PYNQS_F64 */
+  int32_t lut_is_hash;  /* reserved, must be 1 */
+  const void *lut_table;  /* pynqs_hash_build table of the wave-function keys, or NULL */
+  int64_t lut_nkeys;
+  int32_t *counters;    /* [4] out: distinct determinants needed, overflow bits (1 doubles, 2 table, 4 distinct list),
+                           largest seg_count, reserved */
+} pynqs_reduce_io;
+int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
+int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                         int dtype, double eps, int eps_sample, uint64_t seed, const pynqs_reduce_io *io, void *stream);
+int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
+                          const pynqs_reduce_io *io, const double *psi_unique, const double *psi_table, int psi_is_complex,
+                          int divide, double *eloc, double *psi_x, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,13 +200,14 @@ __global__ __launch_bounds__(kBlock) void onv_to_pm1_kernel(const uint64_t *__re
   if (e0 >= total) return;
   uint64_t w = e0 / (uint32_t)sorb;
   int o = (int)(e0 - w * (uint32_t)sorb);
+  // one load per determinant word the lane needs (the V elements of a lane lie in one word unless a row or word boundary cuts them)
   T v[V];
+  uint64_t word = bra[w * len + (o >> 6)];
 #pragma unroll
   for (int i = 0; i < V; ++i) {
-    const bool in = e0 + i < total;
-    const uint64_t word = in ? bra[w * len + (o >> 6)] : 0;
     v[i] = ((word >> (o & 63)) & 1ull) ? T(1) : T(-1);
     if (++o == sorb) { o = 0; ++w; }
+    if (i + 1 < V && (o & 63) == 0 && e0 + i + 1 < total) word = bra[w * len + (o >> 6)];
   }
   if (e0 + V <= total) {
     TV pack;

@@ -1,0 +1,876 @@
+// kernels_reduce_onepass.hip -- the REDUCE front end of the local energy in ONE launch: everything between the walkers and
+// the ansatz' forward (vmc/energy/eloc.py:205-324 _reduce_psi, `Func` of vmc/energy/flip.py:29-63, onv_to_tensor).
+//
+// Round 2 ran this as count -> host read-back -> emit (-> count_sums -> torch.multinomial -> draw) -> unique_insert ->
+// unique_first -> onv_to_pm1 plus ~80 small torch kernels, and enumerated every row two or three times.  Here one workgroup
+// owns a (walker, chunk) and
+//   phase A  visits every column once on the tile scheduler (plan_tiles.h).  Kept columns (|H| >= eps) become records:
+//            column 0, the singles and the few unpaired doubles have a FIXED slot each (they are produced by heavy tiles
+//            that must not hold anybody up); the kept doubles of a tile wait in the wave's LDS scratch until the tile is
+//            finished, get their place by a decoupled look-back over the tiles' counts in LDS (a wave never waits for more
+//            than the COUNT of an earlier tile, which is published before anything else), and are written in tile order:
+//            no atomics on the output position, no second pass, reproducible.  Sub-eps |H| are summed per tile into LDS.
+//   phase B  (eps_sample > 0) scans the tile sums, draws the N uniforms of the reference's torch.multinomial over the tiles
+//            (counter-based generator) and turns the per-tile draw counts into slot offsets -- all in LDS.
+//   phase C  re-visits only the tiles that received draws and draws inside them (the machinery of kernels_reduce_sample.hip).
+// Every record's determinant is looked up in the wave-function table (if given), else inserted into a de-duplication table;
+// the winner of a slot takes the next row of the distinct list and the wave writes its +1/-1 row (the ansatz' input).
+// A second, small kernel (reduce_contract_kernel) forms E_loc from the records and the amplitudes of the distinct rows.
+#include "detcore.h"
+#include "launch.h"
+#include "plan.h"
+#include "plan_dev.h"
+#include "plan_tiles.h"
+
+namespace pynqs {
+
+constexpr uint32_t kStatP = 0x80000000u;  // look-back status: inclusive prefix available
+constexpr uint32_t kStatA = 0x40000000u;  //                   this tile's count available
+constexpr uint32_t kStatMask = 0x3fffffffu;
+constexpr int kFixedHead = 8;             // slot 0: column 0; slots 1..6: unpaired doubles; 7: unused
+constexpr int kOneTileCols = 128 * PYNQS_U;
+constexpr uint32_t kProbeLimit = 512;     // a de-duplication table at most half full never needs that many
+
+__device__ __forceinline__ uint64_t op_mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double op_scan(double v, int lane) {  // inclusive, lanes 0.. contiguous
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t op_wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__device__ __forceinline__ double op_wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// ---- outputs (device pointers, by value) -------------------------------------------------------------------------
+template <typename T>
+struct OnepassOut {
+  int32_t *rec_col;
+  T *rec_w;
+  uint64_t *rec_onv;
+  int32_t *rec_link;
+  int32_t *seg_count;
+  int32_t *srec_col;
+  T *srec_w;
+  uint64_t *srec_onv;
+  int32_t *srec_link;
+  double *row_sum;
+  uint64_t *dedup;
+  uint32_t dedup_mask;
+  const uint64_t *lut;
+  uint64_t lut_cap;
+  uint64_t *uniq_onv;
+  void *uniq_pm1;
+  int pm1_f32;
+  uint32_t ucap;
+  int32_t *counters;
+  uint32_t cap_d, fixed;
+};
+
+// ---- de-duplication table ----------------------------------------------------------------------------------------
+// One-word determinants: slot = {key, row | ...}: the key word itself is claimed by a 64-bit CAS (empty = all ones, which no
+// determinant with an excitation left can be).  Two / three words: slot = {state | row << 32, key words...}; the state word
+// goes EMPTY -> BUSY (CAS) -> READY (after the key words are stored); a reader that meets BUSY polls again -- the owner never
+// waits for anybody, and the loop re-converges every iteration, so lanes of one wave cannot starve each other.
+// Every access to the table is an agent-scope atomic (coherent across the XCDs' L2s); the row number is written by the
+// winner with a plain store and only read by later kernels.
+__host__ __device__ constexpr int dedup_slot_words(int len) { return len == 1 ? 2 : 4; }
+constexpr uint32_t kSlotEmpty = 0xffffffffu, kSlotBusy = 1u, kSlotReady = 2u;
+
+template <int LEN>
+__device__ __forceinline__ uint32_t dedup_insert(uint64_t *__restrict__ tab, uint32_t mask, const uint64_t (&q)[LEN], bool &won) {
+  constexpr int W = dedup_slot_words(LEN);
+  uint32_t s = (uint32_t)(hash_of<LEN>(q) >> 17) & mask;
+  won = false;
+  if constexpr (LEN == 1) {
+    for (uint32_t probes = 0; probes < kProbeLimit; ++probes) {
+      unsigned long long *kp = reinterpret_cast<unsigned long long *>(tab + (size_t)s * W);
+      unsigned long long cur = __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == ~0ull) {
+        cur = atomicCAS(kp, ~0ull, (unsigned long long)q[0]);
+        if (cur == ~0ull) { won = true; return s; }
+      }
+      if (cur == q[0]) return s;
+      s = (s + 1) & mask;
+    }
+    return 0xffffffffu;
+  } else {
+    uint32_t probes = 0, polls = 0;
+    while (probes < kProbeLimit) {
+      uint32_t *sp = reinterpret_cast<uint32_t *>(tab + (size_t)s * W);
+      uint32_t st = __hip_atomic_load(sp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (st == kSlotEmpty) {
+        uint32_t expect = kSlotEmpty;
+        if (__hip_atomic_compare_exchange_strong(sp, &expect, kSlotBusy, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+#pragma unroll
+          for (int w = 0; w < LEN; ++w) __hip_atomic_store(tab + (size_t)s * W + 1 + w, q[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp, kSlotReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          won = true;
+          return s;
+        }
+        st = expect;
+      }
+      if (st != kSlotReady) {  // somebody is writing the key: look again (bounded: the owner finishes within its own iteration)
+        if (++polls > (1u << 20)) return 0xffffffffu;
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      bool eq = true;
+#pragma unroll
+      for (int w = 0; w < LEN; ++w)
+        eq = eq && __hip_atomic_load(tab + (size_t)s * W + 1 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == q[w];
+      if (eq) return s;
+      s = (s + 1) & mask;
+      ++probes;
+    }
+    return 0xffffffffu;
+  }
+}
+
+// the row number of a slot: int32 at this offset (in int32 units) of the slot
+__host__ __device__ constexpr int dedup_row_offset(int len) { return len == 1 ? 2 : 1; }
+
+// Where psi(x') will come from: the wave-function table (link <= -2), or the distinct list through a de-duplication slot
+// (link >= 0).  `won`: this lane inserted a new determinant and owns row `row` of the distinct list.
+template <int LEN, typename T>
+__device__ __forceinline__ int32_t resolve_amplitude(const OnepassOut<T> &o, const uint64_t (&ket)[LEN], bool &won, int32_t &row) {
+  won = false;
+  row = -1;
+  if (o.lut) {
+    const int64_t pos = hash_find<LEN>(o.lut, o.lut_cap, ket);
+    if (pos >= 0) return (int32_t)(-2 - pos);
+  }
+  bool w;
+  const uint32_t s = dedup_insert<LEN>(o.dedup, o.dedup_mask, ket, w);
+  if (s == 0xffffffffu) {
+    atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 2u);
+    return -1;
+  }
+  if (w) {
+    const int32_t r = atomicAdd(o.counters, 1);
+    if ((uint32_t)r < o.ucap) {
+      reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN))[dedup_row_offset(LEN)] = r;
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) o.uniq_onv[(size_t)r * LEN + i] = ket[i];
+      won = true;
+      row = r;
+    } else {
+      atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 4u);
+    }
+  }
+  return (int32_t)s;
+}
+
+// The wave writes the +1/-1 rows of the lanes flagged `flag` (all lanes of the wave must call): one coalesced store per row.
+template <int LEN, typename T>
+__device__ __forceinline__ void emit_rows(const OnepassOut<T> &o, int sorb, bool flag, const uint64_t (&ket)[LEN], int32_t row) {
+  if (!o.uniq_pm1) return;
+  const int lane = threadIdx.x & 63;
+  uint64_t m = __ballot(flag);
+  while (m) {
+    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+    m &= m - 1;
+    const int32_t r = __builtin_amdgcn_readlane(row, b);
+    uint64_t kw[LEN];
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) {
+      const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)ket[i], b), hi = __builtin_amdgcn_readlane((uint32_t)(ket[i] >> 32), b);
+      kw[i] = ((uint64_t)hi << 32) | lo;
+    }
+#pragma unroll
+    for (int i = 0; i < LEN; ++i) {
+      const int j = i * 64 + lane;
+      if (j < sorb) {
+        const bool occ = (kw[i] >> lane) & 1ull;
+        if (o.pm1_f32) reinterpret_cast<float *>(o.uniq_pm1)[(size_t)r * sorb + j] = occ ? 1.0f : -1.0f;
+        else reinterpret_cast<double *>(o.uniq_pm1)[(size_t)r * sorb + j] = occ ? 1.0 : -1.0;
+      }
+    }
+  }
+}
+
+// ---- phase A -------------------------------------------------------------------------------------------------------
+// Wave-private LDS: the wave's quarter of the singles staging scratch doubles as the buffer of a doubles tile's kept columns
+// (column, value); a few words for the running count and for the rows that lanes inside divergent code (singles, column 0)
+// won and the whole wave has to write at the end of the tile.
+constexpr int kStash = 24;
+
+template <int LEN>
+struct WaveLds {
+  volatile uint32_t *run;    // kept columns of the current doubles tile
+  volatile uint32_t *nstash;
+  int32_t *stash_row;        // [kStash]
+  uint64_t *stash_ket;       // [kStash][LEN]
+};
+
+template <int LEN, typename T, bool SAMPLED>
+struct KeepSink {
+  T eps;
+  uint32_t chunk, nchunks, tS;
+  int64_t seg_base;
+  WaveLds<LEN> W;
+  uint32_t *bufc;
+  T *bufh;
+  volatile uint32_t *dstat;
+  double *tsum;
+  uint32_t *kept_total;
+  const SDParams *p;
+  const LdsLayout *L;
+  const Walker<LEN> *wk;
+  OnepassOut<T> o;
+  uint32_t tile;
+  double sub;
+
+  __device__ __forceinline__ void record(int64_t g, uint32_t col, T h, const uint64_t (&ket)[LEN], bool &won, int32_t &row) const {
+    o.rec_col[g] = (int32_t)col;
+    o.rec_w[g] = h;
+    if (o.rec_onv) {
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) o.rec_onv[g * LEN + i] = ket[i];
+    }
+    o.rec_link[g] = resolve_amplitude<LEN, T>(o, ket, won, row);
+  }
+
+  // a column with a fixed slot (called from divergent code: any set of lanes)
+  __device__ __forceinline__ void fixed_slot(uint32_t slot, uint32_t col, T h, const uint64_t (&ket)[LEN]) {
+    const T a = fabs(h);
+    if (!(a >= eps)) {
+      if constexpr (SAMPLED) sub += (double)a;
+      return;  // (the slot was pre-filled with -1)
+    }
+    bool won;
+    int32_t row;
+    record(seg_base + slot, col, h, ket, won, row);
+    if (won) {
+      const uint32_t k = atomicAdd(const_cast<uint32_t *>(W.nstash), 1u);
+      W.stash_row[k] = row;
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) W.stash_ket[k * LEN + i] = ket[i];
+    }
+  }
+
+  __device__ __forceinline__ uint32_t advance(uint32_t total) const {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)__ballot(1)) - 1;
+    uint32_t before = 0;
+    if (lane == leader) { before = *W.run; *W.run = before + total; }
+    return __shfl(before, leader);
+  }
+
+  __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&ket)[LEN]) {
+    if (tile == 0) { fixed_slot(col == 0 ? 0u : 1u + (threadIdx.x & 63u), col, h, ket); return; }
+    if (tile <= tS) {
+      const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSinglesPerTile;
+      fixed_slot(kFixedHead + (tile - 1) * kSinglesPerTile + (col - 1 - r0), col, h, ket);
+      return;
+    }
+    const T a = fabs(h);
+    const bool k = a >= eps;
+    if constexpr (SAMPLED) { if (!k) sub += (double)a; }
+    const uint64_t m = __ballot(k);
+    if (!m) return;
+    const uint32_t before = advance((uint32_t)__popcll(m));
+    if (k) {
+      const uint32_t at = before + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+      bufc[at] = col;
+      bufh[at] = h;
+    }
+  }
+  __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&)[LEN], uint32_t c1, T h1, const uint64_t (&)[LEN]) {
+    const T a0 = fabs(h0), a1 = fabs(h1);
+    const bool a = a0 >= eps, b = a1 >= eps;
+    if constexpr (SAMPLED) sub += (a ? 0.0 : (double)a0) + (b ? 0.0 : (double)a1);
+    const uint64_t ma = __ballot(a), mb = __ballot(b);
+    if (!(ma | mb)) return;
+    const uint32_t before = advance((uint32_t)(__popcll(ma) + __popcll(mb)));
+    const uint64_t below = (1ull << (threadIdx.x & 63)) - 1ull;
+    const uint32_t mine = before + __popcll(ma & below) + __popcll(mb & below);
+    if (a) { bufc[mine] = c0; bufh[mine] = h0; }
+    if (b) { bufc[mine + (a ? 1 : 0)] = c1; bufh[mine + (a ? 1 : 0)] = h1; }
+  }
+  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&k0)[LEN], const uint64_t (&k1)[LEN]) {
+    two(col, h0, k0, col + 1, h1, k1);
+  }
+
+  // Exclusive prefix of the kept counts of the doubles tiles before tile d (decoupled look-back, one window of 64 tiles per step).
+  __device__ __forceinline__ uint32_t lookback(uint32_t d, uint32_t c) const {
+    const int lane = threadIdx.x & 63;
+    if (d == 0) {
+      if (lane == 0) dstat[0] = kStatP | c;
+      return 0;
+    }
+    if (lane == 0) dstat[d] = kStatA | c;
+    uint32_t excl = 0;
+    int32_t top = (int32_t)d - 1;
+    for (;;) {
+      const int32_t idx = top - lane;
+      const uint32_t s = idx >= 0 ? dstat[idx] : kStatP;  // below tile 0: an inclusive prefix of 0
+      const uint64_t ready = __ballot(s != 0u);
+      const uint64_t isP = __ballot((s & kStatP) != 0u);
+      const int fp = isP ? __ffsll((long long)isP) - 1 : 64;  // nearest tile whose inclusive prefix is known
+      const uint64_t need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+      if ((ready & need) != need) {
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      excl += op_wave_sum(lane <= fp ? (s & kStatMask) : 0u);
+      if (fp < 64) break;
+      top -= 64;
+    }
+    if (lane == 0) dstat[d] = kStatP | (excl + c);
+    return excl;
+  }
+
+  __device__ __forceinline__ void flush() {  // wave-uniform
+    if (tile == 0xffffffffu) return;
+    const int lane = threadIdx.x & 63;
+    if constexpr (SAMPLED) {
+      const double s = op_wave_sum(sub);
+      if (lane == 0) tsum[tile] = s;
+    }
+    wave_sync();
+    if (tile <= tS) {
+      // rows won inside the divergent code of column 0 / the singles
+      const uint32_t ns = *W.nstash;
+      if (ns) {
+        uint64_t ket[LEN];
+        const bool mine = (uint32_t)lane < ns;
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) ket[i] = mine ? W.stash_ket[lane * LEN + i] : 0ull;
+        emit_rows<LEN, T>(o, p->sorb, mine, ket, mine ? W.stash_row[lane] : 0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *W.nstash = 0u;
+      }
+      return;
+    }
+    const uint32_t c = *W.run;
+    const uint32_t excl = lookback(tile - 1 - tS, c);
+    if (lane == 0 && c) atomicMax(kept_total, excl + c);
+    for (uint32_t i0 = 0; i0 < c; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool act = i < c && excl + i < o.cap_d;
+      bool won = false;
+      int32_t row = -1;
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = 0ull;
+      if (act) {
+        const uint32_t col = bufc[i];
+        const Excitation x = decode(col - 1, *p, *L);
+        make_ket<LEN>(*wk, x, ket);
+        record(seg_base + o.fixed + excl + i, col, bufh[i], ket, won, row);
+      }
+      emit_rows<LEN, T>(o, p->sorb, won, ket, row);
+    }
+  }
+  __device__ __forceinline__ void tile_begin(uint32_t t) {
+    flush();
+    tile = t;
+    sub = 0.0;
+    if ((threadIdx.x & 63) == 0) *W.run = 0u;
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+// ---- phase C: the draws inside a tile (same scheme as kernels_reduce_sample.hip: SampleSink) ------------------------------
+struct DrawLds {
+  double *prefix;
+  uint32_t *cs;
+  uint32_t *hits;
+  volatile uint32_t *ncols;
+  volatile double *run;
+};
+constexpr size_t kDrawLdsPerWave = (size_t)kOneTileCols * (8 + 4 + 4) + 16;
+
+template <int LEN, typename T>
+struct DrawSink {
+  T eps;
+  DrawLds S;
+  const SDParams *p;
+  const LdsLayout *L;
+  const Walker<LEN> *wk;
+  const uint32_t *dinfo;  // LDS: slot offset << 16 | draws, per tile
+  double scale;           // S_walker / N
+  uint64_t key;
+  int64_t sbase;          // first drawn-record slot of this walker
+  OnepassOut<T> o;
+  uint32_t tile;
+
+  __device__ __forceinline__ void entry(uint32_t idx, uint32_t col, T h, double incl) const {
+    S.prefix[idx] = incl;
+    S.cs[idx] = col | (h < T(0) ? 0x80000000u : 0u);
+  }
+  __device__ __forceinline__ double width(T h) const {
+    const T a = fabs(h);
+    return a >= eps ? 0.0 : (double)a;
+  }
+  __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&)[LEN]) const {
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(1);
+    const double w = width(h);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (lane == b) {
+        const uint32_t idx = *S.ncols;
+        const double incl = *S.run + w;
+        entry(idx, col, h, incl);
+        *S.ncols = idx + 1;
+        *S.run = incl;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&)[LEN], const uint64_t (&)[LEN]) const {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nact = (uint32_t)__popcll(__ballot(1));
+    const double w0 = width(h0), w1 = width(h1);
+    const double incl = op_scan(w0 + w1, lane);
+    const uint32_t base = *S.ncols;
+    const double run = *S.run;
+    entry(base + 2 * lane, col, h0, run + incl - w1);
+    entry(base + 2 * lane + 1, col + 1, h1, run + incl);
+    const double total = __shfl(incl, (int)nact - 1);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { *S.ncols = base + 2 * nact; *S.run = run + total; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&)[LEN], uint32_t c1, T h1, const uint64_t (&)[LEN]) const {
+    const int lane = threadIdx.x & 63;
+    const double w0 = width(h0), w1 = width(h1);
+    const double i0 = op_scan(w0, lane), t0 = __shfl(i0, 63);
+    const double i1 = op_scan(w1, lane), t1 = __shfl(i1, 63);
+    const uint32_t base = *S.ncols;
+    const double run = *S.run;
+    entry(base + lane, c0, h0, run + i0);
+    entry(base + 64 + lane, c1, h1, run + t0 + i1);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { *S.ncols = base + 128; *S.run = run + t0 + t1; }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  __device__ __forceinline__ void flush() {  // wave-uniform
+    if (tile == 0xffffffffu) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t info = dinfo[tile];
+    const uint32_t draws = info & 0xffffu;
+    const uint32_t ncols = *S.ncols;
+    const double total = *S.run;
+    if (draws == 0 || ncols == 0 || !(total > 0.0)) return;
+    for (uint32_t k = lane; k < draws; k += 64) {
+      const uint64_t r = op_mix64(key ^ op_mix64(((uint64_t)tile << 32) | k));
+      const double target = (double)(r >> 11) * 0x1.0p-53 * total;
+      uint32_t lo = 0, hi = ncols;  // first idx with prefix[idx] > target
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (S.prefix[mid] > target) hi = mid; else lo = mid + 1;
+      }
+      if (lo >= ncols) lo = ncols - 1;
+      while (lo > 0 && !(S.prefix[lo] > S.prefix[lo - 1])) --lo;  // rounding at the end: back to a column of positive width
+      atomicAdd(&S.hits[lo], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int64_t pos = sbase + (info >> 16);
+    for (uint32_t i0 = 0; i0 < ncols; i0 += 64) {
+      const uint32_t idx = i0 + lane;
+      const uint32_t hc = idx < ncols ? S.hits[idx] : 0u;
+      const uint64_t m = __ballot(hc != 0u);
+      bool won = false;
+      int32_t row = -1;
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = 0ull;
+      if (hc) {
+        const uint32_t e = S.cs[idx], col = e & 0x7fffffffu;
+        const int64_t at = pos + __popcll(m & ((1ull << lane) - 1ull));
+        if (col == 0) {
+#pragma unroll
+          for (int i = 0; i < LEN; ++i) ket[i] = wk->w[i];
+        } else {
+          const Excitation x = decode(col - 1, *p, *L);
+          make_ket<LEN>(*wk, x, ket);
+        }
+        o.srec_col[at] = (int32_t)col;
+        const double v = scale * (double)hc;
+        o.srec_w[at] = (T)((e >> 31) ? -v : v);
+        if (o.srec_onv) {
+#pragma unroll
+          for (int i = 0; i < LEN; ++i) o.srec_onv[at * LEN + i] = ket[i];
+        }
+        o.srec_link[at] = resolve_amplitude<LEN, T>(o, ket, won, row);
+      }
+      emit_rows<LEN, T>(o, p->sorb, won, ket, row);
+      pos += __popcll(m);
+    }
+  }
+  __device__ __forceinline__ bool skip_tile(uint32_t t) const { return (dinfo[t] & 0xffffu) == 0u; }
+  __device__ __forceinline__ void tile_begin(uint32_t t) {
+    flush();
+    tile = t;
+    if ((dinfo[t] & 0xffffu) == 0u) return;
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < kOneTileCols; i += 64) S.hits[i] = 0u;
+    if (lane == 0) { *S.ncols = 0u; *S.run = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+// LDS after the walker tables and the staging scratch: dstat[max_tiles] | (SAMPLED) tsum[max_tiles] f64, dinfo[max_tiles], draw areas
+__host__ __device__ inline size_t onepass_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled) {
+  size_t b = (lds_bytes(p, esz) + 15) & ~(size_t)15;
+  b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
+  if (sampled) {
+    b += (size_t)max_tiles * 8;
+    b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
+    b += (kBlock / 64) * kDrawLdsPerWave;
+  }
+  return b;
+}
+
+template <int LEN, typename T, bool SAMPLED>
+__global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
+                                                                uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
+                                                                uint32_t nsample, uint64_t seed, OnepassOut<T> o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t next_tile, kept_total;
+  __shared__ uint32_t wave_run[kBlock / 64], wave_nstash[kBlock / 64];
+  __shared__ int32_t stash_row[kBlock / 64][kStash];
+  __shared__ uint64_t stash_ket[kBlock / 64][kStash * LEN];
+  __shared__ double s_part[kBlock / 64 + 1];
+  __shared__ uint32_t s_parti[kBlock / 64 + 1];
+  uint64_t walker;
+  uint32_t chunk;
+  map_workgroup(nchunks, false, walker, chunk);
+  const uint64_t slot = walker * nchunks + chunk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t seg_base = (int64_t)slot * ((int64_t)o.fixed + o.cap_d);
+  if (tid == 0) { next_tile = 0; kept_total = 0; }
+  if (lane == 0) wave_nstash[wave] = 0;
+  unsigned char *extra = smem + ((lds_bytes(p, sizeof(T)) + 15) & ~(size_t)15);
+  volatile uint32_t *dstat = reinterpret_cast<volatile uint32_t *>(extra);
+  extra += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
+  double *tsum = reinterpret_cast<double *>(extra);
+  uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
+  for (uint32_t i = tid; i < max_tiles; i += kBlock) {
+    dstat[i] = 0u;
+    if constexpr (SAMPLED) { tsum[i] = 0.0; dinfo[i] = 0u; }
+  }
+  for (uint32_t i = tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
+  if constexpr (SAMPLED) {
+    for (uint32_t i = tid; i < nsample; i += kBlock) o.srec_col[(int64_t)walker * nsample + i] = -1;
+  }
+  Walker<LEN> wk;
+  load_walker<LEN>(bra + walker * LEN, wk);
+  const LdsLayout L = carve_lds(smem, p);
+  const int nocc = build_walker_tables<LEN>(wk, p, L);  // (ends with a barrier: the pre-fills above are done)
+
+  const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+  const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
+  T *quarter = reinterpret_cast<T *>(L.scratch) + wave * (kDiagTile / 4);
+  {
+    KeepSink<LEN, T, SAMPLED> sink;
+    sink.eps = eps; sink.chunk = chunk; sink.nchunks = nchunks; sink.tS = tS; sink.seg_base = seg_base;
+    sink.W.run = wave_run + wave; sink.W.nstash = wave_nstash + wave; sink.W.stash_row = stash_row[wave]; sink.W.stash_ket = stash_ket[wave];
+    sink.bufh = quarter;
+    sink.bufc = reinterpret_cast<uint32_t *>(quarter + kOneTileCols);
+    sink.dstat = dstat; sink.tsum = tsum; sink.kept_total = &kept_total;
+    sink.p = &p; sink.L = &L; sink.wk = &wk; sink.o = o; sink.tile = 0xffffffffu; sink.sub = 0.0;
+    visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+    sink.flush();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    o.seg_count[slot] = (int32_t)kept_total;
+    if (kept_total > o.cap_d) atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 1u);
+    atomicMax(o.counters + 2, (int32_t)kept_total);
+  }
+  if constexpr (SAMPLED) {
+    // ---- phase B: inclusive scan of the tile sums (fixed order of additions), the N draws over the tiles, slot offsets ----
+    const uint32_t per = (max_tiles + kBlock - 1) / kBlock;
+    const uint32_t b0 = min((uint32_t)tid * per, max_tiles), b1 = min(b0 + per, max_tiles);
+    double local = 0.0;
+    for (uint32_t i = b0; i < b1; ++i) local += tsum[i];
+    double incl = op_scan(local, lane);
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    double before = 0.0, total = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) {
+      if (w < wave) before += s_part[w];
+      total += s_part[w];
+    }
+    double run = before + incl - local;
+    for (uint32_t i = b0; i < b1; ++i) { run += tsum[i]; tsum[i] = run; }
+    __syncthreads();
+    const double Srow = total;
+    if (tid == 0 && o.row_sum) o.row_sum[walker] = Srow;
+    const uint64_t key = op_mix64(seed ^ op_mix64(slot));
+    if (Srow > 0.0) {
+      for (uint32_t k = tid; k < nsample; k += kBlock) {
+        const uint64_t r = op_mix64(key ^ op_mix64(0xffffffff00000000ull | k));
+        const double target = (double)(r >> 11) * 0x1.0p-53 * Srow;
+        uint32_t lo = 0, hi = max_tiles;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (tsum[mid] > target) hi = mid; else lo = mid + 1;
+        }
+        if (lo >= max_tiles) lo = max_tiles - 1;
+        while (lo > 0 && !(tsum[lo] > tsum[lo - 1])) --lo;
+        atomicAdd(&dinfo[lo], 1u);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the draw counts -> offset << 16 | count
+    uint32_t lsum = 0;
+    for (uint32_t i = b0; i < b1; ++i) lsum += dinfo[i];
+    uint32_t iscan = lsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t ov = __shfl_up(iscan, d);
+      if (lane >= d) iscan += ov;
+    }
+    if (lane == 63) s_parti[wave] = iscan;
+    __syncthreads();
+    uint32_t ibefore = 0;
+    for (int w = 0; w < wave; ++w) ibefore += s_parti[w];
+    uint32_t off = ibefore + iscan - lsum;
+    for (uint32_t i = b0; i < b1; ++i) {
+      const uint32_t c = dinfo[i];
+      dinfo[i] = (off << 16) | c;
+      off += c;
+    }
+    if (tid == 0) next_tile = 0;
+    __syncthreads();
+    // ---- phase C ----
+    unsigned char *mine = reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) + (size_t)wave * kDrawLdsPerWave;
+    DrawLds S;
+    S.prefix = reinterpret_cast<double *>(mine);
+    S.run = reinterpret_cast<volatile double *>(mine + (size_t)kOneTileCols * 8);
+    S.cs = reinterpret_cast<uint32_t *>(mine + (size_t)kOneTileCols * 8 + 8);
+    S.hits = S.cs + kOneTileCols;
+    S.ncols = reinterpret_cast<volatile uint32_t *>(S.hits + kOneTileCols);
+    DrawSink<LEN, T> sink{eps, S, &p, &L, &wk, dinfo, Srow / (double)nsample, key, (int64_t)walker * nsample, o, 0xffffffffu};
+    visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+    sink.flush();
+  }
+}
+
+// ---- contraction: E_loc(x) = sum_records w psi(x') / psi(x) ------------------------------------------------------------
+// One wave per walker.  Slots are visited in their fixed order (fixed slots, compacted doubles, drawn records; chunk by chunk),
+// lane l takes slots l, l + 64, ...; the 64 partial sums meet in a butterfly: the result does not depend on anything but the
+// records' positions.  psi(x) is the amplitude of the record of column 0 (kept slot 0, else among the drawn ones; 0 if it is
+// nowhere -- the reference divides by zero there, too).
+template <typename T, bool CPLX>
+__global__ __launch_bounds__(kBlock) void reduce_contract_kernel(int64_t nbatch, uint32_t nchunks, uint32_t fixed, uint32_t cap_d,
+                                                                 uint32_t nsample, const int32_t *__restrict__ rec_col,
+                                                                 const T *__restrict__ rec_w, const int32_t *__restrict__ rec_link,
+                                                                 const int32_t *__restrict__ seg_count, const int32_t *__restrict__ srec_col,
+                                                                 const T *__restrict__ srec_w, const int32_t *__restrict__ srec_link,
+                                                                 const int32_t *__restrict__ dedup_i32, int slot_i32, int row_off, uint32_t ucap,
+                                                                 const double *__restrict__ psi_u, const double *__restrict__ psi_t, int divide,
+                                                                 double *__restrict__ eloc, double *__restrict__ psi_x) {
+  const int lane = threadIdx.x & 63;
+  const int64_t walker = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (walker >= nbatch) return;
+  double ar = 0.0, ai = 0.0, xr = 0.0, xi = 0.0;
+  bool bad = false;
+  auto amp = [&](int32_t link, double &re, double &im) {
+    const double *src;
+    int64_t at;
+    if (link >= 0) {
+      const int32_t row = dedup_i32[(int64_t)link * slot_i32 + row_off];
+      if (row < 0 || (uint32_t)row >= ucap) { bad = true; re = im = 0.0; return; }
+      src = psi_u; at = row;
+    } else if (link <= -2) {
+      src = psi_t; at = -2 - (int64_t)link;
+    } else { bad = true; re = im = 0.0; return; }
+    if constexpr (CPLX) { re = src[2 * at]; im = src[2 * at + 1]; }
+    else { re = src[at]; im = 0.0; }
+  };
+  auto visit = [&](int32_t col, double w, int32_t link) {
+    if (col < 0) return;
+    double re, im;
+    amp(link, re, im);
+    ar += w * re; ai += w * im;
+    if (col == 0) { xr = re; xi = im; }
+  };
+  const int64_t stride = (int64_t)fixed + cap_d;
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const int64_t seg = walker * nchunks + c, base = seg * stride;
+    const uint32_t kept = (uint32_t)seg_count[seg];
+    if (kept > cap_d) bad = true;
+    const uint32_t nslots = fixed + min(kept, cap_d);
+    for (uint32_t i = lane; i < nslots; i += 64) visit(rec_col[base + i], (double)rec_w[base + i], rec_link[base + i]);
+  }
+  for (uint32_t i = lane; i < nsample; i += 64) {
+    const int64_t at = walker * nsample + i;
+    visit(srec_col[at], (double)srec_w[at], srec_link[at]);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    ar += __shfl_xor(ar, d); ai += __shfl_xor(ai, d);
+    xr += __shfl_xor(xr, d); xi += __shfl_xor(xi, d);  // (exactly one lane holds a non-zero psi(x))
+  }
+  const bool anybad = __ballot(bad) != 0;
+  if (lane == 0) {
+    if (anybad) { ar = ai = __builtin_nan(""); }
+    if constexpr (CPLX) {
+      const double dn = xr * xr + xi * xi;
+      eloc[2 * walker] = divide ? (ar * xr + ai * xi) / dn : ar;
+      eloc[2 * walker + 1] = divide ? (ai * xr - ar * xi) / dn : ai;
+      psi_x[2 * walker] = xr; psi_x[2 * walker + 1] = xi;
+    } else {
+      eloc[walker] = divide ? ar / xr : ar;
+      psi_x[walker] = xr;
+    }
+  }
+}
+
+}  // namespace pynqs
+
+using namespace pynqs;
+
+static int onepass_geometry(int64_t nbatch, const SDParams &p, bool sampled, uint32_t *nchunks, uint32_t *chunk_len, uint32_t *max_tiles,
+                            uint32_t *fixed) {
+  const uint32_t ncomb = p.nsd + 1;
+  if (sampled) {  // the draws need the sums of the WHOLE row in one workgroup's LDS
+    *nchunks = 1;
+    *chunk_len = (ncomb + 255u) & ~255u;
+  } else {
+    plan_chunks(nbatch, ncomb, nchunks, chunk_len);
+  }
+  *max_tiles = max_tiles_per_chunk(p, *nchunks, *chunk_len);
+  const uint32_t tS_all = (p.d1 + kSinglesPerTile - 1) / kSinglesPerTile;
+  *fixed = kFixedHead + ((tS_all + *nchunks - 1) / *nchunks) * kSinglesPerTile;
+  return 0;
+}
+
+static size_t onepass_static_lds(int len) {
+  return 8 + (kBlock / 64) * (8 + kStash * 4 + (size_t)kStash * 8 * len) + (kBlock / 64 + 1) * 12 + 64;
+}
+
+extern "C" int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4) {
+  SDParams p;
+  PlanLayout pl;
+  if (!out4) return set_error(PYNQS_EINVAL, "null pointer");
+  if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB (even sorb in [2, 192])");
+  if (nbatch < 0 || nbatch > 0x7fffffffll || eps_sample < 0 || eps_sample > 65535) return set_error(PYNQS_EINVAL, "bad nbatch / eps_sample (at most 65535 draws)");
+  uint32_t nchunks, chunk_len, max_tiles, fixed;
+  onepass_geometry(nbatch, p, eps_sample > 0, &nchunks, &chunk_len, &max_tiles, &fixed);
+  const int len = (sorb - 1) / 64 + 1;
+  const int64_t slots = out4[2];
+  out4[0] = nbatch * (int64_t)nchunks;
+  out4[1] = fixed;
+  out4[2] = slots > 0 ? slots * dedup_slot_words(len) * 8 : 0;
+  out4[3] = onepass_lds(p, 8, max_tiles, eps_sample > 0) + onepass_static_lds(len) <= 160 * 1024 ? 1 : 0;
+  return PYNQS_OK;
+}
+
+template <typename T>
+static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed) {
+  OnepassOut<T> o;
+  o.rec_col = io->rec_col; o.rec_w = (T *)io->rec_w; o.rec_onv = io->rec_onv; o.rec_link = io->rec_link; o.seg_count = io->seg_count;
+  o.srec_col = io->srec_col; o.srec_w = (T *)io->srec_w; o.srec_onv = io->srec_onv; o.srec_link = io->srec_link; o.row_sum = io->row_sum;
+  o.dedup = (uint64_t *)io->dedup_table; o.dedup_mask = (uint32_t)(io->dedup_slots - 1);
+  o.lut = (const uint64_t *)io->lut_table; o.lut_cap = io->lut_table ? hash_capacity(io->lut_nkeys) : 0;
+  o.uniq_onv = io->uniq_onv; o.uniq_pm1 = io->uniq_pm1; o.pm1_f32 = io->pm1_dtype == PYNQS_F32; o.ucap = (uint32_t)io->cap_unique;
+  o.counters = io->counters; o.cap_d = (uint32_t)io->cap_doubles; o.fixed = fixed;
+  (void)len;
+  return o;
+}
+
+extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan, int dtype,
+                                    double eps, int eps_sample, uint64_t seed, const pynqs_reduce_io *io, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
+  SDParams p;
+  PlanLayout pl;
+  if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB (even sorb in [2, 192])");
+  if (nbatch < 0 || nbatch > 0x7fffffffll || (dtype != PYNQS_F32 && dtype != PYNQS_F64)) return set_error(PYNQS_EINVAL, "bad nbatch/dtype");
+  if (eps_sample < 0 || eps_sample > 65535) return set_error(PYNQS_EINVAL, "eps_sample must be in [0, 65535]");
+  if (!io) return set_error(PYNQS_EINVAL, "null pointer");
+  const bool sampled = eps_sample > 0;
+  if (!io->counters || !io->dedup_table || !io->uniq_onv || !io->rec_col || !io->rec_w || !io->rec_link || !io->seg_count ||
+      (sampled && (!io->srec_col || !io->srec_w || !io->srec_link)))
+    return set_error(PYNQS_EINVAL, "null pointer");
+  if (io->dedup_slots < 64 || (io->dedup_slots & (io->dedup_slots - 1)) || io->dedup_slots > (1ll << 31) || io->cap_unique < 1 ||
+      2 * io->cap_unique > io->dedup_slots || io->cap_doubles < 0 || io->cap_doubles >= (1ll << 30))
+    return set_error(PYNQS_EINVAL, "bad capacities (dedup_slots: power of two >= 2 * cap_unique)");
+  if (io->pm1_dtype != PYNQS_F32 && io->pm1_dtype != PYNQS_F64) return set_error(PYNQS_EINVAL, "bad pm1_dtype");
+  if (io->lut_table && io->lut_nkeys < 0) return set_error(PYNQS_EINVAL, "bad lut_nkeys");
+  hipStream_t st = (hipStream_t)stream;
+  const int len = (sorb - 1) / 64 + 1;
+  if (hipMemsetAsync(io->counters, 0, 16, st) != hipSuccess) return check_launch("memset");
+  if (hipMemsetAsync(io->dedup_table, 0xFF, (size_t)io->dedup_slots * dedup_slot_words(len) * 8, st) != hipSuccess) return check_launch("memset");
+  if (nbatch == 0) return PYNQS_OK;
+  if (!bra || !plan) return set_error(PYNQS_EINVAL, "null pointer");
+  uint32_t nchunks, chunk_len, max_tiles, fixed;
+  onepass_geometry(nbatch, p, sampled, &nchunks, &chunk_len, &max_tiles, &fixed);
+  const uint64_t grid = (uint64_t)nbatch * nchunks;
+  if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
+  if (grid * ((uint64_t)fixed + (uint64_t)io->cap_doubles) > 0x7fffffffull * 16ull) return set_error(PYNQS_EINVAL, "record arrays too large");
+  const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
+  const size_t lds = onepass_lds(p, esz, max_tiles, sampled);
+  if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
+  // eloc.py:257-264: with draws and eps <= 0 nothing is kept (every column can be drawn); without draws |H| >= eps as it stands
+  const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
+#define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
+  do {                                                                                                                               \
+    auto kfn = reduce_onepass_kernel<LEN, TT, SM>;                                                                                   \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                               (int)lds) != hipSuccess)                                                              \
+      return check_launch("hipFuncSetAttribute");                                                                                   \
+    hipLaunchKernelGGL(kfn, dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, chunk_len, max_tiles, (const TT *)plan, \
+                       (TT)eps_eff, (uint32_t)eps_sample, seed, make_out<TT>(io, len, fixed));                                       \
+  } while (0)
+  DISPATCH_LEN(len, {
+    if (dtype == PYNQS_F64) { if (sampled) PYNQS_OP_LAUNCH(double, true); else PYNQS_OP_LAUNCH(double, false); }
+    else { if (sampled) PYNQS_OP_LAUNCH(float, true); else PYNQS_OP_LAUNCH(float, false); }
+  });
+#undef PYNQS_OP_LAUNCH
+  return check_launch("reduce_onepass");
+}
+
+extern "C" int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
+                                     const pynqs_reduce_io *io, const double *psi_unique, const double *psi_table, int psi_is_complex,
+                                     int divide, double *eloc, double *psi_x, void *stream) {
+  pynqs::DeviceScope device_scope_(eloc);
+  SDParams p;
+  if (!make_sd_params(sorb, nele, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
+  if (nbatch < 0 || nbatch > 0x7fffffffll || (dtype != PYNQS_F32 && dtype != PYNQS_F64) || eps_sample < 0 || eps_sample > 65535)
+    return set_error(PYNQS_EINVAL, "bad nbatch/dtype/eps_sample");
+  if (nbatch == 0) return PYNQS_OK;
+  if (!io || !io->rec_col || !io->rec_w || !io->rec_link || !io->seg_count || !io->dedup_table || !psi_unique || !eloc || !psi_x ||
+      (eps_sample > 0 && (!io->srec_col || !io->srec_w || !io->srec_link)) || (io->lut_table && !psi_table))
+    return set_error(PYNQS_EINVAL, "null pointer");
+  uint32_t nchunks, chunk_len, max_tiles, fixed;
+  onepass_geometry(nbatch, p, eps_sample > 0, &nchunks, &chunk_len, &max_tiles, &fixed);
+  const int len = (sorb - 1) / 64 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t grid = (uint32_t)((nbatch + kBlock / 64 - 1) / (kBlock / 64));
+#define PYNQS_CT_LAUNCH(TT, CX)                                                                                                          \
+  hipLaunchKernelGGL((reduce_contract_kernel<TT, CX>), dim3(grid), dim3(kBlock), 0, st, nbatch, nchunks, fixed, (uint32_t)io->cap_doubles, \
+                     (uint32_t)eps_sample, io->rec_col, (const TT *)io->rec_w, io->rec_link, io->seg_count, io->srec_col,                \
+                     (const TT *)io->srec_w, io->srec_link, (const int32_t *)io->dedup_table, dedup_slot_words(len) * 2,                 \
+                     dedup_row_offset(len), (uint32_t)io->cap_unique, psi_unique, psi_table, divide, eloc, psi_x)
+  if (dtype == PYNQS_F64) { if (psi_is_complex) PYNQS_CT_LAUNCH(double, true); else PYNQS_CT_LAUNCH(double, false); }
+  else { if (psi_is_complex) PYNQS_CT_LAUNCH(float, true); else PYNQS_CT_LAUNCH(float, false); }
+#undef PYNQS_CT_LAUNCH
+  return check_launch("reduce_contract");
+}

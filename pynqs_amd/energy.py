@@ -33,6 +33,7 @@ from torch import Tensor, nn
 
 from . import C_extension as CX
 from . import _native as N
+from . import reduce_front as RF
 from .C_extension import get_comb_hij_fused, get_hij_torch
 from .distributed import get_rank
 from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, check_para, get_Num_SinglesDoubles,
@@ -41,6 +42,7 @@ from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, che
 FUSED = True  # use the fused sample-space / reduce kernels when the configuration allows it
 FUSED_SAMPLED = True  # REDUCE with eps_sample > 0: select and draw on chip (reduce_compact_sampled) instead of torch.multinomial on the matrix
 FUSED_RBM = True  # SIMPLE method: evaluate a real RBM ansatz inside the kernel (pynqs_eloc_rbm) instead of calling the module
+FUSED_ONEPASS = True  # REDUCE: the one-launch front end (reduce_front.ReduceFrontEnd); False: the multi-pass compaction of round 2
 
 
 def Func(func: Callable[..., Tensor], x: Tensor, WF_LUT: Optional[WavefunctionLUT] = None, use_unique: bool = False) -> Tensor:
@@ -381,8 +383,7 @@ def reduce_compact_sampled(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele:
     if seed is None:
         # from torch's host generator (reproducible after torch.manual_seed), decorrelated between the ranks: after the usual
         # manual_seed(seed) every rank's generator is in the same state, and the kernel's stream is keyed by (seed, local walker, tile, k)
-        seed = (int(torch.randint(0, 2**62, (1,)).item()) ^ ((get_rank() + 1) * 0x9E3779B97F4A7C15)) & (2**63 - 1) if get_rank() else \
-            int(torch.randint(0, 2**62, (1,)).item())
+        seed = _draw_seed()
     N.check(lib.pynqs_reduce_sample(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), code, eps_eff, tile_draws.data_ptr(),
                                     sample_off.data_ptr(), scale.data_ptr(), seed, s_col.data_ptr(), s_onv.data_ptr(), s_h.data_ptr(), st),
             "pynqs_reduce_sample")
@@ -397,6 +398,60 @@ def reduce_compact_sampled(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele:
     s_counts = torch.segment_reduce(valid.to(torch.float64), "sum", lengths=draws_per_row, unsafe=True).to(torch.int64) if used else \
         torch.zeros(n, dtype=torch.int64, device=dev)
     return (row, col, onv, h, counts), (s_row, s_col[keep], s_onv[keep], s_h[keep], s_counts)
+
+# ---- REDUCE through the one-launch front end ---------------------------------------------------------------------------------
+_FRONTS: "dict[tuple, RF.ReduceFrontEnd]" = {}
+_MAX_FRONTS = 4
+
+
+def _draw_seed() -> int:
+    """from torch's host generator (reproducible after torch.manual_seed), decorrelated between the ranks: after the usual
+    manual_seed(seed) every rank's generator is in the same state, and the kernels' streams are keyed by (seed, walker, tile, k)"""
+    s = int(torch.randint(0, 2**62, (1,)).item())
+    r = get_rank()
+    return (s ^ ((r + 1) * 0x9E3779B97F4A7C15)) & (2**63 - 1) if r else s
+
+
+def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
+                 lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None):
+    """Run the fused REDUCE front end on the walkers x (vmc/energy/eloc.py:243-298 + flip.py:29-63 in one launch) and return
+    (front end, number of distinct x').  Buffers are cached per (device, batch size, system, eps_sample) and grown when a call
+    reports that it needed more (the call is then repeated); ONE device-to-host read per call, after the kernel has been enqueued."""
+    plan = CX.plan_for(h1e, h2e, sorb, x.device)
+    n = x.size(0)
+    pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
+    key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype)
+    fe = _FRONTS.pop(key, None)
+    if fe is None:
+        nseg, fixed, _, _ = RF.geometry(n, sorb, nele, noa, nob, eps_sample)
+        ncomb = get_Num_SinglesDoubles(sorb, noa, nob) + 1
+        per_seg = (ncomb * max(n, 1) + max(nseg, 1) - 1) // max(nseg, 1)
+        cap_d = min(per_seg, max(64, per_seg // 32))
+        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, max(4096, 32 * n), pm1_dtype)
+    if seed is None:
+        seed = _draw_seed() if eps_sample > 0 else 0
+    while True:
+        fe.run(x, plan.buf, eps, seed, lut)
+        cnt = fe.counters_host()
+        if not fe.overflowed(cnt):
+            break
+        nu, flags, mx = cnt
+        cap_d = max(fe.cap_doubles, int(mx * 1.25) + 16) if mx > fe.cap_doubles else fe.cap_doubles
+        cap_u = fe.cap_unique
+        if flags & RF.OVERFLOW_TABLE:
+            cap_u = max(2 * cap_u, int(nu * 1.5))
+        elif nu > cap_u:
+            cap_u = int(nu * 1.25) + 1024
+        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype)
+    _FRONTS[key] = fe  # (most recently used last)
+    while len(_FRONTS) > _MAX_FRONTS:
+        _FRONTS.pop(next(iter(_FRONTS)))
+    return fe, cnt[0]
+
+
+def _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample) -> bool:
+    return (FUSED and FUSED_ONEPASS and x.is_cuda and sorb % 2 == 0 and h1e.dtype in (torch.float64, torch.float32)
+            and (eps_sample == 0 or FUSED_SAMPLED) and RF.supported(x.size(0), sorb, nele, noa, nob, int(eps_sample)))
 
 
 def local_energy(
@@ -490,7 +545,65 @@ def local_energy(
             ansatz_extra = None
             ansatz_f = partial(ansatz_batch, func=ansatz)
 
-        # ---- fast path: REDUCE (deterministic) with on-chip compaction -----------------------------------
+        # ---- fast path: REDUCE through the one-launch front end (deterministic and semi-stochastic, every form) ---------------
+        if reduce_psi and not use_sample_space and batch > 0 and _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample):
+            plain = not (use_multi_psi or use_spin_flip)
+            # the table is asked inside the kernel when it has a GPU hash table and psi is all that is needed on x' (f of the multi-psi
+            # form has no table; the projected forms look flip(x') up as well): otherwise on the distinct rows, below
+            ht = getattr(WF_LUT, "hashtable", None) if (WF_LUT is not None and plain) else None
+            fe, nu = reduce_front(x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht)
+            t2 = time.time_ns()
+            uniq = fe.uniq_onv[:nu]
+            takes_rows = getattr(ansatz_batch, "accepts_pm1_rows", False) and fe.pm1_dtype == torch.get_default_dtype()
+
+            def on_distinct(fn, lut) -> Tensor:
+                """a function of the determinant on the distinct x' (the rows the kernel wrote are the module's input already)"""
+                if lut is None:
+                    return fn(fe.uniq_pm1[:nu] if takes_rows else uniq).to(dtype)
+                return Func(fn, uniq, lut, False).to(dtype)
+
+            psi_u = on_distinct(ansatz_f, WF_LUT if ht is None else None)
+            tab = WF_LUT.wf_value if ht is not None else None
+            if plain:
+                eloc, psi_x = fe.contract(psi_u, tab)
+                num_over_psi = None
+            else:
+                # projected / multi-psi forms (flip.py:153-319): per distinct x'
+                #   T = f psi + eta eta_m(x') f(flip x') psi(flip x');  E_loc = conj(f(x)) sum_k w_k T(x'_k) / (N^2 psi(x))
+                t_u = psi_u
+                f_u = None
+                if use_multi_psi:
+                    f_u = on_distinct(ansatz_extra, None)
+                    t_u = f_u * psi_u
+                if use_spin_flip:
+                    uniq_flip = spin_flip_onv(uniq, sorb)
+                    psi_flip = Func(ansatz_f, uniq_flip, WF_LUT, use_unique).to(dtype)
+                    if use_multi_psi:
+                        psi_flip = Func(ansatz_extra, uniq_flip, None, use_unique).to(dtype) * psi_flip
+                    t_u = t_u + SpinProjection.eta * spin_flip_sign(uniq, sorb) * psi_flip
+                num, _ = fe.contract(t_u, None, divide=False)
+                _, psi_x = fe.contract(psi_u, None, divide=False)
+                scale = 1.0 / extra_norm**2
+                if use_multi_psi:
+                    scale = scale * fe.contract(f_u, None, divide=False)[1].conj()
+                num_over_psi = scale / psi_x
+                eloc = num * num_over_psi
+            if use_spin_raising:
+                # <S-S+> over the same records (eloc.py:250-310: the raw S-S+ matrix elements, also on the drawn columns)
+                xs = x if fe.nchunks == 1 else x.repeat_interleave(fe.nchunks, 0)
+                hs = get_hij_torch(xs, fe.rec_onv.view(fe.nseg, fe.stride, -1), h1e_spin, h2e_spin, sorb, nele).reshape(-1).to(fe.h_dtype)
+                hs_s = get_hij_torch(x, fe.srec_onv.view(batch, fe.eps_sample, -1), h1e_spin, h2e_spin, sorb, nele).reshape(-1).to(fe.h_dtype) \
+                    if fe.eps_sample else None
+                if plain:
+                    sloc = fe.contract(psi_u, tab, rec_w=hs, srec_w=hs_s)[0]
+                else:
+                    sloc = fe.contract(t_u, None, divide=False, rec_w=hs, srec_w=hs_s)[0] * num_over_psi
+            else:
+                sloc = torch.zeros_like(eloc)
+            t3 = time.time_ns()
+            return eloc.to(dtype), sloc.to(dtype), psi_x.to(dtype), ((t2 - t0) / 1e6, 0.0, (t3 - t2) / 1e6)
+
+        # ---- fast path: REDUCE (deterministic) with on-chip compaction, multi-pass (rows too long for the fused front end) -----
         # (also the spin-flip projected and multi-psi forms, flip.py:200-319: their extra factors are evaluated on the kept records only)
         if (FUSED and reduce_psi and not use_sample_space and eps_sample == 0 and sorb % 2 == 0 and x.is_cuda):
             row, col, onv, h, counts = reduce_compact(x, h1e, h2e, sorb, nele, noa, nob, eps)
@@ -633,6 +746,8 @@ def total_energy(
 
     def _ansatz_batch(x: Tensor, func: Callable[[Tensor], Tensor]) -> Tensor:
         return ansatz_batch(func, x, fp_batch, sorb, device, dtype)
+
+    _ansatz_batch.accepts_pm1_rows = True  # (public_function.ansatz_batch takes uint8 determinants or ready +-1 rows)
 
     begin = 0
     for end in ends:
