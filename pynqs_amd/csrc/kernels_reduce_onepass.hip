@@ -82,6 +82,7 @@ struct OnepassOut {
   uint32_t ucap;
   int32_t *counters;
   uint32_t cap_d, fixed;
+  uint32_t debug;  // PYNQS_OP_DEBUG ablations (timing only): 1 no amplitude source, 2 no +-1 rows, 4 no look-back
 };
 
 // ---- de-duplication table ----------------------------------------------------------------------------------------
@@ -147,12 +148,26 @@ __device__ __forceinline__ uint32_t dedup_insert(uint64_t *__restrict__ tab, uin
 // the row number of a slot: int32 at this offset (in int32 units) of the slot
 __host__ __device__ constexpr int dedup_row_offset(int len) { return len == 1 ? 2 : 1; }
 
+// Rows of the distinct list are handed out per WORKGROUP, not per determinant: a global counter that every new determinant
+// increments is one address for 10^5 - 10^6 atomics per launch, and same-address atomics retire at ~4 ns each (measured: the first
+// version of this kernel spent 1.26 ms on 245 k of them, 6.3 ms on 1.47 M).  The lane that wins a de-duplication slot only notes
+// (slot, column) in an LDS list of its workgroup; at the end of a phase the workgroup takes ONE block of rows from the global counter
+// and its waves write the slots' row numbers, the determinants and the +-1 rows.  A full list falls back to one atomic per wave and
+// flush step.
+struct WinnerList {
+  uint32_t *n;      // LDS counter
+  uint32_t *slot;   // [cap]
+  uint32_t *col;    // [cap]
+  uint32_t cap;
+};
+
 // Where psi(x') will come from: the wave-function table (link <= -2), or the distinct list through a de-duplication slot
-// (link >= 0).  `won`: this lane inserted a new determinant and owns row `row` of the distinct list.
+// (link >= 0).  `unlisted`: this lane inserted a new determinant and the workgroup's list was full: the caller allocates its row.
 template <int LEN, typename T>
-__device__ __forceinline__ int32_t resolve_amplitude(const OnepassOut<T> &o, const uint64_t (&ket)[LEN], bool &won, int32_t &row) {
-  won = false;
-  row = -1;
+__device__ __forceinline__ int32_t resolve_amplitude(const OnepassOut<T> &o, const WinnerList &wl, const uint64_t (&ket)[LEN], uint32_t col,
+                                                     bool &unlisted) {
+  unlisted = false;
+  if (o.debug & 1u) return -1;
   if (o.lut) {
     const int64_t pos = hash_find<LEN>(o.lut, o.lut_cap, ket);
     if (pos >= 0) return (int32_t)(-2 - pos);
@@ -164,24 +179,30 @@ __device__ __forceinline__ int32_t resolve_amplitude(const OnepassOut<T> &o, con
     return -1;
   }
   if (w) {
-    const int32_t r = atomicAdd(o.counters, 1);
-    if ((uint32_t)r < o.ucap) {
-      reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN))[dedup_row_offset(LEN)] = r;
-#pragma unroll
-      for (int i = 0; i < LEN; ++i) o.uniq_onv[(size_t)r * LEN + i] = ket[i];
-      won = true;
-      row = r;
-    } else {
-      atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 4u);
-    }
+    const uint32_t k = atomicAdd(wl.n, 1u);
+    if (k < wl.cap) { wl.slot[k] = s; wl.col[k] = col; }
+    else unlisted = true;
   }
   return (int32_t)s;
+}
+
+// row `r` of the distinct list belongs to the determinant in de-duplication slot `s`
+template <int LEN, typename T>
+__device__ __forceinline__ bool assign_row(const OnepassOut<T> &o, uint32_t s, int32_t r, const uint64_t (&ket)[LEN]) {
+  if ((uint32_t)r >= o.ucap) {
+    atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 4u);
+    return false;
+  }
+  reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN))[dedup_row_offset(LEN)] = r;
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) o.uniq_onv[(size_t)r * LEN + i] = ket[i];
+  return true;
 }
 
 // The wave writes the +1/-1 rows of the lanes flagged `flag` (all lanes of the wave must call): one coalesced store per row.
 template <int LEN, typename T>
 __device__ __forceinline__ void emit_rows(const OnepassOut<T> &o, int sorb, bool flag, const uint64_t (&ket)[LEN], int32_t row) {
-  if (!o.uniq_pm1) return;
+  if (!o.uniq_pm1 || (o.debug & 2u)) return;
   const int lane = threadIdx.x & 63;
   uint64_t m = __ballot(flag);
   while (m) {
@@ -206,26 +227,66 @@ __device__ __forceinline__ void emit_rows(const OnepassOut<T> &o, int sorb, bool
   }
 }
 
+// Lanes flagged `flag` own a new determinant (slot `slot`) that found no room in the workgroup's list: one atomic for the wave.
+// All lanes of the wave must call.
+template <int LEN, typename T>
+__device__ __forceinline__ void allocate_now(const OnepassOut<T> &o, int sorb, bool flag, uint32_t slot, const uint64_t (&ket)[LEN]) {
+  const uint64_t m = __ballot(flag);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  int32_t base = 0;
+  if (lane == leader) base = atomicAdd(o.counters, (int32_t)__popcll(m));
+  base = __shfl(base, leader);
+  const int32_t r = base + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
+  const bool ok = flag && assign_row<LEN, T>(o, slot, r, ket);
+  emit_rows<LEN, T>(o, sorb, ok, ket, r);
+}
+
+// End of a phase: the workgroup's new determinants get their rows.  Every thread of the block must call; contains barriers.
+template <int LEN, typename T>
+__device__ __forceinline__ void flush_winner_list(const OnepassOut<T> &o, const WinnerList &wl, int32_t *wl_base, const SDParams &p,
+                                                  const LdsLayout &L, const Walker<LEN> &wk) {
+  __syncthreads();
+  const uint32_t n = min(*wl.n, wl.cap);
+  if (threadIdx.x == 0 && n) *wl_base = atomicAdd(o.counters, (int32_t)n);
+  __syncthreads();
+  if (n) {
+    const int32_t base = *wl_base;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < n; i0 += blockDim.x) {
+      const uint32_t i = i0 + lane;
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = wk.w[w];
+      bool ok = false;
+      if (i < n) {
+        const uint32_t col = wl.col[i];
+        if (col) {
+          const Excitation x = decode(col - 1, p, L);
+          make_ket<LEN>(wk, x, ket);
+        }
+        ok = assign_row<LEN, T>(o, wl.slot[i], base + (int32_t)i, ket);
+      }
+      emit_rows<LEN, T>(o, p.sorb, ok, ket, base + (int32_t)i);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *wl.n = 0u;
+  __syncthreads();
+}
+
 // ---- phase A -------------------------------------------------------------------------------------------------------
 // Wave-private LDS: the wave's quarter of the singles staging scratch doubles as the buffer of a doubles tile's kept columns
-// (column, value); a few words for the running count and for the rows that lanes inside divergent code (singles, column 0)
-// won and the whole wave has to write at the end of the tile.
-constexpr int kStash = 24;
-
-template <int LEN>
-struct WaveLds {
-  volatile uint32_t *run;    // kept columns of the current doubles tile
-  volatile uint32_t *nstash;
-  int32_t *stash_row;        // [kStash]
-  uint64_t *stash_ket;       // [kStash][LEN]
-};
+// (column, value); one word for the running count.
 
 template <int LEN, typename T, bool SAMPLED>
 struct KeepSink {
   T eps;
   uint32_t chunk, nchunks, tS;
   int64_t seg_base;
-  WaveLds<LEN> W;
+  volatile uint32_t *run;  // kept columns of the current doubles tile (wave-private LDS)
+  WinnerList wl;
   uint32_t *bufc;
   T *bufh;
   volatile uint32_t *dstat;
@@ -238,14 +299,17 @@ struct KeepSink {
   uint32_t tile;
   double sub;
 
-  __device__ __forceinline__ void record(int64_t g, uint32_t col, T h, const uint64_t (&ket)[LEN], bool &won, int32_t &row) const {
+  // returns the de-duplication slot; unlisted: a new determinant whose row the caller has to allocate
+  __device__ __forceinline__ int32_t record(int64_t g, uint32_t col, T h, const uint64_t (&ket)[LEN], bool &unlisted) const {
     o.rec_col[g] = (int32_t)col;
     o.rec_w[g] = h;
     if (o.rec_onv) {
 #pragma unroll
       for (int i = 0; i < LEN; ++i) o.rec_onv[g * LEN + i] = ket[i];
     }
-    o.rec_link[g] = resolve_amplitude<LEN, T>(o, ket, won, row);
+    const int32_t link = resolve_amplitude<LEN, T>(o, wl, ket, col, unlisted);
+    o.rec_link[g] = link;
+    return link;
   }
 
   // a column with a fixed slot (called from divergent code: any set of lanes)
@@ -255,14 +319,17 @@ struct KeepSink {
       if constexpr (SAMPLED) sub += (double)a;
       return;  // (the slot was pre-filled with -1)
     }
-    bool won;
-    int32_t row;
-    record(seg_base + slot, col, h, ket, won, row);
-    if (won) {
-      const uint32_t k = atomicAdd(const_cast<uint32_t *>(W.nstash), 1u);
-      W.stash_row[k] = row;
-#pragma unroll
-      for (int i = 0; i < LEN; ++i) W.stash_ket[k * LEN + i] = ket[i];
+    bool unlisted;
+    const int32_t link = record(seg_base + slot, col, h, ket, unlisted);
+    if (unlisted) {  // (list full: this lane alone, inside divergent code -- rare)
+      const int32_t r = atomicAdd(o.counters, 1);
+      if (assign_row<LEN, T>(o, (uint32_t)link, r, ket) && o.uniq_pm1) {
+        for (int j = 0; j < p->sorb; ++j) {
+          const bool occ = (ket[j >> 6] >> (j & 63)) & 1ull;
+          if (o.pm1_f32) reinterpret_cast<float *>(o.uniq_pm1)[(size_t)r * p->sorb + j] = occ ? 1.0f : -1.0f;
+          else reinterpret_cast<double *>(o.uniq_pm1)[(size_t)r * p->sorb + j] = occ ? 1.0 : -1.0;
+        }
+      }
     }
   }
 
@@ -270,7 +337,7 @@ struct KeepSink {
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)__ballot(1)) - 1;
     uint32_t before = 0;
-    if (lane == leader) { before = *W.run; *W.run = before + total; }
+    if (lane == leader) { before = *run; *run = before + total; }
     return __shfl(before, leader);
   }
 
@@ -312,8 +379,8 @@ struct KeepSink {
   // Exclusive prefix of the kept counts of the doubles tiles before tile d (decoupled look-back, one window of 64 tiles per step).
   __device__ __forceinline__ uint32_t lookback(uint32_t d, uint32_t c) const {
     const int lane = threadIdx.x & 63;
-    if (d == 0) {
-      if (lane == 0) dstat[0] = kStatP | c;
+    if (d == 0 || (o.debug & 4u)) {
+      if (lane == 0) dstat[d] = kStatP | c;
       return 0;
     }
     if (lane == 0) dstat[d] = kStatA | c;
@@ -346,28 +413,15 @@ struct KeepSink {
       if (lane == 0) tsum[tile] = s;
     }
     wave_sync();
-    if (tile <= tS) {
-      // rows won inside the divergent code of column 0 / the singles
-      const uint32_t ns = *W.nstash;
-      if (ns) {
-        uint64_t ket[LEN];
-        const bool mine = (uint32_t)lane < ns;
-#pragma unroll
-        for (int i = 0; i < LEN; ++i) ket[i] = mine ? W.stash_ket[lane * LEN + i] : 0ull;
-        emit_rows<LEN, T>(o, p->sorb, mine, ket, mine ? W.stash_row[lane] : 0);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) *W.nstash = 0u;
-      }
-      return;
-    }
-    const uint32_t c = *W.run;
+    if (tile <= tS) return;  // column 0, the singles and the unpaired doubles wrote their fixed slots themselves
+    const uint32_t c = *run;
     const uint32_t excl = lookback(tile - 1 - tS, c);
     if (lane == 0 && c) atomicMax(kept_total, excl + c);
     for (uint32_t i0 = 0; i0 < c; i0 += 64) {
       const uint32_t i = i0 + lane;
       const bool act = i < c && excl + i < o.cap_d;
-      bool won = false;
-      int32_t row = -1;
+      bool unlisted = false;
+      int32_t link = -1;
       uint64_t ket[LEN];
 #pragma unroll
       for (int w = 0; w < LEN; ++w) ket[w] = 0ull;
@@ -375,16 +429,16 @@ struct KeepSink {
         const uint32_t col = bufc[i];
         const Excitation x = decode(col - 1, *p, *L);
         make_ket<LEN>(*wk, x, ket);
-        record(seg_base + o.fixed + excl + i, col, bufh[i], ket, won, row);
+        link = record(seg_base + o.fixed + excl + i, col, bufh[i], ket, unlisted);
       }
-      emit_rows<LEN, T>(o, p->sorb, won, ket, row);
+      if (__ballot(unlisted)) allocate_now<LEN, T>(o, p->sorb, unlisted, (uint32_t)link, ket);
     }
   }
   __device__ __forceinline__ void tile_begin(uint32_t t) {
     flush();
     tile = t;
     sub = 0.0;
-    if ((threadIdx.x & 63) == 0) *W.run = 0u;
+    if ((threadIdx.x & 63) == 0) *run = 0u;
     __builtin_amdgcn_wave_barrier();
   }
 };
@@ -411,6 +465,7 @@ struct DrawSink {
   uint64_t key;
   int64_t sbase;          // first drawn-record slot of this walker
   OnepassOut<T> o;
+  WinnerList wl;
   uint32_t tile;
 
   __device__ __forceinline__ void entry(uint32_t idx, uint32_t col, T h, double incl) const {
@@ -492,8 +547,8 @@ struct DrawSink {
       const uint32_t idx = i0 + lane;
       const uint32_t hc = idx < ncols ? S.hits[idx] : 0u;
       const uint64_t m = __ballot(hc != 0u);
-      bool won = false;
-      int32_t row = -1;
+      bool unlisted = false;
+      int32_t link = -1;
       uint64_t ket[LEN];
 #pragma unroll
       for (int w = 0; w < LEN; ++w) ket[w] = 0ull;
@@ -514,9 +569,10 @@ struct DrawSink {
 #pragma unroll
           for (int i = 0; i < LEN; ++i) o.srec_onv[at * LEN + i] = ket[i];
         }
-        o.srec_link[at] = resolve_amplitude<LEN, T>(o, ket, won, row);
+        link = resolve_amplitude<LEN, T>(o, wl, ket, col, unlisted);
+        o.srec_link[at] = link;
       }
-      emit_rows<LEN, T>(o, p->sorb, won, ket, row);
+      if (__ballot(unlisted)) allocate_now<LEN, T>(o, p->sorb, unlisted, (uint32_t)link, ket);
       pos += __popcll(m);
     }
   }
@@ -534,7 +590,7 @@ struct DrawSink {
 };
 
 // LDS after the walker tables and the staging scratch: dstat[max_tiles] | (SAMPLED) tsum[max_tiles] f64, dinfo[max_tiles], draw areas
-__host__ __device__ inline size_t onepass_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled) {
+__host__ __device__ inline size_t onepass_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t wl_cap) {
   size_t b = (lds_bytes(p, esz) + 15) & ~(size_t)15;
   b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
   if (sampled) {
@@ -542,18 +598,25 @@ __host__ __device__ inline size_t onepass_lds(const SDParams &p, size_t esz, uin
     b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
     b += (kBlock / 64) * kDrawLdsPerWave;
   }
-  return b;
+  return b + (size_t)wl_cap * 8;
+}
+
+// entries of a workgroup's list of new determinants: what one phase can win (all its draws; a few hundred kept columns), within the
+// LDS that is left
+__host__ inline uint32_t winner_list_cap(int eps_sample) {
+  uint32_t c = eps_sample > 256 ? (uint32_t)eps_sample : 256u;
+  c = (c + 63u) & ~63u;
+  return c > 2048u ? 2048u : c;
 }
 
 template <int LEN, typename T, bool SAMPLED>
 __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
                                                                 uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
-                                                                uint32_t nsample, uint64_t seed, OnepassOut<T> o) {
+                                                                uint32_t nsample, uint64_t seed, uint32_t wl_cap, OnepassOut<T> o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t next_tile, kept_total;
-  __shared__ uint32_t wave_run[kBlock / 64], wave_nstash[kBlock / 64];
-  __shared__ int32_t stash_row[kBlock / 64][kStash];
-  __shared__ uint64_t stash_ket[kBlock / 64][kStash * LEN];
+  __shared__ uint32_t next_tile, kept_total, wl_n;
+  __shared__ int32_t wl_base;
+  __shared__ uint32_t wave_run[kBlock / 64];
   __shared__ double s_part[kBlock / 64 + 1];
   __shared__ uint32_t s_parti[kBlock / 64 + 1];
   uint64_t walker;
@@ -562,13 +625,17 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
   const uint64_t slot = walker * nchunks + chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t seg_base = (int64_t)slot * ((int64_t)o.fixed + o.cap_d);
-  if (tid == 0) { next_tile = 0; kept_total = 0; }
-  if (lane == 0) wave_nstash[wave] = 0;
+  if (tid == 0) { next_tile = 0; kept_total = 0; wl_n = 0; }
   unsigned char *extra = smem + ((lds_bytes(p, sizeof(T)) + 15) & ~(size_t)15);
   volatile uint32_t *dstat = reinterpret_cast<volatile uint32_t *>(extra);
   extra += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
   double *tsum = reinterpret_cast<double *>(extra);
   uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
+  WinnerList wl;
+  wl.n = &wl_n;
+  wl.cap = wl_cap;
+  wl.slot = reinterpret_cast<uint32_t *>(smem + onepass_lds(p, sizeof(T), max_tiles, SAMPLED, 0));
+  wl.col = wl.slot + wl_cap;
   for (uint32_t i = tid; i < max_tiles; i += kBlock) {
     dstat[i] = 0u;
     if constexpr (SAMPLED) { tsum[i] = 0.0; dinfo[i] = 0u; }
@@ -588,7 +655,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
   {
     KeepSink<LEN, T, SAMPLED> sink;
     sink.eps = eps; sink.chunk = chunk; sink.nchunks = nchunks; sink.tS = tS; sink.seg_base = seg_base;
-    sink.W.run = wave_run + wave; sink.W.nstash = wave_nstash + wave; sink.W.stash_row = stash_row[wave]; sink.W.stash_ket = stash_ket[wave];
+    sink.run = wave_run + wave; sink.wl = wl;
     sink.bufh = quarter;
     sink.bufc = reinterpret_cast<uint32_t *>(quarter + kOneTileCols);
     sink.dstat = dstat; sink.tsum = tsum; sink.kept_total = &kept_total;
@@ -596,11 +663,13 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
     visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
     sink.flush();
   }
-  __syncthreads();
+  flush_winner_list<LEN, T>(o, wl, &wl_base, p, L, wk);  // (barriers inside: phase A is over for every wave)
   if (tid == 0) {
     o.seg_count[slot] = (int32_t)kept_total;
-    if (kept_total > o.cap_d) atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 1u);
-    atomicMax(o.counters + 2, (int32_t)kept_total);
+    if (kept_total > o.cap_d) {  // (what the largest overflowing segment needed; 0 when everything fitted)
+      atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 1u);
+      atomicMax(o.counters + 2, (int32_t)kept_total);
+    }
   }
   if constexpr (SAMPLED) {
     // ---- phase B: inclusive scan of the tile sums (fixed order of additions), the N draws over the tiles, slot offsets ----
@@ -666,9 +735,417 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
     S.cs = reinterpret_cast<uint32_t *>(mine + (size_t)kOneTileCols * 8 + 8);
     S.hits = S.cs + kOneTileCols;
     S.ncols = reinterpret_cast<volatile uint32_t *>(S.hits + kOneTileCols);
-    DrawSink<LEN, T> sink{eps, S, &p, &L, &wk, dinfo, Srow / (double)nsample, key, (int64_t)walker * nsample, o, 0xffffffffu};
+    DrawSink<LEN, T> sink{eps, S, &p, &L, &wk, dinfo, Srow / (double)nsample, key, (int64_t)walker * nsample, o, wl, 0xffffffffu};
     visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
     sink.flush();
+    flush_winner_list<LEN, T>(o, wl, &wl_base, p, L, wk);
+  }
+}
+
+
+// ====================================================================================================================
+// LIST form (the production regime: a few hundred kept columns per segment, e.g. the Fe2S2 example's eps = 1e-2).
+// The kept columns of a workgroup do not go through per-wave buffers and a look-back: every lane that keeps a column appends
+// (column, value) to ONE LDS list of the workgroup (an LDS atomic; 1 % of the columns).  When the row has been visited the
+// workgroup sorts the list by column -- records come out in ASCENDING COLUMN order, like the reference's boolean mask, whatever the
+// waves' timing was -- and only then, with all 256 lanes busy, forms the kets, writes the records and asks the wave-function table /
+// the de-duplication table for each of them: one round of probe latency per 256 records instead of one per tile.  New determinants
+// of a batch take their rows with one global atomic.  The drawn records of phase C are resolved the same way after the draws.
+// The look-back form above remains for segments whose kept columns do not fit the LDS list.
+
+template <int LEN, typename T>
+__device__ __forceinline__ int32_t probe_amplitude(const OnepassOut<T> &o, const uint64_t (&ket)[LEN], bool &won) {
+  won = false;
+  if (o.debug & 1u) return -1;
+  if (o.lut) {
+    const int64_t pos = hash_find<LEN>(o.lut, o.lut_cap, ket);
+    if (pos >= 0) return (int32_t)(-2 - pos);
+  }
+  const uint32_t s = dedup_insert<LEN>(o.dedup, o.dedup_mask, ket, won);
+  if (s == 0xffffffffu) {
+    won = false;
+    atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 2u);
+    return -1;
+  }
+  return (int32_t)s;
+}
+
+// The lanes of the WORKGROUP flagged `won` own new determinants (de-duplication slot `slot`): one global atomic for all of them,
+// then the slots' rows, the determinants and the +-1 rows.  Every thread of the block must call; contains barriers.
+template <int LEN, typename T>
+__device__ __forceinline__ void allocate_batch(const OnepassOut<T> &o, int sorb, bool won, uint32_t slot, const uint64_t (&ket)[LEN],
+                                               uint32_t *bw_cnt, int32_t *bw_base) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t m = __ballot(won);
+  uint32_t woff = 0;
+  if (m && lane == 0) woff = atomicAdd(bw_cnt, (uint32_t)__popcll(m));
+  woff = __shfl(woff, 0);
+  __syncthreads();
+  const uint32_t total = *bw_cnt;
+  if (threadIdx.x == 0 && total) *bw_base = atomicAdd(o.counters, (int32_t)total);
+  __syncthreads();
+  if (total) {
+    const int32_t r = *bw_base + (int32_t)woff + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const bool ok = won && assign_row<LEN, T>(o, slot, r, ket);
+    emit_rows<LEN, T>(o, sorb, ok, ket, r);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *bw_cnt = 0u;
+  __syncthreads();
+}
+
+template <int LEN, typename T, bool SAMPLED>
+struct ListKeepSink {
+  T eps;
+  uint32_t *list_n;
+  uint32_t *list_col;
+  T *list_h;
+  uint32_t cap;
+  double *tsum;
+  uint32_t tile;
+  double sub;
+  __device__ __forceinline__ void add(uint32_t col, T h) {
+    const T a = fabs(h);
+    if (a >= eps) {
+      const uint32_t k = atomicAdd(list_n, 1u);
+      if (k < cap) { list_col[k] = col; list_h[k] = h; }
+    } else if constexpr (SAMPLED) {
+      sub += (double)a;
+    }
+  }
+  __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&)[LEN]) { add(col, h); }
+  __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&)[LEN], uint32_t c1, T h1, const uint64_t (&)[LEN]) { add(c0, h0); add(c1, h1); }
+  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&)[LEN], const uint64_t (&)[LEN]) { add(col, h0); add(col + 1, h1); }
+  __device__ __forceinline__ void flush() {
+    if constexpr (SAMPLED) {
+      if (tile == 0xffffffffu) return;
+      const double s = op_wave_sum(sub);
+      if ((threadIdx.x & 63) == 0) tsum[tile] = s;
+    }
+  }
+  __device__ __forceinline__ void tile_begin(uint32_t t) { flush(); tile = t; sub = 0.0; }
+};
+
+// phase C of the LIST form: as DrawSink, but a drawn record only notes its column in the LDS array `pend` (one entry per draw
+// slot of the walker); kets, links and rows follow for all of them together
+template <int LEN, typename T>
+struct ListDrawSink {
+  T eps;
+  DrawLds S;
+  const uint32_t *dinfo;
+  double scale;
+  uint64_t key;
+  int64_t sbase;
+  int32_t *__restrict__ srec_col;
+  T *__restrict__ srec_w;
+  uint32_t *pend;
+  uint32_t tile;
+
+  __device__ __forceinline__ void entry(uint32_t idx, uint32_t col, T h, double incl) const {
+    S.prefix[idx] = incl;
+    S.cs[idx] = col | (h < T(0) ? 0x80000000u : 0u);
+  }
+  __device__ __forceinline__ double width(T h) const {
+    const T a = fabs(h);
+    return a >= eps ? 0.0 : (double)a;
+  }
+  __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&)[LEN]) const {
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(1);
+    const double w = width(h);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (lane == b) {
+        const uint32_t idx = *S.ncols;
+        const double incl = *S.run + w;
+        entry(idx, col, h, incl);
+        *S.ncols = idx + 1;
+        *S.run = incl;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&)[LEN], const uint64_t (&)[LEN]) const {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nact = (uint32_t)__popcll(__ballot(1));
+    const double w0 = width(h0), w1 = width(h1);
+    const double incl = op_scan(w0 + w1, lane);
+    const uint32_t base = *S.ncols;
+    const double run = *S.run;
+    entry(base + 2 * lane, col, h0, run + incl - w1);
+    entry(base + 2 * lane + 1, col + 1, h1, run + incl);
+    const double total = __shfl(incl, (int)nact - 1);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { *S.ncols = base + 2 * nact; *S.run = run + total; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&)[LEN], uint32_t c1, T h1, const uint64_t (&)[LEN]) const {
+    const int lane = threadIdx.x & 63;
+    const double w0 = width(h0), w1 = width(h1);
+    const double i0 = op_scan(w0, lane), t0 = __shfl(i0, 63);
+    const double i1 = op_scan(w1, lane), t1 = __shfl(i1, 63);
+    const uint32_t base = *S.ncols;
+    const double run = *S.run;
+    entry(base + lane, c0, h0, run + i0);
+    entry(base + 64 + lane, c1, h1, run + t0 + i1);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { *S.ncols = base + 128; *S.run = run + t0 + t1; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void flush() {  // wave-uniform
+    if (tile == 0xffffffffu) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t info = dinfo[tile];
+    const uint32_t draws = info & 0xffffu;
+    const uint32_t ncols = *S.ncols;
+    const double total = *S.run;
+    if (draws == 0 || ncols == 0 || !(total > 0.0)) return;
+    for (uint32_t k = lane; k < draws; k += 64) {
+      const uint64_t r = op_mix64(key ^ op_mix64(((uint64_t)tile << 32) | k));
+      const double target = (double)(r >> 11) * 0x1.0p-53 * total;
+      uint32_t lo = 0, hi = ncols;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (S.prefix[mid] > target) hi = mid; else lo = mid + 1;
+      }
+      if (lo >= ncols) lo = ncols - 1;
+      while (lo > 0 && !(S.prefix[lo] > S.prefix[lo - 1])) --lo;
+      atomicAdd(&S.hits[lo], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t pos = info >> 16;
+    for (uint32_t i0 = 0; i0 < ncols; i0 += 64) {
+      const uint32_t idx = i0 + lane;
+      const uint32_t hc = idx < ncols ? S.hits[idx] : 0u;
+      const uint64_t m = __ballot(hc != 0u);
+      if (hc) {
+        const uint32_t e = S.cs[idx], col = e & 0x7fffffffu;
+        const uint32_t at = pos + __popcll(m & ((1ull << lane) - 1ull));
+        srec_col[sbase + at] = (int32_t)col;
+        const double v = scale * (double)hc;
+        srec_w[sbase + at] = (T)((e >> 31) ? -v : v);
+        pend[at] = col;
+      }
+      pos += __popcll(m);
+    }
+  }
+  __device__ __forceinline__ bool skip_tile(uint32_t t) const { return (dinfo[t] & 0xffffu) == 0u; }
+  __device__ __forceinline__ void tile_begin(uint32_t t) {
+    flush();
+    tile = t;
+    if ((dinfo[t] & 0xffffu) == 0u) return;
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < kOneTileCols; i += 64) S.hits[i] = 0u;
+    if (lane == 0) { *S.ncols = 0u; *S.run = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+// LDS of the LIST form after the walker tables and the staging scratch:
+//   (SAMPLED) tsum[max_tiles] f64 | dinfo[max_tiles] u32 | draw areas ;  then the list: col[P] u32, h[P] T  (P = power of two >= capacity),
+//   which the draw slots' columns (pend[N] u32) re-use in phase C
+__host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample) {
+  size_t b = (lds_bytes(p, esz) + 15) & ~(size_t)15;
+  if (sampled) {
+    b += (size_t)max_tiles * 8;
+    b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
+    b += (kBlock / 64) * kDrawLdsPerWave;
+  }
+  const size_t list = (size_t)P * (4 + esz), pend = (size_t)nsample * 4;
+  return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
+}
+
+template <int LEN, typename T, bool SAMPLED>
+__global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
+                                                                     uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
+                                                                     uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t next_tile, list_n, bw_cnt;
+  __shared__ int32_t bw_base;
+  __shared__ double s_part[kBlock / 64 + 1];
+  __shared__ uint32_t s_parti[kBlock / 64 + 1];
+  uint64_t walker;
+  uint32_t chunk;
+  map_workgroup(nchunks, false, walker, chunk);
+  const uint64_t slot = walker * nchunks + chunk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P)
+  const int64_t seg_base = (int64_t)slot * cap;
+  if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; }
+  unsigned char *extra = smem + ((lds_bytes(p, sizeof(T)) + 15) & ~(size_t)15);
+  double *tsum = reinterpret_cast<double *>(extra);
+  uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
+  unsigned char *after = SAMPLED ? reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) : extra;
+  unsigned char *draw0 = after;
+  if (SAMPLED) after += (kBlock / 64) * kDrawLdsPerWave;
+  T *list_h = reinterpret_cast<T *>(after);                       // h first: 8-byte aligned
+  uint32_t *list_col = reinterpret_cast<uint32_t *>(list_h + P);
+  uint32_t *pend = reinterpret_cast<uint32_t *>(after);           // phase C re-uses the list's memory
+  if constexpr (SAMPLED) {
+    for (uint32_t i = tid; i < max_tiles; i += kBlock) { tsum[i] = 0.0; dinfo[i] = 0u; }
+    for (uint32_t i = tid; i < nsample; i += kBlock) o.srec_col[(int64_t)walker * nsample + i] = -1;
+  }
+  Walker<LEN> wk;
+  load_walker<LEN>(bra + walker * LEN, wk);
+  const LdsLayout L = carve_lds(smem, p);
+  const int nocc = build_walker_tables<LEN>(wk, p, L);
+  {
+    ListKeepSink<LEN, T, SAMPLED> sink{eps, &list_n, list_col, list_h, cap, tsum, 0xffffffffu, 0.0};
+    visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+    sink.flush();
+  }
+  __syncthreads();
+  // ---- the kept columns: sort by column, write, resolve ----
+  const uint32_t ntot = list_n;
+  const uint32_t n = min(ntot, cap);
+  if (tid == 0) {
+    o.seg_count[slot] = (int32_t)(ntot > o.fixed ? ntot - o.fixed : 0u);
+    if (ntot > cap) {
+      atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 1u);
+      atomicMax(o.counters + 2, (int32_t)(ntot - o.fixed));
+    }
+  }
+  for (uint32_t i = n + tid; i < P; i += kBlock) list_col[i] = 0xffffffffu;
+  for (uint32_t i = n + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
+  __syncthreads();
+  uint32_t Ps = 64;  // sort only as many entries as there are
+  while (Ps < n) Ps <<= 1;
+  for (uint32_t k = 2; k <= Ps; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < Ps; i += kBlock) {
+        const uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t a = list_col[i], b = list_col[ixj];
+          if ((a > b) == ((i & k) == 0)) {
+            list_col[i] = b; list_col[ixj] = a;
+            const T ha = list_h[i]; list_h[i] = list_h[ixj]; list_h[ixj] = ha;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i0 = 0; i0 < n; i0 += kBlock) {
+    const uint32_t i = i0 + tid;
+    bool won = false;
+    int32_t link = -1;
+    uint64_t ket[LEN];
+#pragma unroll
+    for (int w = 0; w < LEN; ++w) ket[w] = wk.w[w];
+    if (i < n) {
+      const uint32_t col = list_col[i];
+      if (col) {
+        const Excitation x = decode(col - 1, p, L);
+        make_ket<LEN>(wk, x, ket);
+      }
+      const int64_t g = seg_base + i;
+      o.rec_col[g] = (int32_t)col;
+      o.rec_w[g] = list_h[i];
+      if (o.rec_onv) {
+#pragma unroll
+        for (int w = 0; w < LEN; ++w) o.rec_onv[g * LEN + w] = ket[w];
+      }
+      link = probe_amplitude<LEN, T>(o, ket, won);
+      o.rec_link[g] = link;
+    }
+    allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
+  }
+  if constexpr (SAMPLED) {
+    // ---- phase B (as in the look-back form) ----
+    const uint32_t per = (max_tiles + kBlock - 1) / kBlock;
+    const uint32_t b0 = min((uint32_t)tid * per, max_tiles), b1 = min(b0 + per, max_tiles);
+    double local = 0.0;
+    for (uint32_t i = b0; i < b1; ++i) local += tsum[i];
+    double incl = op_scan(local, lane);
+    if (lane == 63) s_part[wave] = incl;
+    for (uint32_t i = tid; i < nsample; i += kBlock) pend[i] = 0xffffffffu;  // (the list is done with)
+    __syncthreads();
+    double before = 0.0, total = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) {
+      if (w < wave) before += s_part[w];
+      total += s_part[w];
+    }
+    double run = before + incl - local;
+    for (uint32_t i = b0; i < b1; ++i) { run += tsum[i]; tsum[i] = run; }
+    __syncthreads();
+    const double Srow = total;
+    if (tid == 0 && o.row_sum) o.row_sum[walker] = Srow;
+    const uint64_t key = op_mix64(seed ^ op_mix64(slot));
+    if (Srow > 0.0) {
+      for (uint32_t k = tid; k < nsample; k += kBlock) {
+        const uint64_t r = op_mix64(key ^ op_mix64(0xffffffff00000000ull | k));
+        const double target = (double)(r >> 11) * 0x1.0p-53 * Srow;
+        uint32_t lo = 0, hi = max_tiles;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (tsum[mid] > target) hi = mid; else lo = mid + 1;
+        }
+        if (lo >= max_tiles) lo = max_tiles - 1;
+        while (lo > 0 && !(tsum[lo] > tsum[lo - 1])) --lo;
+        atomicAdd(&dinfo[lo], 1u);
+      }
+    }
+    __syncthreads();
+    uint32_t lsum = 0;
+    for (uint32_t i = b0; i < b1; ++i) lsum += dinfo[i];
+    uint32_t iscan = lsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t ov = __shfl_up(iscan, d);
+      if (lane >= d) iscan += ov;
+    }
+    if (lane == 63) s_parti[wave] = iscan;
+    __syncthreads();
+    uint32_t ibefore = 0;
+    for (int w = 0; w < wave; ++w) ibefore += s_parti[w];
+    uint32_t off = ibefore + iscan - lsum;
+    for (uint32_t i = b0; i < b1; ++i) {
+      const uint32_t c = dinfo[i];
+      dinfo[i] = (off << 16) | c;
+      off += c;
+    }
+    if (tid == 0) next_tile = 0;
+    __syncthreads();
+    // ---- phase C: the draws inside the tiles ----
+    unsigned char *mine = draw0 + (size_t)wave * kDrawLdsPerWave;
+    DrawLds S;
+    S.prefix = reinterpret_cast<double *>(mine);
+    S.run = reinterpret_cast<volatile double *>(mine + (size_t)kOneTileCols * 8);
+    S.cs = reinterpret_cast<uint32_t *>(mine + (size_t)kOneTileCols * 8 + 8);
+    S.hits = S.cs + kOneTileCols;
+    S.ncols = reinterpret_cast<volatile uint32_t *>(S.hits + kOneTileCols);
+    {
+      ListDrawSink<LEN, T> sink{eps, S, dinfo, Srow / (double)nsample, key, (int64_t)walker * nsample, o.srec_col, o.srec_w, pend, 0xffffffffu};
+      visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+      sink.flush();
+    }
+    __syncthreads();
+    // ---- the drawn records: kets, links, rows, 256 at a time ----
+    for (uint32_t i0 = 0; i0 < nsample; i0 += kBlock) {
+      const uint32_t i = i0 + tid;
+      bool won = false;
+      int32_t link = -1;
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = wk.w[w];
+      const uint32_t col = i < nsample ? pend[i] : 0xffffffffu;
+      if (col != 0xffffffffu) {
+        if (col) {
+          const Excitation x = decode(col - 1, p, L);
+          make_ket<LEN>(wk, x, ket);
+        }
+        const int64_t at = (int64_t)walker * nsample + i;
+        if (o.srec_onv) {
+#pragma unroll
+          for (int w = 0; w < LEN; ++w) o.srec_onv[at * LEN + w] = ket[w];
+        }
+        link = probe_amplitude<LEN, T>(o, ket, won);
+        o.srec_link[at] = link;
+      }
+      allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
+    }
   }
 }
 
@@ -762,9 +1239,7 @@ static int onepass_geometry(int64_t nbatch, const SDParams &p, bool sampled, uin
   return 0;
 }
 
-static size_t onepass_static_lds(int len) {
-  return 8 + (kBlock / 64) * (8 + kStash * 4 + (size_t)kStash * 8 * len) + (kBlock / 64 + 1) * 12 + 64;
-}
+static size_t onepass_static_lds(int) { return 16 + (kBlock / 64) * 4 + (kBlock / 64 + 1) * 12 + 64; }
 
 extern "C" int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4) {
   SDParams p;
@@ -779,7 +1254,7 @@ extern "C" int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele,
   out4[0] = nbatch * (int64_t)nchunks;
   out4[1] = fixed;
   out4[2] = slots > 0 ? slots * dedup_slot_words(len) * 8 : 0;
-  out4[3] = onepass_lds(p, 8, max_tiles, eps_sample > 0) + onepass_static_lds(len) <= 160 * 1024 ? 1 : 0;
+  out4[3] = onepass_lds(p, 8, max_tiles, eps_sample > 0, winner_list_cap(eps_sample)) + onepass_static_lds(len) <= 160 * 1024 ? 1 : 0;
   return PYNQS_OK;
 }
 
@@ -792,6 +1267,8 @@ static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed
   o.lut = (const uint64_t *)io->lut_table; o.lut_cap = io->lut_table ? hash_capacity(io->lut_nkeys) : 0;
   o.uniq_onv = io->uniq_onv; o.uniq_pm1 = io->uniq_pm1; o.pm1_f32 = io->pm1_dtype == PYNQS_F32; o.ucap = (uint32_t)io->cap_unique;
   o.counters = io->counters; o.cap_d = (uint32_t)io->cap_doubles; o.fixed = fixed;
+  static const uint32_t dbg = getenv("PYNQS_OP_DEBUG") ? (uint32_t)atoi(getenv("PYNQS_OP_DEBUG")) : 0u;
+  o.debug = dbg;
   (void)len;
   return o;
 }
@@ -826,18 +1303,27 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   if (grid * ((uint64_t)fixed + (uint64_t)io->cap_doubles) > 0x7fffffffull * 16ull) return set_error(PYNQS_EINVAL, "record arrays too large");
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
-  const size_t lds = onepass_lds(p, esz, max_tiles, sampled);
+  const uint32_t wl_cap = winner_list_cap(eps_sample);
+  // LIST form when a segment's records fit an LDS list (PYNQS_OP_LIST=0 / 1 overrides; 1 only where it fits)
+  static const int list_env = getenv("PYNQS_OP_LIST") ? atoi(getenv("PYNQS_OP_LIST")) : -1;
+  const uint64_t seg_cap = (uint64_t)fixed + (uint64_t)io->cap_doubles;
+  uint32_t P = 64;
+  while (P < seg_cap && P < (1u << 20)) P <<= 1;
+  const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, P, (uint32_t)eps_sample);
+  const bool list_fits = seg_cap <= 2048 && lds_list + 256 <= 160 * 1024;
+  const bool use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024));
+  const size_t lds = use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, wl_cap);
   if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
   // eloc.py:257-264: with draws and eps <= 0 nothing is kept (every column can be drawn); without draws |H| >= eps as it stands
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
   do {                                                                                                                               \
-    auto kfn = reduce_onepass_kernel<LEN, TT, SM>;                                                                                   \
+    auto kfn = use_list ? reduce_onepass_list_kernel<LEN, TT, SM> : reduce_onepass_kernel<LEN, TT, SM>;                              \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                                (int)lds) != hipSuccess)                                                              \
       return check_launch("hipFuncSetAttribute");                                                                                   \
     hipLaunchKernelGGL(kfn, dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, chunk_len, max_tiles, (const TT *)plan, \
-                       (TT)eps_eff, (uint32_t)eps_sample, seed, make_out<TT>(io, len, fixed));                                       \
+                       (TT)eps_eff, (uint32_t)eps_sample, seed, use_list ? P : wl_cap, make_out<TT>(io, len, fixed));                \
   } while (0)
   DISPATCH_LEN(len, {
     if (dtype == PYNQS_F64) { if (sampled) PYNQS_OP_LAUNCH(double, true); else PYNQS_OP_LAUNCH(double, false); }
