@@ -840,6 +840,7 @@ struct ListDrawSink {
   T *__restrict__ srec_w;
   uint32_t *pend;
   uint32_t tile;
+  bool nodraw = false;
 
   __device__ __forceinline__ void entry(uint32_t idx, uint32_t col, T h, double incl) const {
     S.prefix[idx] = incl;
@@ -900,7 +901,7 @@ struct ListDrawSink {
     const uint32_t draws = info & 0xffffu;
     const uint32_t ncols = *S.ncols;
     const double total = *S.run;
-    if (draws == 0 || ncols == 0 || !(total > 0.0)) return;
+    if (draws == 0 || ncols == 0 || !(total > 0.0) || nodraw) return;
     for (uint32_t k = lane; k < draws; k += 64) {
       const uint64_t r = op_mix64(key ^ op_mix64(((uint64_t)tile << 32) | k));
       const double target = (double)(r >> 11) * 0x1.0p-53 * total;
@@ -943,11 +944,22 @@ struct ListDrawSink {
   }
 };
 
+// The LIST form keeps nothing in the staging scratch but the singles' and the diagonal's terms.  The sampled kernel, which is short
+// of LDS (draw areas), takes 256 elements per wave instead of 512: two rounds per singles tile, 3 -> 4 workgroups per CU
+// (1253 -> 1057 us per 8192 Fe2S2 walkers; 128 elements: 1148 us); the deterministic kernel keeps 512 (with 128 it loses 10 %).
+#ifndef PYNQS_LIST_Q_SAMPLED
+#define PYNQS_LIST_Q_SAMPLED 256
+#endif
+__host__ __device__ constexpr int list_quarter(bool sampled) { return sampled ? PYNQS_LIST_Q_SAMPLED : kDiagTile / 4; }
+__host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, bool sampled) {
+  return (lds_fixed_bytes(p) + esz * (size_t)(list_quarter(sampled) * (kBlock / 64)) + 15) & ~(size_t)15;
+}
+
 // LDS of the LIST form after the walker tables and the staging scratch:
 //   (SAMPLED) tsum[max_tiles] f64 | dinfo[max_tiles] u32 | draw areas ;  then the list: col[P] u32, h[P] T  (P = power of two >= capacity),
 //   which the draw slots' columns (pend[N] u32) re-use in phase C
 __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample) {
-  size_t b = (lds_bytes(p, esz) + 15) & ~(size_t)15;
+  size_t b = list_base_lds(p, esz, sampled);
   if (sampled) {
     b += (size_t)max_tiles * 8;
     b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
@@ -974,7 +986,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P)
   const int64_t seg_base = (int64_t)slot * cap;
   if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; }
-  unsigned char *extra = smem + ((lds_bytes(p, sizeof(T)) + 15) & ~(size_t)15);
+  unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED);
   double *tsum = reinterpret_cast<double *>(extra);
   uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
   unsigned char *after = SAMPLED ? reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) : extra;
@@ -993,7 +1005,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   const int nocc = build_walker_tables<LEN>(wk, p, L);
   {
     ListKeepSink<LEN, T, SAMPLED> sink{eps, &list_n, list_col, list_h, cap, tsum, 0xffffffffu, 0.0};
-    visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+    visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
     sink.flush();
   }
   __syncthreads();
@@ -1116,9 +1128,10 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     S.cs = reinterpret_cast<uint32_t *>(mine + (size_t)kOneTileCols * 8 + 8);
     S.hits = S.cs + kOneTileCols;
     S.ncols = reinterpret_cast<volatile uint32_t *>(S.hits + kOneTileCols);
-    {
+    if (!(o.debug & 16u)) {
       ListDrawSink<LEN, T> sink{eps, S, dinfo, Srow / (double)nsample, key, (int64_t)walker * nsample, o.srec_col, o.srec_w, pend, 0xffffffffu};
-      visit_tiles<LEN, T>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+      sink.nodraw = (o.debug & 8u) != 0;
+      visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
       sink.flush();
     }
     __syncthreads();

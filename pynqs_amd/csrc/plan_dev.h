@@ -23,13 +23,15 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <typename T, typename Sink>
+// QUARTER: elements of the wave's private part of L.scratch (default: a quarter of the kDiagTile elements a 256-thread workgroup
+// reserves; kernels that are short of LDS pass less and take more rounds)
+template <typename T, int QUARTER = kDiagTile / 4, typename Sink>
 __device__ __forceinline__ void diag_wave(const SDParams &p, const PlanLayout &pl, const LdsLayout &L,
                                           const T *__restrict__ plan, Sink sink) {
   const T *__restrict__ D1 = plan + pl.offD1;
   const T *__restrict__ D2 = plan + pl.offD2;
   // the wave's private quarter of L.scratch (other waves may be staging singles in theirs)
-  constexpr int kQuarter = kDiagTile / 4;
+  constexpr int kQuarter = QUARTER;
   T *tile = reinterpret_cast<T *>(L.scratch) + (threadIdx.x >> 6) * kQuarter;
   const int lane = threadIdx.x & 63;
   const int nele = p.nele;
@@ -94,14 +96,14 @@ __device__ __forceinline__ void diag_wave(const SDParams &p, const PlanLayout &p
 // sink(rank, value, table entry) is called by the summing lanes.
 constexpr int kSinglesPerTile = 16;
 
-template <typename T, typename Sink>
+template <typename T, int QUARTER = kDiagTile / 4, typename Sink>
 __device__ __forceinline__ void singles_tile(uint32_t r0, uint32_t r_end, const SDParams &p, const PlanLayout &pl,
                                              const LdsLayout &L, int nocc, const T *__restrict__ plan, Sink sink) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t K = (uint32_t)pl.K;
-  T *tile = reinterpret_cast<T *>(L.scratch) + wave * (kDiagTile / 4);
+  T *tile = reinterpret_cast<T *>(L.scratch) + wave * QUARTER;
   const int stride = nocc | 1;
-  const int cap = max(1, min(kSinglesPerTile, (kDiagTile / 4) / stride));  // singles per pass
+  const int cap = max(1, min(kSinglesPerTile, QUARTER / stride));  // singles per pass
   const T *__restrict__ S2 = plan + pl.offS2;
   const int G = nocc <= 16 ? 16 : (nocc <= 32 ? 32 : 64);
   const int gshift = nocc <= 16 ? 4 : (nocc <= 32 ? 5 : 6);

@@ -88,7 +88,7 @@ __host__ __device__ inline uint32_t max_tiles_per_chunk(const SDParams &p, uint3
 }
 
 // EXACT = true : <x|H|x> and the singles are summed in the reference's order (bit-identical values; needs the LDS
-//                staging scratch of lds_bytes(p, sizeof(T))).
+//                staging scratch of lds_bytes(p, sizeof(T)), or 4 * QUARTER elements when QUARTER is given).
 // EXACT = false: order-free sums (plan_dev.h: fast_diag / fast_single), no scratch (lds_bytes(p, 0)), 64 singles per
 //                tile: for sinks that only accumulate a rounded sum over all columns (fused local energies).
 constexpr int kSinglesPerFastTile = 64;
@@ -101,7 +101,7 @@ struct sink_can_skip : std::false_type {};
 template <typename S>
 struct sink_can_skip<S, std::void_t<decltype(std::declval<S &>().skip_tile(0u))>> : std::true_type {};
 
-template <int LEN, typename T, typename Sink, bool EXACT = true>
+template <int LEN, typename T, typename Sink, bool EXACT = true, int QUARTER = kDiagTile / 4>
 __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
                                             uint32_t chunk_len, uint32_t odd_base, uint32_t *next_tile, Sink &sink) {
@@ -162,7 +162,7 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
       }
       if (lo == 0) {
         if constexpr (EXACT) {
-          diag_wave<T>(p, pl, L, plan, [&](T v) {
+          diag_wave<T, QUARTER>(p, pl, L, plan, [&](T v) {
             uint64_t ket[LEN];
 #pragma unroll
             for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
@@ -183,7 +183,7 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
     if (tile <= tS) {
       const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSPT;
       if constexpr (EXACT) {
-        singles_tile<T>(r0, min(r0 + kSPT, p.d1), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
+        singles_tile<T, QUARTER>(r0, min(r0 + kSPT, p.d1), p, pl, L, nocc, plan, [&](uint32_t r, T v, uint32_t e) {
           uint64_t ket[LEN];
 #pragma unroll
           for (int i = 0; i < LEN; ++i) ket[i] = wk.w[i];
