@@ -11,7 +11,11 @@ line (the contract of the build prompt) with `roofline` (dominant kernel, live H
 `cpu_baseline` (reference/oracle timed on the host cores, rank 0, N = 1 only).
 
 Workloads (config.workload):
-  fe2s2_vmc_step (default)   one COMPLETE local-energy step of a VMC iteration on this rank's shard of the walkers
+  fe2s2_reduce_vmc_step (default)   one COMPLETE local-energy step of a VMC iteration with the method the Fe2S2 example runs: semi-stochastic
+                 REDUCE (eps = 1e-2, eps_sample = 1000): the one-launch REDUCE front end (enumerate, keep |H| >= eps, draw, de-duplicate,
+                 +-1 rows of the distinct x') -> amplitudes on the distinct rows (PyTorch module) -> contraction kernel -> moments +
+                 packed RCCL all-reduce -> gradient estimator.  See ReduceVmcStep.
+  fe2s2_vmc_step   the same step with the SAMPLE_SPACE method: one COMPLETE local-energy step of a VMC iteration on this rank's shard of the walkers
                  (BASELINE configs C3/C4 on the shipped Fe2S2 problem): fused SAMPLE_SPACE local energies (enumerate, <x|H|x'>,
                  psi(x') from the sample table, contraction: one kernel) -> weighted moments kernel + ONE packed RCCL all-reduce
                  of (sum p E, sum p |E|^2, sum p) -> gradient estimator: micro-batched backward of a complex128 module under
@@ -552,6 +556,221 @@ class VmcStep(SampleSpaceFused):
                 "one_thread": {"value": v1, "unit": "local energies/s", "cores": 1, "sample": f"{r1} x the same on the first {s1} walkers ({el1:.1f} s)"}}
 
 
+class ReduceVmcStep(Workload):
+    """One complete local-energy step with the method the Fe2S2 example itself runs (example/Fe2S2/Fe2S2-OO-dcut-20.py:103-113:
+    ElocMethod.REDUCE, eps = 1e-2, eps_sample = 1000; vmc/energy/eloc.py:205-324), for this rank's walker shard:
+      1. the REDUCE front end in ONE kernel (pynqs_reduce_onepass): every column of every walker's row enumerated, |<x|H|x'>| >= eps kept,
+         the N = 1000 draws of the reference's torch.multinomial drawn inside the kernel from the sub-eps part, every selected x'
+         de-duplicated through a hash table and the +-1 rows of the DISTINCT x' written as the amplitude module's input;
+      2. psi on the distinct x' by the amplitude module (PyTorch-ROCm; ~1.5 M rows per 8192 walkers);
+      3. E_loc(x) = sum_records w psi(x') / psi(x): one kernel (pynqs_reduce_contract);
+      4. <E>, var: weighted-moments kernel + ONE packed all-reduce over the ranks (RCCL);
+      5. the gradient estimator of vmc/grad/energy_grad.py:118-184 on the walkers (HIP-graph replay + one all-reduce of the flat
+         gradient buffer, or grad() under DistributedDataParallel with --eager-grad).
+    Nothing of size walkers x ncomb exists at any point, and nothing is read back between 1 and 5: buffers have fixed capacities
+    (sized by one calibration call outside the timed region) and the overflow word is checked after the timed region.
+    The amplitude module is a complex128 RBM (alpha = 1, seeded; ansatz families are outside this package) standing in for the
+    example's BDG-RNN."""
+
+    bound = "valu"
+
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev, eps=1e-2, eps_sample=1000, micro_batch=50000, graphed=True):
+        import torch.distributed as dist
+
+        from pynqs_amd import _native as N, C_extension as cx, energy as E, grad as G, reduce_front as RF
+        from pynqs_amd.rbm import ComplexRBM
+
+        self.N, self.cx, self.G, self.RF = N, cx, G, RF
+        self.name = f"{tag}_reduce_vmc_step"
+        self.kernel, self.pmc_name, self.path = "reduce_onepass_list_kernel", f"{tag}_reduce_vmc_step", "plan"
+        self.sorb, self.nele, self.noA, self.noB, self.dev = sorb, nele, noA, noB, dev
+        self.eps, self.eps_sample = eps, eps_sample
+        self.h1, self.h2, self.x = h1.to(dev), h2.to(dev), walkers.to(dev).contiguous()
+        self.n = self.x.size(0)
+        _, self.ncomb = algorithmic_bytes_dropin(sorb, nele, noA, noB)
+        st = torch.cuda.current_stream(dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        self.plan = cx.plan_for(self.h1, self.h2, sorb, dev)
+        e1.record(st); e1.synchronize()
+        self.plan_build_ms = e0.elapsed_time(e1)
+        g = torch.Generator().manual_seed(7)
+        m = ComplexRBM(0.02 * (torch.rand(sorb, sorb, 2, generator=g, dtype=torch.float64) - 0.5),
+                       0.02 * (torch.rand(sorb, 2, generator=g, dtype=torch.float64) - 0.5),
+                       0.05 * (torch.rand(sorb, 2, generator=g, dtype=torch.float64) - 0.5)).to(dev)
+        self.module = m
+        self.nqs = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) if dist.is_initialized() and not graphed else m
+        self.micro_batch = micro_batch
+        # calibration (untimed): one self-sizing call tells how many kept columns a walker has and how many distinct x' there are
+        fe0, nu = E.reduce_front(self.x, self.h1, self.h2, sorb, nele, noA, noB, eps, eps_sample, None, seed=1, pm1_dtype=torch.float64)
+        kept_max = int(fe0.seg_count[: fe0.nseg].max())
+        E._FRONTS.clear()
+        del fe0
+        torch.cuda.empty_cache()
+        self.front = RF.ReduceFrontEnd(self.n, sorb, nele, noA, noB, eps_sample, torch.float64, dev, int(kept_max * 1.25) + 16, int(nu * 1.1) + 1024,
+                                       torch.float64, keep_onv=False)
+        self.distinct_calibrated = nu
+        self.seed = 12345
+        self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
+        self.graphed = G.GraphedGrad(m, self.n, sorb, torch.complex128, dev) if graphed else None
+        if self.graphed is not None:
+            self.graphed.events = []
+        self.phase_events = []
+        self.stats = self.eloc = self.psi_x = None
+        self.roofline_note = ("one launch: enumeration of all columns (exact matrix elements), kept-column list sorted in LDS, in-kernel multinomial draw, "
+                              "re-enumeration of the drawn tiles, hash-table de-duplication, +-1 rows of the distinct x'; bound by vector-ALU "
+                              "instruction issue (index arithmetic of the enumeration), HBM traffic = the records and rows written")
+
+    def step(self):
+        st = torch.cuda.current_stream(self.dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        fe = self.front
+        ev[0].record(st)
+        self.seed += 1
+        fe.run(self.x, self.plan.buf, self.eps, self.seed, None)
+        ev[1].record(st)
+        with torch.no_grad():
+            psi_u = self.module(fe.uniq_pm1)  # all rows: static shape, nothing read back (rows beyond the distinct count are valid and unused)
+        ev[2].record(st)
+        self.eloc, self.psi_x = fe.contract(psi_u)
+        ev[3].record(st)
+        from pynqs_amd.distributed import get_world_size
+        from pynqs_amd.stats import dist_stats_moments
+
+        self.stats = dist_stats_moments(self.eloc, self.prob, None, get_world_size())
+        ev[4].record(st)
+        states = self.cx.onv_to_tensor(self.x, self.sorb)
+        for p in self.module.parameters():
+            p.grad = None
+        if self.graphed is not None:
+            self.loss = self.graphed(states, self.prob, self.eloc, self.stats[0])
+        else:
+            self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, torch.complex128, self.micro_batch)
+        ev[5].record(st)
+        self.phase_events.append(ev)
+        return ev[0], ev[1]
+
+    def phases_ms(self):
+        evs, self.phase_events = self.phase_events, []
+        if not evs:
+            return None
+        k = len(evs)
+        names = ("reduce_front_end_kernel_ms", "amplitudes_on_distinct_rows_ms", "contraction_kernel_ms", "stats_allreduce_ms", "grad_ms")
+        out = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in evs) / k for i, nm in enumerate(names)}
+        if self.graphed is not None and self.graphed.events:
+            ge = self.graphed.events[-k:]
+            out["grad_allreduce_ms"] = sum(a.elapsed_time(b) for a, b in ge) / len(ge)
+            self.graphed.events = []
+        cnt = self.front.counters_host()  # the one read-back, after the timed region
+        if self.front.overflowed(cnt):
+            raise SystemExit(f"REDUCE front end overflowed during the run: {cnt}")
+        out["distinct_rows_last_step"] = cnt[0]
+        out["distinct_rows_capacity"] = self.front.cap_unique
+        return out
+
+    def parity_gate(self):
+        """First walkers against the CPU oracle: the kept records are exactly |<x|H|x'>| >= eps of the oracle's row (bit for bit), the
+        drawn records are sub-eps columns whose weights are whole multiples of S / N adding up to N draws, and E_loc equals the sum
+        over these records evaluated on the host (amplitudes by the same module on the CPU)."""
+        from oracle import oracle as O
+
+        m = min(self.n, 8)
+        fe = self.front
+        walker, col, w, link, _, drawn = fe.records()
+        sel = walker < m
+        walker, col, w, link, drawn = walker[sel].cpu(), col[sel].cpu().long(), w[sel].cpu(), link[sel].cpu().long(), drawn[sel].cpu()
+        co, ho = O.comb_hij_fused(self.x[:m].cpu().numpy(), self.h1.cpu().numpy(), self.h2.cpu().numpy(), self.sorb, self.nele, self.noA, self.noB)
+        ho = torch.from_numpy(ho)
+        keep = ho.abs() >= self.eps
+        got = torch.zeros_like(keep)
+        got[walker[~drawn], col[~drawn]] = True
+        exact = bool(torch.equal(got, keep)) and bool(torch.equal(w[~drawn], ho[walker[~drawn], col[~drawn]]))
+        S = torch.where(keep, torch.zeros_like(ho), ho.abs()).sum(1)
+        hits = w[drawn].abs() * self.eps_sample / S[walker[drawn]]
+        exact = exact and bool(torch.allclose(hits, hits.round(), atol=1e-6)) and not bool(keep[walker[drawn], col[drawn]].any())
+        tot = torch.zeros(m, dtype=torch.float64).index_add_(0, walker[drawn], hits.round())
+        exact = exact and bool((tot == self.eps_sample).all())
+        rows = fe.table_rows().cpu().long()[link]
+        kets = torch.from_numpy(co).reshape(m, self.ncomb, -1)[walker, col]
+        assert bool(torch.equal(fe.uniq_onv.cpu()[rows], kets)), "a record's link does not lead to its determinant"
+        mod = type(self.module)(*(p.detach().cpu() for p in (self.module.params_weights, self.module.params_hidden_bias, self.module.params_visible_bias)))
+        bits = np.unpackbits(kets.numpy(), axis=1, bitorder="little")[:, : self.sorb].astype(np.float64) * 2 - 1
+        with torch.no_grad():
+            psi = mod(torch.from_numpy(bits))
+        num = torch.zeros(m, dtype=torch.complex128).index_add_(0, walker, w.to(torch.complex128) * psi)
+        p0 = torch.zeros(m, dtype=torch.complex128)
+        p0[walker[col == 0]] = psi[col == 0]
+        de = float((self.eloc[:m].cpu() - num / p0).abs().max())
+        return exact, de
+
+    def cpu_baseline(self, budget_s=20.0):
+        """The reference's own CPU extension (oracle/_ref, compiled from its sources where they lie) running the reference's _reduce_psi
+        algorithm (vmc/energy/eloc.py:243-318) with the same module evaluated by PyTorch on the host: get_comb_tensor -> get_hij_torch ->
+        |H| >= eps mask -> torch.multinomial on the sub-eps part -> unique -> Func (torch.unique(dim=0) + onv_to_tensor + module) ->
+        scatter -> contraction.  16 host threads, and 1 (run.sh:3)."""
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")
+        if not (self.sorb <= 64 and os.path.exists(os.path.join(ref_dir, "C_extension.so"))):
+            return None
+        sys.path.insert(0, ref_dir)
+        import C_extension as ref  # noqa: the reference module, MAX_SORB_LEN = 1
+
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        x = self.x.cpu(); h1 = self.h1.cpu(); h2 = self.h2.cpu()
+        mod = type(self.module)(*(p.detach().cpu() for p in (self.module.params_weights, self.module.params_hidden_bias, self.module.params_visible_bias)))
+        eps, N, sorb, nele, noA, noB = self.eps, self.eps_sample, self.sorb, self.nele, self.noA, self.noB
+        old = torch.get_default_dtype()
+
+        def fn(m):
+            xs = x[:m].contiguous()
+            comb = ref.get_comb_tensor(xs, sorb, nele, noA, noB, False)[0]
+            ncomb, L8 = comb.size(1), comb.size(2)
+            hij = ref.get_hij_torch(xs, comb, h1, h2, sorb, nele)
+            habs = hij.abs()
+            mask = habs >= eps
+            idx = torch.where(mask.flatten())[0]
+            hsub = torch.where(mask, 0, habs)
+            prob = hsub / hsub.sum(1, keepdim=True)
+            counts = torch.multinomial(prob, N, replacement=True)
+            counts += torch.arange(m).reshape(-1, 1) * ncomb
+            idx1, cnt = counts.unique(sorted=True, return_counts=True)
+            pf_ = prob.flatten()
+            hij.view(-1)[idx1] = (cnt / N) * hij.flatten()[idx1] / pf_[idx1]
+            sel = torch.cat([idx, idx1])
+            xk = comb.reshape(-1, L8)[sel]
+            uniq, inv = torch.unique(xk, dim=0, return_inverse=True)
+            with torch.no_grad():
+                psi = mod(ref.onv_to_tensor(uniq, sorb))[inv]
+            full = torch.zeros(m * ncomb, dtype=psi.dtype)
+            full[sel] = psi
+            full = full.reshape(m, ncomb)
+            return ((full.T / full[:, 0]).T * hij).sum(-1)
+
+        def run(threads, budget):
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter(); fn(32); per = (time.perf_counter() - t0) / 32
+            sample = int(max(32, min(self.n, 1024, budget * 0.25 / max(per, 1e-9))))
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget * 0.8 and reps < 100:
+                e = fn(sample); reps += 1
+            el = time.perf_counter() - t0
+            return sample * reps / el, sample, reps, el, e
+
+        try:
+            torch.set_default_dtype(torch.float64)
+            v16, s16, r16, el16, e = run(cores, budget_s)
+            v1, s1, r1, el1, _ = run(1, 4.0)
+        finally:
+            torch.set_default_dtype(old)
+            torch.set_num_threads(cores)
+        # the estimator is stochastic on both sides: compare the batch means of the same walkers
+        dmean = abs(complex(e.mean()) - complex(self.eloc[: e.numel()].mean().cpu()))
+        return {"value": v16, "unit": "local energies/s", "cores": cores, "kind": "reference",
+                "sample": f"{r16} x (reference get_comb_tensor + get_hij_torch + multinomial selection + unique + module on the host + contraction, "
+                          f"eloc.py:243-318) on the first {s16} walkers of the same batch ({el16:.1f} s)",
+                "abs_diff_of_mean_eloc_gpu_vs_reference_same_walkers": dmean,
+                "one_thread": {"value": v1, "unit": "local energies/s", "cores": 1, "sample": f"{r1} x the same on the first {s1} walkers ({el1:.1f} s)"}}
+
+
 class DecoderAmplitude(torch.nn.Module):
     """Stand-in for BASELINE.json's 'Transformer ansatz' (DecoderWaveFunction defaults d_model 32, 6 layers,
     8 heads, vmc/ansatz/transformer/decoder.py:43-69): an autoregressive decoder over the sorb/2 spatial orbitals (4 occupation
@@ -579,6 +798,12 @@ class DecoderAmplitude(torch.nn.Module):
 
 
 def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", keys: int = 65536, graphed: bool = True) -> Workload:
+    if name == "fe2s2_reduce_vmc_step":
+        d = load_fe2s2()
+        ci = d["ci_space"]
+        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        return ReduceVmcStep("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
+                             torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev, graphed=graphed)
     if name == "fe2s2_vmc_step":
         d = load_fe2s2()
         ci = d["ci_space"]
@@ -634,7 +859,7 @@ def main():
     # W warm-up steps, so that short runs (--steps 20) measure sustained clocks too
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="fe2s2_vmc_step")
+    ap.add_argument("--workload", default="fe2s2_reduce_vmc_step")
     ap.add_argument("--walkers", type=int, default=8192, help="walkers per GPU")
     ap.add_argument("--keys", type=int, default=65536, help="sample-space size of the syn<sorb>_eloc_sample_space workloads")
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
@@ -807,21 +1032,23 @@ def main():
                            ("; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p); gradient estimator: " +
                             ("HIP-graph replay + one RCCL all-reduce of the flat gradient buffer (mean over ranks, as DDP)" if wl.graphed is not None
                              else "DDP bucketed RCCL all-reduce in the last micro-batch's backward"))
-                           if isinstance(wl, VmcStep) else "; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p)" if hasattr(wl, "stats")
+                           if isinstance(wl, (VmcStep, ReduceVmcStep)) else "; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p)" if hasattr(wl, "stats")
                            else "; no data-path collective")},
             "roofline": roofline(wl, kern_ms),
             "parity": {"exact_part_bit_exact": bool(ok_c), "max_abs_diff_vs_oracle": dh} if ok_c is not None
                       else "oracle too slow at this size (tests/ cover the kernel at sizes it finishes)",
         }
-        if isinstance(wl, VmcStep):
+        if isinstance(wl, (VmcStep, ReduceVmcStep)):
             out["step_phases_gpu_ms"] = phases
             out["config"]["amplitude_module"] = "complex128 RBM, alpha = 1 (stand-in for the example's BDG-RNN), AD_MAX_DIM = %d as in example/Fe2S2 (one micro-batch for 8192 walkers)" % wl.micro_batch
+        if isinstance(wl, ReduceVmcStep):
+            out["config"].update({"method": "REDUCE (vmc/energy/eloc.py:205-324), the Fe2S2 example's setting", "eps": wl.eps, "eps_sample": wl.eps_sample})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
     # secondary measurements (same run, N = 1 only): drop-in rows, the other fused local energies and the larger word counts
-    if world == 1 and not args.no_extra and args.workload in ("fe2s2_dropin", "fe2s2_vmc_step"):
+    if world == 1 and not args.no_extra and args.workload in ("fe2s2_dropin", "fe2s2_vmc_step", "fe2s2_reduce_vmc_step"):
         extra = {}
-        for name, nw, steps in (("fe2s2_dropin", args.walkers, 2000), ("fe2s2_eloc_sample_space", args.walkers, 1000), ("fe2s2_eloc_rbm", args.walkers, 500),
+        for name, nw, steps in (("fe2s2_vmc_step", args.walkers, 300), ("fe2s2_dropin", args.walkers, 2000), ("fe2s2_eloc_sample_space", args.walkers, 1000), ("fe2s2_eloc_rbm", args.walkers, 500),
                                 ("syn56_eloc_rbm", 4096, 200), ("syn120_dropin", 64, 500), ("syn184_dropin", 16, 200),
                                 ("syn120_eloc_sample_space", args.walkers, 10), ("syn120_eloc_rbm", 512, 10),
                                 ("syn184_eloc_sample_space", args.walkers, 10), ("syn184_eloc_rbm", 128, 3)):
@@ -834,7 +1061,9 @@ def main():
                                   "ms_per_step": el2 / steps * 1e3, "roofline": roofline(w2, k2),
                                   "parity": {"exact_part_bit_exact": bool(ok2), "max_abs_diff_vs_oracle": d2} if ok2 is not None
                                             else "oracle too slow at this size (tests/ cover the kernel at sizes it finishes)"}
-                if name in ("fe2s2_dropin", "fe2s2_eloc_rbm") and not args.no_cpu_baseline:
+                if hasattr(w2, "phases_ms"):
+                    extra[w2.name]["step_phases_gpu_ms"] = w2.phases_ms()
+                if name in ("fe2s2_dropin", "fe2s2_eloc_rbm", "fe2s2_vmc_step") and not args.no_cpu_baseline:
                     extra[w2.name]["cpu_baseline"] = w2.cpu_baseline(budget_s=8.0)
                 del w2
                 torch.cuda.empty_cache()

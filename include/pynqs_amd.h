@@ -332,7 +332,9 @@ typedef struct pynqs_reduce_io {
   const void *lut_table;  /* pynqs_hash_build table of the wave-function keys, or NULL */
   int64_t lut_nkeys;
   int32_t *counters;    /* [4] out: distinct determinants needed, overflow bits (1 doubles, 2 table, 4 distinct list),
-                           largest seg_count, reserved */
+                           largest seg_count of an overflowing segment, reserved */
+  const uint64_t *seed_dev; /* optional: a seed in DEVICE memory, added to `seed` (a captured HIP graph replays the launch with
+                               the same arguments: the caller bumps this word between replays) */
 } pynqs_reduce_io;
 int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,

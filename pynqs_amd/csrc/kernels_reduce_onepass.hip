@@ -82,6 +82,7 @@ struct OnepassOut {
   uint32_t ucap;
   int32_t *counters;
   uint32_t cap_d, fixed;
+  const uint64_t *seed_dev;
   uint32_t debug;  // PYNQS_OP_DEBUG ablations (timing only): 1 no amplitude source, 2 no +-1 rows, 4 no look-back
 };
 
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
     __syncthreads();
     const double Srow = total;
     if (tid == 0 && o.row_sum) o.row_sum[walker] = Srow;
-    const uint64_t key = op_mix64(seed ^ op_mix64(slot));
+    const uint64_t key = op_mix64((o.seed_dev ? seed + *o.seed_dev : seed) ^ op_mix64(slot));
     if (Srow > 0.0) {
       for (uint32_t k = tid; k < nsample; k += kBlock) {
         const uint64_t r = op_mix64(key ^ op_mix64(0xffffffff00000000ull | k));
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     __syncthreads();
     const double Srow = total;
     if (tid == 0 && o.row_sum) o.row_sum[walker] = Srow;
-    const uint64_t key = op_mix64(seed ^ op_mix64(slot));
+    const uint64_t key = op_mix64((o.seed_dev ? seed + *o.seed_dev : seed) ^ op_mix64(slot));
     if (Srow > 0.0) {
       for (uint32_t k = tid; k < nsample; k += kBlock) {
         const uint64_t r = op_mix64(key ^ op_mix64(0xffffffff00000000ull | k));
@@ -1282,6 +1283,7 @@ static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed
   o.counters = io->counters; o.cap_d = (uint32_t)io->cap_doubles; o.fixed = fixed;
   static const uint32_t dbg = getenv("PYNQS_OP_DEBUG") ? (uint32_t)atoi(getenv("PYNQS_OP_DEBUG")) : 0u;
   o.debug = dbg;
+  o.seed_dev = io->seed_dev;
   (void)len;
   return o;
 }

@@ -88,6 +88,7 @@ class ReduceFrontEnd:
         # so that a captured step may run the ansatz on all cap_unique rows
         self.uniq_pm1 = torch.ones((self.cap_unique, sorb), dtype=pm1_dtype, device=dev)
         self.counters = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # added to run()'s seed: bump it between the replays of a captured step
         self._lut = None
         self._io = self._make_io()
 
@@ -106,6 +107,7 @@ class ReduceFrontEnd:
         io.lut_table = lut.table.data_ptr() if lut is not None else None
         io.lut_nkeys = lut.nkeys if lut is not None else 0
         io.counters = self.counters.data_ptr()
+        io.seed_dev = self.seed_dev.data_ptr()
         return io
 
     # ---- launches -------------------------------------------------------------------------------------------------------
@@ -177,3 +179,58 @@ class ReduceFrontEnd:
         drawn = torch.cat([torch.zeros(p[0].numel(), dtype=torch.bool, device=dev) if i == 0 else torch.ones(p[0].numel(), dtype=torch.bool, device=dev)
                            for i, p in enumerate(parts)])
         return cat(0), cat(1), cat(2), cat(3), (cat(4) if self.rec_onv is not None else None), drawn
+
+
+class ReduceStep:
+    """REDUCE local energies of a fixed batch shape with nothing read back on the way:
+        front end (one kernel) -> `amplitude` on ALL cap_unique rows of the distinct list -> contraction (one kernel).
+    The shapes are static (rows beyond the distinct count hold valid +-1 rows whose amplitudes nobody reads), so the whole step can
+    be replayed from a HIP graph (graph=True: captured on first use; the draw seed lives in device memory and is bumped inside the
+    graph).  `check()` is the one read-back: call it whenever convenient (e.g. with the energy statistics of the step); it raises
+    OverflowError when a buffer was too small -- the results of that step must then be discarded and the step rebuilt larger."""
+
+    def __init__(self, front: ReduceFrontEnd, plan: Tensor, eps: float, amplitude, lut=None, lut_values: Optional[Tensor] = None,
+                 seed: int = 0, graph: bool = False) -> None:
+        self.front, self.plan, self.eps, self.amplitude = front, plan, float(eps), amplitude
+        self.lut, self.lut_values, self.seed = lut, lut_values, int(seed)
+        self.x = torch.zeros((front.n, 8 * front.L), dtype=torch.uint8, device=front.device)
+        self.eloc = self.psi_x = None
+        self._graph = None
+        self._want_graph = graph
+
+    def _body(self) -> None:
+        fe = self.front
+        fe.run(self.x, self.plan, self.eps, self.seed, self.lut)
+        if fe.eps_sample:
+            fe.seed_dev.add_(1)
+        with torch.no_grad():
+            psi_u = self.amplitude(fe.uniq_pm1)
+        self.eloc, self.psi_x = fe.contract(psi_u, self.lut_values)
+
+    def __call__(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        self.x.copy_(x)
+        if not self._want_graph:
+            self._body()
+        elif self._graph is None:
+            # warm up on a side stream (allocator pools, lazily loaded kernels), then capture
+            s = torch.cuda.Stream(self.front.device)
+            s.wait_stream(torch.cuda.current_stream(self.front.device))
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    self._body()
+            torch.cuda.current_stream(self.front.device).wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self._graph = g
+            g.replay()
+        else:
+            self._graph.replay()
+        return self.eloc, self.psi_x
+
+    def check(self) -> Tuple[int, int, int]:
+        cnt = self.front.counters_host()
+        if self.front.overflowed(cnt):
+            raise OverflowError(f"REDUCE front end too small: needed {cnt[0]} distinct rows (capacity {self.front.cap_unique}), "
+                                f"{cnt[2]} kept columns in a segment (capacity {self.front.cap_doubles}), flags {cnt[1]}")
+        return cnt

@@ -11,4 +11,4 @@ for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VME
   timeout -k 5 90 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra "$@" > $out/pmc_$name.log 2>&1 || echo "pmc pass $c failed" >> $out/errors.log
 done
 python3 tools/summarize_prof.py $out $out/summary > /dev/null 2>&1
-grep -A40 "comb_hij_plan_kernel\|filtered_kernel\|eloc_rbm_kernel\|eloc_sample_space_keys_kernel" $out/summary.txt | head -${LINES_OUT:-120}
+grep -A40 "comb_hij_plan_kernel\|filtered_kernel\|eloc_rbm_kernel\|eloc_sample_space_keys_kernel\|reduce_onepass\|reduce_contract" $out/summary.txt | head -${LINES_OUT:-120}
