@@ -1,0 +1,143 @@
+"""The semi-stochastic REDUCE local energies of every form, and local energies with the Fe2S2 example's own amplitude, against
+the reference's Python at 1e-8 Ha ABSOLUTE (|E_loc| <= 155 Ha in every vector: printed by tests/golden/make_golden_r3.py).
+
+  * eloc_reduce_sampled_fe2s2.npz: vmc/energy/eloc.py:257-296 and flip.py:205-236 (eps = 1e-2, eps_sample = 200) -- plain, + look-up table,
+    complex128 module, spin-flip projected, multi-psi, both, <S-S+>.  The reference ran with torch.multinomial answering with the draws
+    of OUR kernel for torch.manual_seed(20240) (tests/golden/reduce_draws_fe2s2.npz, written by tests/golden/dump_reduce_draws.py on
+    the GPU box): the same seed here reproduces the draws, so the comparison is exact, not statistical.
+  * eloc_bdg_rnn_fe2s2.npz: psi of the reference's Graph_MPS_RNN with the shipped parameters (complex128, |psi| over 24 decades) on
+    every x' the selections touch, fed through a table-backed module: REDUCE, semi-stochastic REDUCE and SAMPLE_SPACE."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8  # Ha, absolute
+SYS = (40, 30, 15, 15)
+
+
+class Holder:
+    def __init__(self, sample, extra):
+        self.module = types.SimpleNamespace(sample=sample, extra=extra)
+
+
+class TableAmplitude(torch.nn.Module):
+    """psi(x) by look-up of the determinant in a table of the reference's amplitudes: forward(+-1 rows [n, sorb]) -> psi[n]"""
+
+    def __init__(self, keys, psi, sorb):
+        super().__init__()
+        from pynqs_amd import public_function as pf
+
+        self.lut = pf.WavefunctionLUT(keys, psi, sorb, device=keys.device)
+        self.sorb = sorb
+
+    def forward(self, x):
+        from pynqs_amd import C_extension as cx
+
+        onv = cx.tensor_to_onv((x > 0).to(torch.uint8), self.sorb)
+        pos, found = self.lut.find(onv)
+        assert bool(found.all()), "the selection touched a determinant the reference's run did not"
+        return self.lut.wf_value[pos]
+
+
+@pytest.fixture(scope="module")
+def env(fe2s2):
+    from pynqs_amd import energy, public_function as pf
+    from pynqs_amd.rbm import ComplexRBM, RealRBM
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    torch.set_default_dtype(torch.float64)
+    d0, d2 = golden("eloc_e2e_fe2s2.npz"), golden("eloc_flip_multipsi_fe2s2.npz")
+    g = golden("eloc_reduce_sampled_fe2s2.npz")
+    rbm = RealRBM(T(d0["W"]), T(d0["hb"]), T(d0["vb"])).to(dev)
+    extra = RealRBM(T(d2["W2"]), T(d2["hb2"]), T(d2["vb2"])).to(dev)
+    crbm = ComplexRBM(T(d2["Wc"]), T(d2["hbc"]), T(d2["vbc"])).to(dev)
+    pf.SpinProjection.init(30, 0)
+    assert pf.SpinProjection.eta == int(g["eta"])
+    e = dict(energy=energy, pf=pf, g=g, dev=dev, T=T, h1e=T(fe2s2["h1e"]), h2e=T(fe2s2["h2e"]), x=T(g["x"]), rbm=rbm, crbm=crbm,
+             multi=Holder(rbm, extra), en=torch.tensor(float(g["extra_norm"]), device=dev), enm=torch.tensor(float(g["extra_norm_multi"]), device=dev),
+             lut=pf.WavefunctionLUT(T(g["lut_keys"]), T(g["lut_wf"]), 40, device=dev), h1s=T(g["h1e_spin"]), h2s=T(g["h2e_spin"]))
+    yield e
+    torch.set_default_dtype(torch.float32)
+
+
+CASES = {
+    "plain": ("rbm", torch.double, lambda v: {}),
+    "lut": ("rbm", torch.double, lambda v: dict(WF_LUT=v["lut"])),
+    "complex": ("crbm", torch.complex128, lambda v: {}),
+    "flip": ("rbm", torch.double, lambda v: dict(use_spin_flip=True, extra_norm=v["en"])),
+    "flip_lut": ("rbm", torch.double, lambda v: dict(use_spin_flip=True, extra_norm=v["en"], WF_LUT=v["lut"])),
+    "multi": ("multi", torch.double, lambda v: dict(use_multi_psi=True, extra_norm=v["enm"])),
+    "flip_multi": ("multi", torch.double, lambda v: dict(use_spin_flip=True, use_multi_psi=True, extra_norm=v["enm"])),
+    "spin_raising": ("rbm", torch.double, lambda v: dict(use_spin_raising=True, h1e_spin=v["h1s"], h2e_spin=v["h2s"])),
+    "flip_spin_raising": ("rbm", torch.double, lambda v: dict(use_spin_flip=True, extra_norm=v["en"], use_spin_raising=True, h1e_spin=v["h1s"], h2e_spin=v["h2s"])),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_semi_stochastic_reduce_matches_reference_python(env, name):
+    energy, pf, g = env["energy"], env["pf"], env["g"]
+    key, dt, kw = CASES[name]
+    ab = lambda x, func: pf.ansatz_batch(func, x, 100000, 40, env["dev"], dt)  # noqa: E731
+    assert energy._front_ok(env["x"], env["h1e"], *SYS, int(g["eps_sample"]))  # the fused front end is what runs
+    torch.manual_seed(int(g["torch_seed"]))
+    e, s, p, _ = energy.local_energy(env["x"], env["h1e"], env["h2e"], env[key], ab, *SYS, dtype=dt, reduce_psi=True, eps=float(g["eps"]),
+                                     eps_sample=int(g["eps_sample"]), **kw(env))
+    assert e.dtype == dt
+    assert float(np.abs(g["eloc_" + name]).max()) < 200.0  # (absolute tolerance on numbers of this size)
+    np.testing.assert_allclose(p.cpu().numpy(), g["psi_" + name], rtol=1e-12)
+    np.testing.assert_allclose(e.cpu().numpy(), g["eloc_" + name], rtol=0, atol=TOL)
+    np.testing.assert_allclose(s.cpu().numpy(), g["sloc_" + name], rtol=0, atol=TOL)
+    if "spin_raising" in name:
+        assert float(np.abs(g["sloc_" + name]).max()) > 1e-3
+
+
+def test_the_kernel_draws_what_the_fixture_says(env):
+    """the draws the reference was given (reduce_draws_fe2s2.npz) are the draws of this build for the same seed"""
+    energy = env["energy"]
+    d = golden("reduce_draws_fe2s2.npz")
+    torch.manual_seed(int(d["torch_seed"]))
+    seed = energy._draw_seed()
+    assert seed == int(d["kernel_seed"])
+    energy._FRONTS.clear()
+    fe, _ = energy.reduce_front(env["x"], env["h1e"], env["h2e"], *SYS, float(d["eps"]), int(d["eps_sample"]), None, seed=seed)
+    walker, col, w, _, _, drawn = fe.records()
+    hits = (w[drawn].abs() * int(d["eps_sample"]) / fe.row_sum[: env["x"].size(0)][walker[drawn]]).round().long()
+    order = torch.argsort(walker[drawn] * 10000 + col[drawn].long())
+    want = np.argsort(d["draw_walker"].astype(np.int64) * 10000 + d["draw_col"])
+    assert np.array_equal(walker[drawn][order].cpu().numpy(), d["draw_walker"][want]) and np.array_equal(col[drawn][order].cpu().numpy(), d["draw_col"][want])
+    assert np.array_equal(hits[order].cpu().numpy(), d["draw_hits"][want])
+
+
+def test_local_energies_with_the_examples_bdg_rnn_amplitude(env, fe2s2):
+    energy, pf, dev, T = env["energy"], env["pf"], env["dev"], env["T"]
+    b = golden("eloc_bdg_rnn_fe2s2.npz")
+    amp = np.abs(b["table_psi"])
+    assert amp[amp > 0].min() < 1e-30 and amp.max() > 1e-9          # |psi| over more than 20 decades
+    assert max(float(np.abs(b[k]).max()) for k in ("eloc_reduce", "eloc_sampled", "eloc_ss")) < 200.0
+    x = T(b["x"])
+    keys, psi = T(b["table_keys"]), T(b["table_psi"])
+    module = TableAmplitude(keys, psi, 40)
+    ab = lambda x_, func: pf.ansatz_batch(func, x_, 100000, 40, dev, torch.complex128)  # noqa: E731
+    le = lambda **kw: energy.local_energy(x, env["h1e"], env["h2e"], module, ab, *SYS, dtype=torch.complex128, **kw)  # noqa: E731
+    e, _, p, _ = le(reduce_psi=True, eps=float(b["eps"]), eps_sample=0)
+    np.testing.assert_allclose(p.cpu().numpy(), b["psi_reduce"], rtol=1e-13)
+    np.testing.assert_allclose(e.cpu().numpy(), b["eloc_reduce"], rtol=0, atol=TOL)
+    torch.manual_seed(int(b["torch_seed"]))
+    e, _, p, _ = le(reduce_psi=True, eps=float(b["eps"]), eps_sample=int(b["eps_sample"]))
+    np.testing.assert_allclose(e.cpu().numpy(), b["eloc_sampled"], rtol=0, atol=TOL)
+    lut = pf.WavefunctionLUT(keys, psi, 40, device=dev)
+    for force in (True, False):  # key-major and column-major SAMPLE_SPACE kernels
+        old, energy.SS_KEYS = energy.SS_KEYS, force
+        try:
+            e, _, p, _ = le(use_sample_space=True, WF_LUT=lut)
+        finally:
+            energy.SS_KEYS = old
+        np.testing.assert_allclose(p.cpu().numpy(), b["psi_ss"], rtol=1e-13)
+        np.testing.assert_allclose(e.cpu().numpy(), b["eloc_ss"], rtol=0, atol=TOL)
