@@ -62,7 +62,7 @@ def test_c2_sorb56_4096_walkers():
     e_ref, p_ref = O.eloc_simple_rbm(onv_np[:64], h1, h2, sorb, 2 * no, no, no, W, hb, vb)
     e, p = cx.eloc_rbm(x[:64].contiguous(), h1e, h2e, cx.RBMTable(G(W), G(hb), G(vb)), sorb, 2 * no, no, no)
     np.testing.assert_allclose(p.cpu().numpy(), p_ref, rtol=1e-11)
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"|E_loc|max = {float(np.abs(e_ref).max()):.6g} Ha")
 
 
 def _rbm_eloc_logdomain(O, comb_row, hm_row, sorb, W, hb, vb, chunk=1 << 19):
@@ -115,11 +115,11 @@ def test_half_filled_multiword(sorb, no, n, H):
     e, _, p0, _ = energy.local_energy(x, h1e, h2e, None, None, sorb, 2 * no, no, no, WF_LUT=lut, use_sample_space=True, dtype=torch.complex128)
     e_ref, p_ref = O.eloc_sample_space(onv_np, h1, h2, sorb, 2 * no, no, no, lut.bra_key.cpu().numpy(), lut.wf_value.cpu().numpy())
     np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"|E_loc|max = {float(np.abs(e_ref).max()):.6g} Ha")
     del comb, hm
     # ---- SIMPLE with the RBM on chip: alpha = 2 hidden units, the windowed kernel at these sizes ----------------------
     W, hb, vb = 0.01 * (g.random((H, sorb)) - 0.5), 0.01 * (g.random(H) - 0.5), 0.1 * (g.random(sorb) - 0.5)
     e_ref, p_ref = _rbm_eloc_logdomain(O, co[0], ho[0], sorb, W, hb, vb)
     e, p = cx.eloc_rbm(x[:1].contiguous(), h1e, h2e, cx.RBMTable(G(W), G(hb), G(vb)), sorb, 2 * no, no, no)
     np.testing.assert_allclose(p.cpu().numpy(), [p_ref], rtol=1e-10)
-    np.testing.assert_allclose(e.cpu().numpy(), [e_ref], rtol=0, atol=TOL * max(1.0, abs(e_ref)))
+    np.testing.assert_allclose(e.cpu().numpy(), [e_ref], rtol=0, atol=TOL, err_msg=f"|E_loc| = {abs(e_ref):.6g} Ha")

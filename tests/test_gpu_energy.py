@@ -376,7 +376,7 @@ def test_sample_space_kernel_filter_levels(sorb, no, nkeys, use_hash, key_major)
     e_ref, p_ref = O.eloc_sample_space(x.view(np.uint8).reshape(n, 8 * L), h1, h2, sorb, 2 * no, no, no, lut.bra_key.cpu().numpy(),
                                        lut.wf_value.cpu().numpy())
     np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"|E_loc|max = {float(np.abs(e_ref).max()):.6g} Ha")
 
 
 @pytest.mark.parametrize("L,n,distinct", [(1, 1, 1), (1, 1000, 7), (1, 700_000, 90_000), (2, 300_000, 300_000), (3, 250_000, 1000)])

@@ -61,8 +61,7 @@ def test_random_against_oracle(cx, sorb, noA, noB, H, n):
     tab = cx.RBMTable(_dev(W), _dev(hb), _dev(vb))
     e, p = cx.eloc_rbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
     np.testing.assert_allclose(p.cpu().numpy(), p_ref, rtol=1e-11)
-    scale = max(1.0, float(np.abs(e_ref).max()))
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"|E_loc|max = {float(np.abs(e_ref).max()):.6g} Ha")
 
 
 def test_no_visible_bias_and_large_theta(cx):
@@ -79,7 +78,7 @@ def test_no_visible_bias_and_large_theta(cx):
     tab = cx.RBMTable(_dev(W), _dev(hb), None)
     e, p = cx.eloc_rbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, 6, noA, noB)
     assert torch.isfinite(e).all() and torch.isfinite(p).all()
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"|E_loc|max = {float(np.abs(e_ref).max()):.6g} Ha")
 
 
 def test_empty_and_errors(cx, fe2s2):
@@ -125,11 +124,10 @@ def test_windowed_kernel_against_oracle(cx, sorb, noA, noB, H, n):
     if np.isfinite(p_ref).all():
         np.testing.assert_allclose(p.cpu().numpy(), p_ref, rtol=1e-10)
         e_orc, _ = oracle.eloc_simple_rbm(bra_cpu, h1, h2, sorb, noA + noB, noA, noB, W, hb, vb)
-        np.testing.assert_allclose(e_orc, e_ref, rtol=0, atol=TOL * max(1.0, float(np.abs(e_ref).max())))
+        np.testing.assert_allclose(e_orc, e_ref, rtol=0, atol=TOL, err_msg=f"|E_loc|max = {float(np.abs(e_ref).max()):.6g} Ha")
     else:
         assert torch.isinf(p).all()
-    scale = max(1.0, float(np.abs(e_ref).max()))
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"|E_loc|max = {float(np.abs(e_ref).max()):.6g} Ha")
 
 
 @pytest.mark.parametrize("kind", ["tanh", "pRBM"])
@@ -260,8 +258,7 @@ def test_complex_rbm_random_systems(cx, sorb, noA, noB, H, n):
     p_ref = np.exp(ax[:, 0]) * np.prod(2 * np.cosh(th[:, 0]), axis=-1)
     tab = cx.CRBMTable(_dev(W), _dev(hb), _dev(vb))
     e, p = cx.eloc_crbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
-    scale = max(1.0, float((np.abs(hm) * np.abs(ratio)).sum(1).max()))
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"sum |H| |ratio| max = {float((np.abs(hm) * np.abs(ratio)).sum(1).max()):.6g} Ha")
     np.testing.assert_allclose(p.cpu().numpy(), p_ref, rtol=1e-10)
 
 
@@ -291,8 +288,7 @@ def test_flavours_random_systems(cx, sorb, noA, noB, H, n, kind):
     e_ref = (hm * ratio).sum(1)
     tab = cx.RBMTable(_dev(W), _dev(hb), _dev(vb))
     e, p = cx.eloc_rbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB, rbm_type=kind)
-    scale = max(1.0, float(np.abs(hm).sum(1).max()))
-    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL * scale)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"sum |H| max = {float(np.abs(hm).sum(1).max()):.6g} Ha")
     if kind == "pRBM":
         np.testing.assert_allclose(p.cpu().numpy(), np.exp(1j * (ax + lncosh)[:, 0]), rtol=0, atol=1e-9)
 
