@@ -1041,6 +1041,13 @@ def main():
         if isinstance(wl, (VmcStep, ReduceVmcStep)):
             out["step_phases_gpu_ms"] = phases
             out["config"]["amplitude_module"] = "complex128 RBM, alpha = 1 (stand-in for the example's BDG-RNN), AD_MAX_DIM = %d as in example/Fe2S2 (one micro-batch for 8192 walkers)" % wl.micro_batch
+        if isinstance(wl, (VmcStep, ReduceVmcStep)):
+            # what the ranks agreed on in the last step: the all-reduced moments and the all-reduced gradient (for the N > 1 rehearsal test:
+            # N ranks x W walkers must give what one rank gives on the N W walkers)
+            mean = wl.stats[0]
+            flat = wl.graphed.flat if wl.graphed is not None else torch.cat([p.grad.reshape(-1) for p in wl.module.parameters()])
+            out["check"] = {"mean_eloc": [float(mean.real), float(mean.imag) if mean.is_complex() else 0.0], "var_eloc": float(wl.stats[1]),
+                            "grad_l2": float(flat.double().norm()), "grad_first": [float(v) for v in flat[:4].double().cpu()]}
         if isinstance(wl, ReduceVmcStep):
             out["config"].update({"method": "REDUCE (vmc/energy/eloc.py:205-324), the Fe2S2 example's setting", "eps": wl.eps, "eps_sample": wl.eps_sample})
         if world == 1 and not args.no_cpu_baseline:

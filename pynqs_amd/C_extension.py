@@ -136,15 +136,17 @@ def plan_for(h1e: Tensor, h2e: Tensor, sorb: int, device: "torch.device | None" 
     if sorb % 2 or sorb < 2:
         return None
     ver = (_ver(h1e), _ver(h2e), h1e.data_ptr(), h2e.data_ptr())
-    for i, (r1, r2, v, s, pl) in enumerate(_PLANS):
+    trackable = ver[0] >= 0 and ver[1] >= 0  # (inference-mode tensors have no version counter: in-place edits would go unnoticed)
+    for i, (r1, r2, v, s, pl) in enumerate(_PLANS if trackable else ()):
         if r1() is h1e and r2() is h2e and v == ver and s == sorb and (device is None or device.type != "cuda" or pl.device == device
                                                                        or h1e.device.type == "cuda"):
             if i:
                 _PLANS.insert(0, _PLANS.pop(i))
             return pl
     pl = IntegralPlan(h1e, h2e, sorb, device)
-    _PLANS.insert(0, (weakref.ref(h1e), weakref.ref(h2e), ver, sorb, pl))
-    del _PLANS[_MAX_PLANS:]
+    if trackable:
+        _PLANS.insert(0, (weakref.ref(h1e), weakref.ref(h2e), ver, sorb, pl))
+        del _PLANS[_MAX_PLANS:]
     key = (sorb, h2e.numel(), str(pl.device))
     _PLAN_BUILDS[key] = _PLAN_BUILDS.get(key, 0) + 1
     if _PLAN_BUILDS[key] == _PLAN_REBUILD_WARN:
@@ -168,14 +170,16 @@ def integrals_f64(h1e: Tensor, h2e: Tensor) -> Tuple[Tensor, Tensor]:
     if h1e.dtype == torch.float64:
         return h1e, h2e
     ver = (_ver(h1e), _ver(h2e), h1e.data_ptr(), h2e.data_ptr())
-    for i, (r1, r2, v, a, b) in enumerate(_F64_COPIES):
+    trackable = ver[0] >= 0 and ver[1] >= 0
+    for i, (r1, r2, v, a, b) in enumerate(_F64_COPIES if trackable else ()):
         if r1() is h1e and r2() is h2e and v == ver:
             if i:
                 _F64_COPIES.insert(0, _F64_COPIES.pop(i))
             return a, b
     a, b = h1e.double(), h2e.double()
-    _F64_COPIES.insert(0, (weakref.ref(h1e), weakref.ref(h2e), ver, a, b))
-    del _F64_COPIES[_MAX_PLANS:]
+    if trackable:
+        _F64_COPIES.insert(0, (weakref.ref(h1e), weakref.ref(h2e), ver, a, b))
+        del _F64_COPIES[_MAX_PLANS:]
     return a, b
 
 
@@ -229,6 +233,7 @@ def onv_to_tensor(bra: Tensor, sorb: int) -> Tensor:
 # fused plan kernel in its Hmat-only form -- bit-identical values at a fifth of the generic pair kernel's time.
 _last_comb = None  # (weakref(comb), comb ptr, comb version, weakref(bra), bra ptr, bra version, sorb, nele, noA, noB)
 REUSE_COMB = True
+CHECK_COMB_REUSE = __import__("os").environ.get("PYNQS_CHECK_COMB_REUSE", "0") == "1"
 
 
 def _remember_comb(comb: Tensor, bra: Tensor, sorb: int, nele: int, noA: int, noB: int) -> None:
@@ -327,6 +332,17 @@ def get_hij_torch(bra: Tensor, ket: Tensor, h1e: Tensor, h2e: Tensor, sorb: int,
             hmat = torch.empty((n, m), dtype=h1e.dtype, device=bra.device)
             N.check(N.lib().pynqs_comb_hij_fused_plan(bra.data_ptr(), n, sorb, nele, same[0], same[1], plan.data_ptr(), code, None,
                                                       hmat.data_ptr(), _stream(bra.device)), "get_hij_torch")
+            if CHECK_COMB_REUSE:
+                # the shortcut trusts identity + version counters: with PYNQS_CHECK_COMB_REUSE=1 a few columns are recomputed from the
+                # kets actually passed in (generic pair kernel) -- a caller that wrote into comb without bumping its version shows up here
+                cols = torch.randint(0, m, (min(m, 8),), device=ket.device)
+                sub = ket[:, cols].contiguous()
+                chk = torch.empty((n, cols.numel()), dtype=h1e.dtype, device=bra.device)
+                N.check(N.lib().pynqs_hij(bra.data_ptr(), n, sub.data_ptr(), cols.numel(), 1, h1e.data_ptr(), h2e.data_ptr(), code, sorb, nele,
+                                          chk.data_ptr(), _stream(bra.device)), "get_hij_torch (check)")
+                if not torch.equal(chk, hmat[:, cols]):
+                    raise RuntimeError("get_hij_torch: `ket` is not the S+D list get_comb_tensor returned for `bra` any more (modified in place "
+                                       "through a path that does not bump the version counter?)")
             return hmat
     dev, (x, k, a, b), cpu = _stage(bra, ket, h1e, h2e)
     hmat = torch.empty((n, m), dtype=h1e.dtype, device=dev)
@@ -339,10 +355,14 @@ def wavefunction_lut(bra_key: Tensor, onv: Tensor, sorb: int, little_endian: boo
     """bind.cpp:216-236 -> cpu_tensor.cpp:642-688: binary search of onv in the sorted bra_key.
     Returns (idx int64[n] with -1 for misses, mask bool[n]).  If either input is on the CPU the result
     is on the CPU, as in the reference."""
-    if not little_endian:
-        raise NotImplementedError("big-endian keys are not supported (the reference's branch is broken, cpu_tensor.cpp:613)")
     _check_onv(bra_key, "bra_key", sorb, (2,))
     _check_onv(onv, "onv", sorb, (2,))
+    if not little_endian:
+        # keys sorted as BIG-endian multi-word integers (most significant word first; the reference's own branch for this order
+        # decrements its loop index the wrong way, cpu_tensor.cpp:613, and is used nowhere): the same search on word-reversed copies
+        L = _bra_len(sorb)
+        rev = lambda t: t.view(-1, L, 8).flip(1).reshape(-1, 8 * L).contiguous()  # noqa: E731
+        return wavefunction_lut(rev(bra_key), rev(onv), sorb, True)
     n = onv.size(0)
     any_cpu = bra_key.device.type == "cpu" or onv.device.type == "cpu"
     if onv.numel() == 0:
@@ -626,26 +646,28 @@ def _pair_maps(sorb: int):
 
 def compress_h1e_h2e(h1e: np.ndarray, h2e: np.ndarray, sorb: int):
     """integral.cpp:6-60: h1e[s, s], antisymmetrised h2e[s, s, s, s] -> (h1e[s*s], h2e[pair(pair+1)/2]).
-    When several (i,j,k,l) share a packed slot the LAST one in lexicographic order wins, as in the
-    reference's loop (numpy fancy assignment keeps the last write)."""
+    When several (i,j,k,l) share a packed slot the LAST one in lexicographic order wins, as in the reference's loop: the blocks
+    h2e[i] are visited in order and numpy's fancy assignment keeps the last write inside a block.  Working memory is one [s, s, s]
+    block (the reference is an O(1)-memory loop; the input itself is s^4: 1.7 GB at sorb 120, 9.2 GB at sorb 184)."""
     h1e = np.asarray(h1e, dtype=np.float64)
     h2e = np.asarray(h2e, dtype=np.float64)
     if h1e.shape != (sorb, sorb) or h2e.shape != (sorb,) * 4:
         raise ValueError(f"expected h1e {(sorb, sorb)} and h2e {(sorb,) * 4}, got {h1e.shape} and {h2e.shape}")
     npair = sorb * (sorb - 1) // 2
     pair, sgn, off = _pair_maps(sorb)
-    ij = pair[:, :, None, None]; kl = pair[None, None, :, :]
-    valid = off[:, :, None, None] & off[None, None, :, :]
-    P = np.maximum(ij, kl); Q = np.minimum(ij, kl)
-    slot = (P * (P + 1) // 2 + Q)[valid]
-    vals = (sgn[:, :, None, None] * sgn[None, None, :, :] * h2e)[valid]
     out = np.zeros(npair * (npair + 1) // 2, dtype=np.float64)
-    out[slot] = vals  # C-order traversal == the reference's i,j,k,l loop order; last write wins
+    kl, skl, okl = pair[None, :, :], sgn[None, :, :], off[None, :, :]
+    for i in range(sorb):
+        ij = pair[i][:, None, None]
+        valid = off[i][:, None, None] & okl                 # [s, s, s] over (j, k, l)
+        P, Q = np.maximum(ij, kl), np.minimum(ij, kl)
+        out[(P * (P + 1) // 2 + Q)[valid]] = (sgn[i][:, None, None] * skl * h2e[i])[valid]
     return h1e.reshape(-1).copy(), out
 
 
 def decompress_h1e_h2e(h1e: np.ndarray, h2e: np.ndarray, sorb: int):
-    """integral.cpp:62-125; raises ValueError on a size mismatch (std::invalid_argument)."""
+    """integral.cpp:62-125; raises ValueError on a size mismatch (std::invalid_argument).  Elements with i == j or k == l are 0
+    (the reference leaves them unwritten).  Working memory beyond the s^4 result: one [s, s, s] block."""
     h1e = np.asarray(h1e, dtype=np.float64).reshape(-1)
     h2e = np.asarray(h2e, dtype=np.float64).reshape(-1)
     npair = sorb * (sorb - 1) // 2
@@ -654,9 +676,12 @@ def decompress_h1e_h2e(h1e: np.ndarray, h2e: np.ndarray, sorb: int):
     if h2e.size != npair * (npair + 1) // 2:
         raise ValueError(f"h2e array size is incorrect: expected {npair * (npair + 1) // 2}, got {h2e.size}")
     pair, sgn, off = _pair_maps(sorb)
-    ij = pair[:, :, None, None]; kl = pair[None, None, :, :]
-    valid = off[:, :, None, None] & off[None, None, :, :]
-    P = np.maximum(ij, kl); Q = np.minimum(ij, kl)
-    slot = np.where(valid, P * (P + 1) // 2 + Q, 0)
-    full = np.where(valid, h2e[slot] * sgn[:, :, None, None] * sgn[None, None, :, :], 0.0)
+    full = np.zeros((sorb,) * 4, dtype=np.float64)
+    kl, skl, okl = pair[None, :, :], sgn[None, :, :], off[None, :, :]
+    for i in range(sorb):
+        ij = pair[i][:, None, None]
+        valid = off[i][:, None, None] & okl
+        P, Q = np.maximum(ij, kl), np.minimum(ij, kl)
+        slot = np.where(valid, P * (P + 1) // 2 + Q, 0)
+        full[i] = np.where(valid, h2e[slot] * (sgn[i][:, None, None] * skl), 0.0)
     return h1e.reshape(sorb, sorb).copy(), full

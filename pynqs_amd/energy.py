@@ -199,7 +199,10 @@ SS_KEYS: Optional[bool] = None
 # winner (profiles/r02_*_sample_space_vs_table_size.txt: sorb 56, sparse table: key-major wins up to 30 x ncomb; Fe2S2's CAS table: up to
 # 1.7 x ncomb; sorb 120 / 184: at every size tried).
 SS_KEYS_ZONE = {1: (0.75, 64.0, 1.5), 2: (16.0, 256.0, 16.0), 3: (16.0, 256.0, 16.0)}
-SS_AUTOTUNE = True
+# Timing both kernels costs a host synchronisation inside a VMC step and makes the choice (key-major accumulates with float atomics) depend
+# on the machine's state: OFF by default -- the fixed ratios above decide, the same on every rank and in every run.  PYNQS_SS_AUTOTUNE=1
+# (or SS_AUTOTUNE = True) turns the probe on; with several ranks rank 0 probes and everybody takes its answer.
+SS_AUTOTUNE = __import__("os").environ.get("PYNQS_SS_AUTOTUNE", "0") == "1"
 _SS_CHOICE: dict = {}
 
 
@@ -221,7 +224,19 @@ def _key_major(nkeys: int, sorb: int, noa: int, nob: int, probe: Optional[Callab
         return nkeys <= ratio * ncomb  # (a probe synchronises: never inside a graph capture)
     key = (sorb, noa, nob, (4 * nkeys).bit_length(), tag)  # table sizes in steps of sqrt(2)... of 2 with two guard bits: [2^k/4 steps]
     if key not in _SS_CHOICE:
-        _SS_CHOICE[key] = bool(probe())
+        from .distributed import get_world_size
+
+        choice = bool(probe()) if get_rank() == 0 or get_world_size() == 1 else False
+        if get_world_size() > 1:  # one answer for all ranks (every rank reaches this point with the same key in the same call)
+            import torch.distributed as dist
+
+            t = torch.tensor([int(choice)], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t, 0)
+            choice = bool(t.item())
+        _SS_CHOICE[key] = choice
+        import logging
+
+        logging.getLogger("pynqs_amd").info("SAMPLE_SPACE kernel for sorb %d, %d keys: %s (timed)", sorb, nkeys, "key-major" if choice else "column-major")
     return _SS_CHOICE[key]
 
 
@@ -275,7 +290,10 @@ def choose_sample_space_kernel(x, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx) 
             t[mode] = a.elapsed_time(b)
         return t[True] <= t[False]
 
-    return _key_major(WF_LUT.bra_key.size(0), sorb, noa, nob, probe, (bool(cplx), x.size(0) >= 1024))
+    from .distributed import get_world_size
+
+    # (the cache key must be the same on every rank: shard sizes are not)
+    return _key_major(WF_LUT.bra_key.size(0), sorb, noa, nob, probe, (bool(cplx), x.size(0) >= 1024 if get_world_size() == 1 else None))
 
 
 def _sample_space_fused(x, h1e, h2e, sorb, nele, noa, nob, WF_LUT, wf: Optional[Tensor] = None, flip: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
@@ -478,8 +496,21 @@ def local_energy(
         # ---- fast path: SAMPLE_SPACE in one kernel ----------------------------------------------------
         if use_sample_space and _fast_sample_space_ok(x, h1e, h2e, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa, nob):
             f_keys = None
-            if use_multi_psi:  # f on the sample-space keys, once (the reference stores f in the table's dtype, flip.py:392)
-                f_keys = Func(partial(ansatz_batch, func=ansatz.module.extra), WF_LUT.bra_key, None, True).to(WF_LUT.dtype)
+            if use_multi_psi:
+                # f on the sample-space keys (the reference stores f in the table's dtype, flip.py:392): once per parameter state, not once
+                # per chunk of walkers -- total_energy calls this function for every chunk, and the table has up to 1e5-1e6 keys
+                extra = ansatz.module.extra
+                stamp = (id(extra), WF_LUT.bra_key.data_ptr(), WF_LUT.bra_key.size(0), str(WF_LUT.dtype),
+                         tuple((id(q), q._version) for q in extra.parameters()) if hasattr(extra, "parameters") else None)
+                cached = getattr(WF_LUT, "_pynqs_f_keys", None)
+                if cached is not None and cached[0] == stamp and stamp[4] is not None:
+                    f_keys = cached[1]
+                else:
+                    f_keys = Func(partial(ansatz_batch, func=extra), WF_LUT.bra_key, None, True).to(WF_LUT.dtype)
+                    try:
+                        WF_LUT._pynqs_f_keys = (stamp, f_keys)
+                    except AttributeError:  # (a table object that takes no attributes)
+                        pass
 
             def in_sample_space(h1, h2):
                 """sum over the sample space with the integrals (h1, h2): the energy, and with the S-S+ integrals <S-S+> (eloc.py:377-400)"""

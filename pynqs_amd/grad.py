@@ -18,8 +18,10 @@ from .public_function import split_batch_idx
 
 
 def grad(nqs: nn.Module, states: Tensor, state_prob: Tensor, eloc: Tensor, e_total: Union[complex, float, Tensor],
-         extra_psi_pow: Union[Tensor, float] = 1.0, dtype=torch.double, AD_MAX_DIM: int = -1) -> Tensor:
-    """Accumulates d<E>/dtheta into the parameters' .grad; returns the all-reduced loss (logging value)."""
+         extra_psi_pow: Union[Tensor, float] = 1.0, dtype=torch.double, AD_MAX_DIM: int = -1, empty_shard_state: "Tensor | None" = None) -> Tensor:
+    """Accumulates d<E>/dtheta into the parameters' .grad; returns the all-reduced loss (logging value).
+    empty_shard_state: one VALID configuration ([1, sorb], e.g. the first state of the unsharded batch) for the dummy forward a rank
+    with an empty shard needs to join DDP's reduction; without it an all-zero row is used, which is not a configuration."""
     device = states.device
     dim = states.size(0)
     loss_sum = torch.zeros(1, device=device, dtype=torch.double)
@@ -53,8 +55,12 @@ def grad(nqs: nn.Module, states: Tensor, state_prob: Tensor, eloc: Tensor, e_tot
         # an empty shard (fewer unique samples than ranks): the other ranks' last backward waits in DDP's bucketed
         # all-reduce, so this rank must take part with a zero gradient (the reference indexes idx_lst[-1] of an empty list
         # and dies, leaving the others hanging).  A forward through the DDP wrapper arms its reducer.
-        zero = states.new_zeros((1,) + tuple(states.shape[1:]))
-        (nqs(zero).to(dtype).sum().real * 0.0).backward()
+        dummy = empty_shard_state if empty_shard_state is not None else states.new_zeros((1,) + tuple(states.shape[1:]))
+        out = nqs(dummy.reshape((1,) + tuple(states.shape[1:])).to(states.dtype)).to(dtype).sum()
+        if not bool(torch.isfinite(torch.view_as_real(out) if out.is_complex() else out).all()):
+            # 0 * inf = nan would reach every rank's gradient through the all-reduce
+            raise ValueError("empty shard: the ansatz is not finite on the dummy configuration; pass empty_shard_state=<a valid state>")
+        (out.real * 0.0).backward()
     return all_reduce_packed([loss_sum], get_world_size())[0]
 
 
@@ -67,11 +73,16 @@ class GraphedGrad:
     flat gradient buffer after the replay (RCCL over xGMI; mean over the ranks, DDP's convention).  Parameters keep their
     identity: after the call every p.grad is a view into that buffer, so any torch optimizer works unchanged.
     Restrictions (otherwise use grad()): fixed number of walkers per call, float +-1 states, parameters not re-allocated.
+    With a REAL dtype the logarithm of a negative amplitude is nan (grad() raises "negative numbers in the log-psi" there): the replay's
+    loss is checked after every call (one scalar read-back; check_nan=False leaves it to the caller) and the gradients are not
+    installed when it is nan.  Complex dtypes need no check (ln of a non-zero complex number is finite).
     """
 
-    def __init__(self, nqs: nn.Module, n: int, sorb: int, dtype=torch.double, device=None, use_pow: bool = False, warmup: int = 3) -> None:
+    def __init__(self, nqs: nn.Module, n: int, sorb: int, dtype=torch.double, device=None, use_pow: bool = False, warmup: int = 3,
+                 check_nan: "bool | None" = None) -> None:
         m = getattr(nqs, "module", nqs)
         self.module, self.dtype = m, dtype
+        self.check_nan = (not dtype.is_complex) if check_nan is None else check_nan
         self.params = [p for p in m.parameters() if p.requires_grad]
         dev = device if device is not None else self.params[0].device
         rdt = dtype.to_real() if dtype.is_complex else dtype
@@ -117,6 +128,10 @@ class GraphedGrad:
         if self.pow is not None:
             self.pow.copy_(extra_psi_pow)
         self.graph.replay()
+        if self.check_nan and bool(torch.isnan(self.loss).any()):
+            for p in self.params:
+                p.grad = None
+            raise ValueError("There are negative numbers in the log-psi, please use complex128")  # (grad()'s message, energy_grad.py:150-151)
         ws = get_world_size()
         ev = None
         if self.events is not None:  # caller wants the GPU-timeline split replay | all-reduce

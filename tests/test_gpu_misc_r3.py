@@ -1,0 +1,74 @@
+"""Round-3 robustness items: big-endian keys in wavefunction_lut (bind.cpp:216-236, cpu_tensor.cpp:589-641), the NaN guard of
+GraphedGrad (vmc/grad/energy_grad.py:150-151), the cross-check of get_hij_torch's "the list I just returned" shortcut, and the
+compress / decompress of the integrals at a BASELINE size (cpp_src/tensor/integral.cpp:6-125)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rand_occ, synth_integrals
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("sorb", [40, 130])
+def test_wavefunction_lut_big_endian(sorb):
+    from pynqs_amd import C_extension as cx
+
+    L = (sorb - 1) // 64 + 1
+    g = np.random.default_rng(3)
+    keys = np.unique(g.integers(0, 2**63, size=(500, L), dtype=np.uint64), axis=0)
+    # sort as big-endian multi-word integers: word 0 most significant
+    order = np.lexsort([keys[:, w] for w in range(L - 1, -1, -1)])
+    keys = keys[order]
+    q = np.concatenate([keys[::7], g.integers(0, 2**63, size=(40, L), dtype=np.uint64)])
+    idx, mask = cx.wavefunction_lut(_dev(keys.view(np.uint8).reshape(-1, 8 * L)), _dev(q.view(np.uint8).reshape(-1, 8 * L)), sorb, little_endian=False)
+    want = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    exp = np.array([want.get(tuple(r), -1) for r in q.tolist()])
+    assert np.array_equal(idx.cpu().numpy(), exp) and np.array_equal(mask.cpu().numpy(), exp >= 0)
+
+
+def test_graphed_grad_refuses_negative_real_amplitudes():
+    from pynqs_amd.grad import GraphedGrad
+    from pynqs_amd.rbm import RealRBM
+
+    torch.manual_seed(0)
+    sorb, n = 12, 64
+    m = RealRBM(0.3 * torch.randn(6, sorb, dtype=torch.float64), torch.zeros(6, dtype=torch.float64), torch.zeros(sorb, dtype=torch.float64), rbm_type="tanh").cuda()
+    gg = GraphedGrad(m, n, sorb, torch.double, torch.device("cuda"))
+    states = (torch.randint(0, 2, (n, sorb), device="cuda").double() * 2 - 1)
+    prob = torch.full((n,), 1.0 / n, dtype=torch.float64, device="cuda")
+    eloc = torch.randn(n, dtype=torch.float64, device="cuda")
+    assert bool((m(states) < 0).any())  # tanh(a.x) takes both signs
+    for p in m.parameters():
+        p.grad = None
+    with pytest.raises(ValueError, match="negative numbers in the log-psi"):
+        gg(states, prob, eloc, 0.1)
+    assert all(p.grad is None for p in m.parameters())  # nothing nan was installed
+
+
+def test_comb_reuse_shortcut_can_be_cross_checked(fe2s2, monkeypatch):
+    from pynqs_amd import C_extension as cx
+
+    x = _dev(fe2s2["ci_space"][:16])
+    h1e, h2e = _dev(fe2s2["h1e"]), _dev(fe2s2["h2e"])
+    monkeypatch.setattr(cx, "CHECK_COMB_REUSE", True)
+    comb, _ = cx.get_comb_tensor(x, 40, 30, 15, 15)
+    hm = cx.get_hij_torch(x, comb, h1e, h2e, 40, 30)      # served by the plan kernel, checked on a few columns
+    _, want = cx.get_comb_hij_fused(x, h1e, h2e, 40, 30, 15, 15)
+    assert torch.equal(hm, want)
+    comb2, _ = cx.get_comb_tensor(x, 40, 30, 15, 15)
+    comb2.data[:, 1:, 0] ^= 3                              # written behind the version counter's back
+    with pytest.raises(RuntimeError, match="not the S\\+D list"):
+        cx.get_hij_torch(x, comb2, h1e, h2e, 40, 30)
+
+
+def test_integral_layout_at_sorb_120():
+    """cpp_src/tensor/integral.cpp:6-125 at a BASELINE size: 25.5 M packed elements <-> the 207 M-element (1.7 GB) full tensor, against the
+    oracle, with bounded working memory.  Host-only arithmetic; it lives in the GPU tier because of its size (see test_host_logic.py)."""
+    from test_host_logic import check_integral_layout
+
+    check_integral_layout(120)

@@ -244,3 +244,35 @@ def test_spin_projection_follows_the_host_programs_instance():
         assert mine.eta == -1  # its own initialisation wins
     finally:
         del sys.modules["utils.public_function"]
+
+
+def check_integral_layout(sorb: int) -> None:
+    """compress / decompress of the integrals (cpp_src/tensor/integral.cpp:6-125) against the oracle, with the working memory beyond
+    input and output bounded by one [s, s, s] block (the first version built several s^4 temporaries: 13 GB at sorb 120)."""
+    import tracemalloc
+
+    from pynqs_amd import C_extension as cx
+
+    h1, h2 = synth_integrals(sorb)
+    tracemalloc.start()
+    a, b = cx.decompress_h1e_h2e(h1, h2, sorb)
+    _, peak = tracemalloc.get_traced_memory()
+    tracemalloc.stop()
+    assert peak < b.nbytes + 40 * sorb**3 + 2**26, f"decompress peaked at {peak / 2**30:.2f} GiB for a {b.nbytes / 2**30:.2f} GiB result"
+    ao, bo = O.decompress_h1e_h2e(h1, h2, sorb)
+    assert np.array_equal(a, ao) and np.array_equal(b, bo)
+    del ao, bo
+    tracemalloc.start()
+    c, e = cx.compress_h1e_h2e(a, b, sorb)
+    _, peak = tracemalloc.get_traced_memory()
+    tracemalloc.stop()
+    assert peak < e.nbytes + 40 * sorb**3 + 2**26, f"compress peaked at {peak / 2**30:.2f} GiB"
+    assert np.array_equal(c, h1) and np.array_equal(e, h2)  # round trip: every packed element comes back
+    co, eo = O.compress_h1e_h2e(a, b, sorb)
+    assert np.array_equal(c, co) and np.array_equal(e, eo)
+
+
+def test_integral_layout_in_blocks():
+    """sorb 64 here (134 MB full tensor); sorb 120 (1.7 GB) runs in the GPU tier, tests/test_gpu_misc_r3.py: first-touch of gigabyte
+    arrays takes minutes in the development container (the oracle's C loop just the same), seconds on an ordinary host."""
+    check_integral_layout(64)
