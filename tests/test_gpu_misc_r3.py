@@ -37,7 +37,7 @@ def test_graphed_grad_refuses_negative_real_amplitudes():
 
     torch.manual_seed(0)
     sorb, n = 12, 64
-    m = RealRBM(0.3 * torch.randn(6, sorb, dtype=torch.float64), torch.zeros(6, dtype=torch.float64), torch.zeros(sorb, dtype=torch.float64), rbm_type="tanh").cuda()
+    m = RealRBM(0.3 * torch.randn(6, sorb, dtype=torch.float64), torch.zeros(6, dtype=torch.float64), 0.5 * torch.randn(sorb, dtype=torch.float64), rbm_type="tanh").cuda()
     gg = GraphedGrad(m, n, sorb, torch.double, torch.device("cuda"))
     states = (torch.randint(0, 2, (n, sorb), device="cuda").double() * 2 - 1)
     prob = torch.full((n,), 1.0 / n, dtype=torch.float64, device="cuda")
