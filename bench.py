@@ -1104,6 +1104,35 @@ def main():
                 torch.cuda.empty_cache()
         except Exception as e:  # pragma: no cover
             extra["reduce_compact"] = {"error": repr(e)}
+        # fused-aware chunking (public_function.get_nbatch(fused=...), total_energy(nbatch=0)): the example's batch of 2048 walkers per
+        # local_energy call against chunks sized for what the fused path allocates, on 65 536 walkers (C4's global batch)
+        try:
+            from pynqs_amd import energy as E3, public_function as pf3
+
+            d3 = load_fe2s2()
+            sorb3, nele3, noA3, noB3 = int(d3["sorb"]), int(d3["nele"]), int(d3["noA"]), int(d3["noB"])
+            ci3 = d3["ci_space"]
+            h1c, h2c = torch.from_numpy(d3["h1e"]).to(dev), torch.from_numpy(d3["h2e"]).to(dev)
+            x65 = torch.from_numpy(np.ascontiguousarray(ci3[np.arange(65536) % ci3.shape[0]])).to(dev)
+            g3 = torch.Generator().manual_seed(7)
+            wf3 = torch.polar(torch.exp(-3.0 * torch.rand(ci3.shape[0], generator=g3, dtype=torch.float64)), 2 * np.pi * torch.rand(ci3.shape[0], generator=g3, dtype=torch.float64))
+            lut3 = pf3.WavefunctionLUT(torch.from_numpy(ci3.copy()).to(dev), wf3.to(dev), sorb3, device=dev)
+            res = {}
+            for tag, nb in (("nbatch_2048_as_in_the_example", 2048), ("nbatch_auto_fused_aware", 0)):
+                fn = lambda: E3.total_energy(x65, nb, -1, h1c, h2c, None, sorb3, nele3, noA3, noB3, WF_LUT=lut3, use_sample_space=True, dtype=torch.complex128)
+                fn(); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    e3, _, _ = fn()
+                torch.cuda.synchronize(dev)
+                el5 = (time.perf_counter() - t0) / 5
+                res[tag] = {"value": 65536 / el5, "unit": "local energies/s", "ms_per_call": el5 * 1e3, "mean_eloc_re": float(e3.mean().real)}
+            res["walkers_per_call_auto"] = E3.auto_nbatch(x65, h1c, sorb3, nele3, noA3, noB3, None, lut3, torch.complex128, False, 0, True, False, False, False)
+            extra["fe2s2_total_energy_sample_space_65536_walkers_chunking"] = res
+            del x65, lut3, h1c, h2c
+            torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            extra["chunking"] = {"error": repr(e)}
         # the generic amplitude path: psi(x') by a PyTorch-ROCm module (real RBM, alpha = 2) through
         # pynqs_amd.energy.local_energy -- SIMPLE (every column) and REDUCE (eps = 1e-2, the Fe2S2 example's setting)
         try:

@@ -36,7 +36,7 @@ from . import _native as N
 from . import reduce_front as RF
 from .C_extension import get_comb_hij_fused, get_hij_torch
 from .distributed import get_rank
-from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, check_para, get_Num_SinglesDoubles,
+from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, check_para, get_nbatch, get_Num_SinglesDoubles,
                               spin_flip_onv, spin_flip_sign, split_batch_idx, unique_onv)
 
 FUSED = True  # use the fused sample-space / reduce kernels when the configuration allows it
@@ -756,6 +756,24 @@ def local_energy(
         return eloc.to(dtype), sloc.to(dtype), psi_x1[..., 0].to(dtype), ((t1 - t0) / 1e6, (t2 - t1) / 1e6, (t3 - t2) / 1e6)
 
 
+def auto_nbatch(x, h1e, sorb, nele, noa, nob, ansatz, WF_LUT, dtype, reduce_psi, eps_sample, use_sample_space, use_multi_psi, use_spin_flip,
+                use_spin_raising, max_memory: float = 64.0, alpha: float = 0.25) -> int:
+    """Walkers per local_energy call for the path local_energy will take on these arguments (same conditions as there)."""
+    n = x.size(0)
+    n_sd = get_Num_SinglesDoubles(sorb, noa, nob)
+    fused = None
+    if n and x.is_cuda and FUSED and sorb % 2 == 0:
+        if use_sample_space and _fast_sample_space_ok(x, h1e, None, sorb, WF_LUT, use_spin_raising, use_multi_psi, use_spin_flip, noa, nob):
+            fused = "sample_space"
+        elif reduce_psi and not use_sample_space and _front_ok(x[: min(n, 4096)], h1e, sorb, nele, noa, nob, eps_sample):
+            fused = "reduce"
+        elif (not reduce_psi and not use_sample_space and FUSED_RBM and WF_LUT is None and not (use_multi_psi or use_spin_flip)
+              and (_real_rbm_params(ansatz) is not None or _complex_rbm_params(ansatz) is not None)):
+            fused = "simple_rbm"
+    return max(1, get_nbatch(sorb, max(n, 1), n_sd, max_memory, alpha, x.device, use_sample_space, dtype if dtype in (torch.double, torch.complex128) else torch.double,
+                             fused=fused, eps_sample=int(eps_sample)))
+
+
 def total_energy(
     x: Tensor, nbatch: int, fp_batch: int, h1e: Tensor, h2e: Tensor, ansatz: Callable[..., Tensor], sorb: int, nele: int, noa: int,
     nob: int, WF_LUT: Optional[WavefunctionLUT] = None, use_unique: bool = True, dtype=torch.double, use_spin_raising: bool = False,
@@ -764,13 +782,18 @@ def total_energy(
     use_spin_flip: bool = False, extra_norm: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Tensor]:
     """vmc/energy/etot.py:24-169: local energies of this rank's walkers in chunks of `nbatch` walkers, ansatz
-    forwards in chunks of `fp_batch` rows; NaN guard; returns (eloc, sloc, placeholder)."""
+    forwards in chunks of `fp_batch` rows; NaN guard; returns (eloc, sloc, placeholder).
+    nbatch = 0 (not in the reference): sized for the path that will actually run (public_function.get_nbatch(fused=...)): the fused
+    kernels need none of the memory the reference's formula budgets for, and few large launches run faster than many small ones."""
     dim = x.shape[0]
     device = x.device
     eloc = torch.zeros(dim, device=device).to(dtype)
     sloc = torch.zeros_like(eloc)
     assert fp_batch > 0 or fp_batch == -1
-    assert nbatch > 0 or nbatch == -1
+    assert nbatch > 0 or nbatch in (-1, 0)
+    if nbatch == 0:
+        nbatch = auto_nbatch(x, h1e, sorb, nele, noa, nob, ansatz, WF_LUT, dtype, reduce_psi, eps_sample, use_sample_space, use_multi_psi,
+                             use_spin_flip, use_spin_raising)
     if nbatch == -1:
         nbatch = dim
     ends = split_batch_idx(dim, min_batch=nbatch) if dim else []

@@ -193,6 +193,93 @@ def ansatz_batch(func: Callable[[Tensor], Tensor], x: Tensor, batch: int, sorb: 
 _DOUBLY = None  # [256] number of doubly occupied spatial orbitals among the four a byte of a packed determinant holds
 
 
+# ---- walker-chunk sizing ------------------------------------------------------------------------------------------------------
+def get_nbatch(sorb: int, n_sample: int, n_sd: int, Max_memory: float = 32, alpha: float = 0.25, device: Optional[torch.device] = None,
+               use_sample: bool = False, dtype=torch.double, fused: Optional[str] = None, eps_sample: int = 0, kept_estimate: Optional[int] = None) -> int:
+    """utils/public_function.py:162-261: how many walkers total_energy hands to one local_energy call.
+
+    `fused=None` is the reference's arithmetic -- memory of the MATERIALISED path: the +-1 expansion of all nbatch x n_sd kets
+    (_get_nbatch_simple, :183-206) or the Hij / psi(x') / comb_x / search arrays of the sample-space method
+    (_get_nbatch_sample_space, :209-261), against min(Max_memory GiB, free device memory).
+
+    The fused paths of pynqs_amd.energy allocate none of that, so sizing them with the reference's formula only multiplies launches
+    (Fe2S2, SAMPLE_SPACE: the example's batch of 2048 walkers per call runs at a fraction of the rate of one 65 536-walker launch,
+    bench.py extra "chunking").  `fused` names what will run and the estimate is of what THAT allocates per walker:
+      "sample_space", "simple_rbm"  outputs only (E_loc, psi(x), partner sum): everything in one call, up to a 2^22-walker cap;
+      "reduce"                      records (fixed + kept + eps_sample slots of 20 + 8 len bytes) plus, per distinct x', the +-1 row,
+                                    the determinant and two de-duplication slots (every record counted as distinct: an upper bound);
+                                    kept_estimate defaults to n_sd / 64.
+    The ansatz' own activation memory is bounded separately by fp_batch, as in the reference."""
+    if device is None:
+        device = torch.device("cpu")
+    budget = float(Max_memory)
+    if device.type != "cpu":
+        torch.cuda.empty_cache()
+        budget = min(torch.cuda.mem_get_info(device)[0] / (1 << 30), budget)
+    if fused is None:
+        if not use_sample:
+            per = n_sd * sorb * 8 / (1 << 30) * 2
+            return int(budget / per * alpha) if per * n_sample / budget >= alpha else n_sample
+        bra_len = (sorb - 1) // 64 + 1
+        if dtype not in (torch.double, torch.complex128):
+            raise NotImplementedError
+        cplx = dtype == torch.complex128
+        a = max(alpha, 1)
+        if n_sd * (2 + cplx + bra_len) * a <= n_sample:
+            per = (((3 if cplx else 2) + bra_len) * n_sd + (12 if cplx else 8)) * 8 / (1 << 30)
+        else:
+            per = (n_sample * (2 if cplx else 1) + (10 if cplx else 6)) * 8 / (1 << 30)
+        return min(n_sample, int(budget / per))
+    if fused in ("sample_space", "simple_rbm"):
+        return max(1, min(n_sample, 1 << 22, int(budget * alpha * (1 << 30) / 64)))
+    if fused == "reduce":
+        bra_len = (sorb - 1) // 64 + 1
+        kept = int(kept_estimate) if kept_estimate is not None else max(64, n_sd // 64)
+        nrec = kept + int(eps_sample) + 64
+        per = nrec * (20 + 8 * bra_len) + nrec * (8 * sorb + 8 * bra_len + 2 * 8 * (2 if bra_len == 1 else 4))
+        return max(1, min(n_sample, int(budget * alpha * (1 << 30) / per)))
+    raise ValueError(f"fused = {fused!r}")
+
+
+class MemoryTrack:
+    """utils/public_function.py:873-925: device memory before / after a block (allocated, peak), for sizing by observation."""
+
+    def __init__(self, device) -> None:
+        self.device = torch.device(device)
+        self.before_memory = self.after_memory = self.before_max_memory = self.after_max_memory = 0.0
+
+    def __enter__(self) -> "MemoryTrack":
+        self.clean_memory_cache(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.reset_peak_memory_stats(self.device)
+        self.before_max_memory = self.get_max_memory(self.device)
+        self.before_memory = self.get_current_memory(self.device)
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb) -> None:
+        self.after_max_memory = self.get_max_memory(self.device)
+        self.clean_memory_cache(self.device)
+        self.after_memory = self.get_current_memory(self.device)
+
+    @property
+    def used(self) -> float:
+        """peak GiB allocated inside the block above what was allocated before it"""
+        return self.after_max_memory - self.before_memory
+
+    @staticmethod
+    def get_max_memory(device) -> float:
+        return torch.cuda.max_memory_allocated(device) / 2**30 if torch.device(device).type == "cuda" else 0.0
+
+    @staticmethod
+    def get_current_memory(device) -> float:
+        return torch.cuda.memory_allocated(device) / 2**30 if torch.device(device).type == "cuda" else 0.0
+
+    @staticmethod
+    def clean_memory_cache(device) -> None:
+        if torch.device(device).type == "cuda":
+            torch.cuda.empty_cache()
+
+
 def _doubly_table(device) -> Tensor:
     global _DOUBLY
     if _DOUBLY is None:

@@ -156,6 +156,19 @@ def test_total_energy_chunks_and_statistics(env):
             assert torch.equal(u, u2)
 
 
+def test_total_energy_sizes_its_own_chunks(env):
+    """nbatch = 0: chunks sized for the fused path that runs (public_function.get_nbatch(fused=...)); same numbers as one call."""
+    energy, pf, d = env["energy"], env["pf"], env["d"]
+    keys = torch.from_numpy(d["psi_lut_keys"]).to(env["dev"])
+    lut = pf.WavefunctionLUT(keys, torch.from_numpy(d["psi_lut"]).to(env["dev"]), 40, device=env["dev"])
+    args = (env["h1e"], env["h2e"], env["rbm"], 40, 30, 15, 15)
+    for kw in (dict(WF_LUT=lut, use_sample_space=True), dict(reduce_psi=True, eps=1e-2), dict()):
+        a, _, _ = energy.total_energy(env["x"], 0, 100000, *args, **kw)
+        b, _, _ = energy.total_energy(env["x"], -1, 100000, *args, **kw)
+        assert torch.equal(a, b)
+    assert energy.auto_nbatch(env["x"], env["h1e"], 40, 30, 15, 15, env["rbm"], lut, torch.double, False, 0, True, False, False, False) == env["x"].size(0)
+
+
 def test_spin_flip_helpers_and_eps0_consistency(env):
     """Helper forms (packed / occupation rows) agree, and REDUCE with eps = 0 equals SIMPLE for the projected form.  (Parity of the
     projected and multi-psi local energies themselves against the reference's Python: test_gpu_energy_flip.py.)"""

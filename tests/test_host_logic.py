@@ -276,3 +276,26 @@ def test_integral_layout_in_blocks():
     """sorb 64 here (134 MB full tensor); sorb 120 (1.7 GB) runs in the GPU tier, tests/test_gpu_misc_r3.py: first-touch of gigabyte
     arrays takes minutes in the development container (the oracle's C loop just the same), seconds on an ordinary host."""
     check_integral_layout(64)
+
+
+def test_get_nbatch_matches_the_reference_and_knows_the_fused_paths():
+    """utils/public_function.py:162-261.  Expected values: the reference's own get_nbatch on the CPU device for these arguments
+    (captured in the development container; inputs and outputs only)."""
+    from pynqs_amd import public_function as pf
+
+    cpu = torch.device("cpu")
+    cases = [(40, 100000, 7875, 32, 0.25, False, torch.double), (40, 1000, 7875, 32, 0.25, False, torch.double),
+             (120, 50000, 1190250, 64, 0.5, False, torch.double), (40, 100000, 7875, 32, 0.25, True, torch.double),
+             (40, 18496, 7875, 32, 0.25, True, torch.complex128), (120, 1000000, 1190250, 48, 2.0, True, torch.complex128),
+             (184, 32768, 6624138, 200, 0.25, True, torch.double)]
+    want = [1704, 1000, 15, 100000, 18496, 3221, 32768]
+    got = [pf.get_nbatch(s, n, nsd, mm, a, device=cpu, use_sample=us, dtype=dt) for (s, n, nsd, mm, a, us, dt) in cases]
+    assert got == want
+    # fused paths: nothing of size walkers x n_sd is allocated
+    assert pf.get_nbatch(40, 65536, 7875, 32, 0.25, cpu, True, torch.complex128, fused="sample_space") == 65536
+    assert pf.get_nbatch(120, 10**7, 1190250, 32, 0.25, cpu, False, fused="simple_rbm") == 1 << 22
+    r = pf.get_nbatch(40, 10**6, 7875, 32, 0.25, cpu, False, fused="reduce", eps_sample=1000)
+    assert 8192 <= r <= 65536  # ~0.45 MB per walker (every record counted as a distinct x') against a quarter of 32 GiB
+    assert pf.get_nbatch(120, 10**6, 1190250, 32, 0.25, cpu, False, fused="reduce") < r
+    with pytest.raises(ValueError):
+        pf.get_nbatch(40, 10, 7875, fused="nope")
