@@ -165,7 +165,7 @@ def test_total_energy_sizes_its_own_chunks(env):
     for kw in (dict(WF_LUT=lut, use_sample_space=True), dict(reduce_psi=True, eps=1e-2), dict()):
         a, _, _ = energy.total_energy(env["x"], 0, 100000, *args, **kw)
         b, _, _ = energy.total_energy(env["x"], -1, 100000, *args, **kw)
-        assert torch.equal(a, b)
+        torch.testing.assert_close(a, b, rtol=0, atol=1e-10)  # (the key-major sample-space kernel adds with atomics: last-bit differences)
     assert energy.auto_nbatch(env["x"], env["h1e"], 40, 30, 15, 15, env["rbm"], lut, torch.double, False, 0, True, False, False, False) == env["x"].size(0)
 
 
