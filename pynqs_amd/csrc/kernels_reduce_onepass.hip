@@ -753,6 +753,10 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
 // the de-duplication table for each of them: one round of probe latency per 256 records instead of one per tile.  New determinants
 // of a batch take their rows with one global atomic.  The drawn records of phase C are resolved the same way after the draws.
 // The look-back form above remains for segments whose kept columns do not fit the LDS list.
+// (Tried and dropped, round 3: a ROW form for rows that fit the LDS -- one 1024-thread workgroup per walker keeps the row's sub-eps
+// elements in LDS (64 KiB for Fe2S2) and draws from a block-wide prefix sum instead of re-enumerating the drawn tiles.  Correct, but
+// 1330 us against 1056 us per 8192 Fe2S2 walkers: with one workgroup per CU nothing overlaps the serial tails (sort, scan, draws,
+// resolution), which four 256-thread workgroups per CU hide behind each other's enumeration.)
 
 template <int LEN, typename T>
 __device__ __forceinline__ int32_t probe_amplitude(const OnepassOut<T> &o, const uint64_t (&ket)[LEN], bool &won) {
@@ -1010,6 +1014,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     sink.flush();
   }
   __syncthreads();
+  if (o.debug & 32u) return;  // (timing ablation: the enumeration alone)
   // ---- the kept columns: sort by column, write, resolve ----
   const uint32_t ntot = list_n;
   const uint32_t n = min(ntot, cap);
