@@ -570,14 +570,18 @@ class ReduceVmcStep(Workload):
     Nothing of size walkers x ncomb exists at any point, and nothing is read back between 1 and 5: buffers have fixed capacities
     (sized by one calibration call outside the timed region) and the overflow word is checked after the timed region.
     The amplitude module is a complex128 RBM (alpha = 1, seeded; ansatz families are outside this package) standing in for the
-    example's BDG-RNN."""
+    example's BDG-RNN.  For an RBM ansatz pynqs_amd.energy evaluates psi on the distinct x' with one kernel from the packed bits
+    (pynqs_rbm_forward) -- the default here; --torch-amplitudes runs the PyTorch module on the +-1 rows instead (what any other ansatz gets)."""
 
     bound = "valu"
 
-    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev, eps=1e-2, eps_sample=1000, micro_batch=50000, graphed=True):
+    def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev, eps=1e-2, eps_sample=1000, micro_batch=50000, graphed=True,
+                 fused_amplitudes=True):
         import torch.distributed as dist
 
         from pynqs_amd import _native as N, C_extension as cx, energy as E, grad as G, reduce_front as RF
+
+        self.fused_amplitudes = fused_amplitudes
         from pynqs_amd.rbm import ComplexRBM
 
         self.N, self.cx, self.G, self.RF = N, cx, G, RF
@@ -629,8 +633,14 @@ class ReduceVmcStep(Workload):
         self.seed += 1
         fe.run(self.x, self.plan.buf, self.eps, self.seed, None)
         ev[1].record(st)
-        with torch.no_grad():
-            psi_u = self.module(fe.uniq_pm1)  # all rows: static shape, nothing read back (rows beyond the distinct count are valid and unused)
+        if self.fused_amplitudes:
+            # the RBM amplitudes of the distinct x' by one kernel from the packed bits (pynqs_rbm_forward: what energy.local_energy does for an
+            # RBM ansatz); all rows: static shape, nothing read back (rows beyond the distinct count are valid and unused)
+            m_ = self.module
+            psi_u = self.cx.rbm_forward(fe.uniq_onv, m_.params_weights, m_.params_hidden_bias, m_.params_visible_bias, self.sorb, "complex")
+        else:
+            with torch.no_grad():
+                psi_u = self.module(fe.uniq_pm1)
         ev[2].record(st)
         self.eloc, self.psi_x = fe.contract(psi_u)
         ev[3].record(st)
@@ -803,7 +813,8 @@ def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", k
         ci = d["ci_space"]
         idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
         return ReduceVmcStep("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
-                             torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev, graphed=graphed)
+                             torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev, graphed=graphed,
+                             fused_amplitudes=os.environ.get("PYNQS_BENCH_TORCH_AMPLITUDES") != "1")
     if name == "fe2s2_vmc_step":
         d = load_fe2s2()
         ci = d["ci_space"]
@@ -865,6 +876,7 @@ def main():
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
     ap.add_argument("--no-comb", action="store_true", help="diagnostic: skip the comb output (Hmat only)")
     ap.add_argument("--eager-grad", action="store_true", help="fe2s2_vmc_step: gradient estimator by grad() under DistributedDataParallel instead of the HIP-graph replay")
+    ap.add_argument("--torch-amplitudes", action="store_true", help="fe2s2_reduce_vmc_step: psi on the distinct x' by the PyTorch module instead of the fused RBM forward kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'extra'")
     args = ap.parse_args()
@@ -906,6 +918,8 @@ def main():
             s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
+    if args.torch_amplitudes:
+        os.environ["PYNQS_BENCH_TORCH_AMPLITUDES"] = "1"
     wl = make_workload(args.workload, args.walkers, rank, dev, args.path, args.keys, not args.eager_grad)
     if args.no_comb:
         wl.comb_ptr = None
@@ -1049,7 +1063,9 @@ def main():
             out["check"] = {"mean_eloc": [float(mean.real), float(mean.imag) if mean.is_complex() else 0.0], "var_eloc": float(wl.stats[1]),
                             "grad_l2": float(flat.double().norm()), "grad_first": [float(v) for v in flat[:4].double().cpu()]}
         if isinstance(wl, ReduceVmcStep):
-            out["config"].update({"method": "REDUCE (vmc/energy/eloc.py:205-324), the Fe2S2 example's setting", "eps": wl.eps, "eps_sample": wl.eps_sample})
+            out["config"].update({"method": "REDUCE (vmc/energy/eloc.py:205-324), the Fe2S2 example's setting", "eps": wl.eps, "eps_sample": wl.eps_sample,
+                                  "amplitudes_on_distinct_rows": "pynqs_rbm_forward (one kernel, from the packed determinants)" if wl.fused_amplitudes
+                                  else "the PyTorch module on the +-1 rows"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
     # secondary measurements (same run, N = 1 only): drop-in rows, the other fused local energies and the larger word counts

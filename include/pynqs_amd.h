@@ -343,6 +343,18 @@ int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA, int noB, 
                           const pynqs_reduce_io *io, const double *psi_unique, const double *psi_table, int psi_is_complex,
                           int divide, double *eloc, double *psi_x, void *stream);
 
+/* ---- the RBM amplitudes themselves on a LIST of determinants (kernels_rbm_forward.hip): psi(x) of vmc/ansatz/rbm/rbm.py:186-211 from the
+ * packed bits, one lane per determinant, nothing but the result written.  The amplitude forward of the REDUCE local energy (`Func` on the
+ * distinct x', vmc/energy/flip.py:44-50) when the ansatz is an RBM: the PyTorch module's GEMM + element-wise kernels on [n, nhidden] arrays
+ * cost 3.5 ms per 1.5 M determinants, this kernel 0.3-0.5 ms.
+ *   flavour PYNQS_RBM_REAL / _TANH: weights double[nhidden][sorb], hidden_bias double[nhidden], visible_bias double[sorb] or NULL; psi double[n]
+ *   flavour PYNQS_RBM_PHASE       : same parameters; psi double[n][2] = exp(i (a.x + sum_h ln 2cosh theta_h))
+ *   flavour PYNQS_RBM_COMPLEX     : weights double[nhidden][sorb][2], hidden_bias double[nhidden][2], visible_bias double[sorb][2] or NULL
+ *                                   (the reference's params_* layout, rbm_type "complex"); psi double[n][2] */
+#define PYNQS_RBM_COMPLEX 4
+int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const double *weights, const double *hidden_bias,
+                      const double *visible_bias, int nhidden, int flavour, double *psi, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

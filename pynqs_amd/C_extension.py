@@ -502,6 +502,32 @@ def eloc_rbm(bra: Tensor, h1e: Tensor, h2e: Tensor, table: RBMTable, sorb: int, 
     return eloc, psi
 
 
+def rbm_forward(onv: Tensor, weights: Tensor, hidden_bias: Tensor, visible_bias: "Tensor | None", sorb: int, rbm_type: str = "real") -> Tensor:
+    """psi(x) of the reference's RBM amplitudes (vmc/ansatz/rbm/rbm.py:186-211) on a list of determinants, one kernel
+    (pynqs_rbm_forward): onv uint8[n, 8 len] -> psi float64[n] (rbm_type "real" / "tanh") or complex128[n] ("pRBM"; "complex" with
+    weights [H, sorb, 2], hidden_bias [H, 2], visible_bias [sorb, 2] as (re, im) pairs: the reference's params_* layout)."""
+    _check_onv(onv, "onv", sorb, (2,))
+    flav = {"real": N.RBM_REAL, "tanh": N.RBM_TANH, "pRBM": N.RBM_PHASE, "complex": N.RBM_COMPLEX}.get(rbm_type)
+    if flav is None:
+        raise RuntimeError(f"rbm_type {rbm_type!r} has no fused forward")
+    cplx_par = rbm_type == "complex"
+    W = weights.detach().double().contiguous()
+    hb = hidden_bias.detach().double().contiguous()
+    vb = visible_bias.detach().double().contiguous() if visible_bias is not None else None
+    H = W.size(0)
+    if W.shape[:2] != (H, sorb) or W.dim() != (3 if cplx_par else 2) or hb.numel() != H * (2 if cplx_par else 1) or \
+            (vb is not None and vb.numel() != sorb * (2 if cplx_par else 1)):
+        raise RuntimeError("RBM parameter shapes do not match sorb / num_hidden")
+    if not (onv.is_cuda and W.is_cuda and hb.is_cuda and (vb is None or vb.is_cuda)):
+        raise RuntimeError("rbm_forward: determinants and parameters must be on the GPU")
+    n = onv.size(0)
+    out_c = rbm_type in ("pRBM", "complex")
+    psi = torch.empty(n, dtype=torch.complex128 if out_c else torch.float64, device=onv.device)
+    N.check(N.lib().pynqs_rbm_forward(onv.data_ptr(), n, sorb, W.data_ptr(), hb.data_ptr(), vb.data_ptr() if vb is not None else None, H, flav,
+                                      psi.data_ptr(), _stream(onv.device)), "pynqs_rbm_forward")
+    return psi
+
+
 class CRBMTable:
     """Device-resident re-layout of an RBM with COMPLEX parameters for the fused SIMPLE local energy (pynqs_crbm_table_build;
     rbm.py:199-211, rbm_type "complex").  weights [num_hidden, sorb], hidden_bias [num_hidden], visible_bias [sorb] or None:

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYNQS_AMD_LIB") or os.path.join(_HERE, "csrc", "libpynqs_amd.so")
 
 PYNQS_F32, PYNQS_F64 = 0, 1
-RBM_REAL, RBM_TANH, RBM_PHASE = 0, 1, 2
+RBM_REAL, RBM_TANH, RBM_PHASE, RBM_COMPLEX = 0, 1, 2, 4
 OK, EINVAL, ELAUNCH, ELENGTH, EOVERFLOW = 0, -1, -2, -3, -4
 
 _i64, _int, _vp, _dbl = C.c_int64, C.c_int, C.c_void_p, C.c_double
@@ -81,6 +81,7 @@ class ReduceIO(C.Structure):
 SIGNATURES.update({
     "pynqs_reduce_onepass_geometry": (_int, [_i64, _int, _int, _int, _int, _int, C.POINTER(_i64)]),
     "pynqs_reduce_onepass": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _int, C.c_uint64, C.POINTER(ReduceIO), _vp]),
+    "pynqs_rbm_forward": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_reduce_contract": (_int, [_i64, _int, _int, _int, _int, _int, _int, C.POINTER(ReduceIO), _vp, _vp, _int, _int, _vp, _vp, _vp]),
 })
 

@@ -593,7 +593,21 @@ def local_energy(
                     return fn(fe.uniq_pm1[:nu] if takes_rows else uniq).to(dtype)
                 return Func(fn, uniq, lut, False).to(dtype)
 
-            psi_u = on_distinct(ansatz_f, WF_LUT if ht is None else None)
+            def rbm_on_distinct():
+                """psi on the distinct x' by one kernel when the ansatz is an RBM of the reference's family (pynqs_rbm_forward), else None"""
+                if not FUSED_RBM or use_multi_psi or (WF_LUT is not None and ht is None):
+                    return None
+                prm = _real_rbm_params(ansatz)
+                if prm is not None and (dtype.is_complex == (prm[3] == "pRBM")):
+                    return CX.rbm_forward(uniq, prm[0], prm[1], prm[2], sorb, prm[3]).to(dtype)
+                cprm = _complex_rbm_params(ansatz)
+                if cprm is not None and not cprm[4] and dtype.is_complex:
+                    return CX.rbm_forward(uniq, cprm[0], cprm[1], cprm[2], sorb, "complex").to(dtype)
+                return None
+
+            psi_u = rbm_on_distinct()
+            if psi_u is None:
+                psi_u = on_distinct(ansatz_f, WF_LUT if ht is None else None)
             tab = WF_LUT.wf_value if ht is not None else None
             if plain:
                 eloc, psi_x = fe.contract(psi_u, tab)

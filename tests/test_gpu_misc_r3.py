@@ -72,3 +72,33 @@ def test_integral_layout_at_sorb_120():
     from test_host_logic import check_integral_layout
 
     check_integral_layout(120)
+
+
+@pytest.mark.parametrize("kind", ["real", "tanh", "pRBM", "complex"])
+@pytest.mark.parametrize("sorb,H", [(40, 80), (12, 5), (130, 37)])
+def test_rbm_forward_kernel_matches_the_module(kind, sorb, H):
+    """pynqs_rbm_forward against the PyTorch modules (the reference's formulas, vmc/ansatz/rbm/rbm.py:186-211) on random determinants."""
+    from pynqs_amd import C_extension as cx
+    from pynqs_amd.rbm import ComplexRBM, RealRBM
+
+    g = torch.Generator().manual_seed(sorb + H)
+    n = 3000
+    occ = (torch.rand(n, sorb, generator=g) < 0.5).to(torch.uint8).cuda()
+    onv = cx.tensor_to_onv(occ, sorb)
+    x = occ.double() * 2 - 1
+    if kind == "complex":
+        W = 0.3 * (torch.rand(H, sorb, 2, generator=g, dtype=torch.float64) - 0.5)
+        hb = torch.rand(H, 2, generator=g, dtype=torch.float64) - 0.5
+        vb = 0.2 * (torch.rand(sorb, 2, generator=g, dtype=torch.float64) - 0.5)
+        m = ComplexRBM(W, hb, vb).cuda()
+        got = cx.rbm_forward(onv, m.params_weights, m.params_hidden_bias, m.params_visible_bias, sorb, "complex")
+    else:
+        W = 0.3 * (torch.rand(H, sorb, generator=g, dtype=torch.float64) - 0.5)
+        hb = 3.0 * (torch.rand(H, generator=g, dtype=torch.float64) - 0.5)
+        vb = 0.2 * (torch.rand(sorb, generator=g, dtype=torch.float64) - 0.5)
+        m = RealRBM(W, hb, vb, rbm_type=kind).cuda()
+        got = cx.rbm_forward(onv, m.weights, m.hidden_bias, m.visible_bias, sorb, kind)
+    with torch.no_grad():
+        want = m(x)
+    assert got.dtype == want.dtype
+    torch.testing.assert_close(got, want, rtol=1e-11, atol=0 if kind != "pRBM" else 1e-11)
