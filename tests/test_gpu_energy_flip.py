@@ -274,9 +274,10 @@ def test_key_major_kernel_edge_cases(env):
 
 
 def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2, monkeypatch):
-    """A table of 2.3 x ncomb keys (Fe2S2's whole CI space) is neither clearly small nor clearly large: the first call times both
-    kernels on the walkers at hand, remembers the winner for that (system, table-size bucket), and the energies match the oracle
-    whichever it was."""
+    """A table of 2.3 x ncomb keys (Fe2S2's whole CI space) is neither clearly small nor clearly large.  By default the fixed ratio decides
+    (the same kernel on every rank and in every run, no timing inside a step); with SS_AUTOTUNE (PYNQS_SS_AUTOTUNE=1) the first call times
+    both kernels on the walkers at hand and remembers the winner for that (system, table-size bucket).  The energies match the oracle
+    whichever kernel runs."""
     from oracle import oracle as O
 
     energy, pf, T, dev = env["energy"], env["pf"], env["T"], env["dev"]
@@ -285,9 +286,12 @@ def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2
     wf = (torch.rand(keys.size(0), generator=g, dtype=torch.float64) + 0.2).to(dev)
     lut = pf.WavefunctionLUT(keys, wf, 40, device=dev)
     monkeypatch.delenv("PYNQS_SS_KEYS", raising=False)
-    assert energy.SS_KEYS is None and energy.SS_AUTOTUNE
+    assert energy.SS_KEYS is None and not energy.SS_AUTOTUNE  # (deterministic by default)
     energy._SS_CHOICE.clear()
     x = T(fe2s2["ci_space"][:96])
+    e0, _, _, _ = energy.local_energy(x, env["h1e"], env["h2e"], None, None, *SYS, WF_LUT=lut, use_sample_space=True)
+    assert len(energy._SS_CHOICE) == 0  # nothing was timed
+    monkeypatch.setattr(energy, "SS_AUTOTUNE", True)
     e, _, p0, _ = energy.local_energy(x, env["h1e"], env["h2e"], None, None, *SYS, WF_LUT=lut, use_sample_space=True)
     assert len(energy._SS_CHOICE) == 1 and isinstance(next(iter(energy._SS_CHOICE.values())), bool)
     e2, _, _, _ = energy.local_energy(x, env["h1e"], env["h2e"], None, None, *SYS, WF_LUT=lut, use_sample_space=True)
@@ -297,6 +301,8 @@ def test_sample_space_kernel_choice_is_probed_between_the_clear_cases(env, fe2s2
     np.testing.assert_array_equal(p0.cpu().numpy(), p_ref)
     np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL)
     np.testing.assert_allclose(e2.cpu().numpy(), e_ref, rtol=0, atol=TOL)
+    np.testing.assert_allclose(e0.cpu().numpy(), e_ref, rtol=0, atol=TOL)
+    energy._SS_CHOICE.clear()
 
 
 def test_fused_sample_space_accepts_the_reference_lut_class_shape(env):
