@@ -213,3 +213,40 @@ def test_float32_integrals():
     got[walker[k], col[k].long()] = True
     assert w.dtype == torch.float32 and torch.equal(got, keep) and torch.equal(w[k], hm[walker[k], col[k].long()])
     assert not keep[walker[drawn], col[drawn].long()].any()
+
+
+@pytest.mark.parametrize("N", [0, 300])
+def test_step_is_graph_capturable(N, fe2s2):
+    """reduce_front.ReduceStep: front end -> module on ALL rows of the distinct list -> contraction with static shapes, nothing read back;
+    replayed from a HIP graph it gives what the eager step gives (same seed), and every replay draws afresh (the seed word lives in
+    device memory and is bumped inside the graph)."""
+    from pynqs_amd import C_extension as cx, reduce_front as RF
+    from pynqs_amd.rbm import RealRBM
+
+    d = golden("eloc_e2e_fe2s2.npz")
+    sorb, nele, noA, noB, n, eps = 40, 30, 15, 15, 256, 1e-2
+    x = _dev(fe2s2["ci_space"][:n])
+    h1e, h2e = _dev(fe2s2["h1e"]), _dev(fe2s2["h2e"])
+    plan = cx.plan_for(h1e, h2e, sorb, x.device).buf
+    rbm = RealRBM(_dev(d["W"]), _dev(d["hb"]), _dev(d["vb"])).cuda().double()
+    mk = lambda: RF.ReduceFrontEnd(n, sorb, nele, noA, noB, N, torch.float64, x.device, 256, 60000 + 300 * n * (N > 0), torch.float64)  # noqa: E731
+    eager = RF.ReduceStep(mk(), plan, eps, rbm, seed=5, graph=False)
+    graphed = RF.ReduceStep(mk(), plan, eps, rbm, seed=5, graph=True)
+    e0, p0 = eager(x)
+    g0, q0 = graphed(x)          # (two warm-up runs on a side stream bump the device seed before the capture: align the eager step)
+    g0, q0 = g0.clone(), q0.clone()  # (a replay writes into the same output buffers)
+    eager.check(); graphed.check()
+    assert torch.equal(p0, q0) and bool(torch.isfinite(g0).all())
+    if N == 0:
+        torch.testing.assert_close(g0, e0, rtol=0, atol=1e-12)
+        g1, _ = graphed(x)
+        torch.testing.assert_close(g1, e0, rtol=0, atol=1e-12)
+    else:
+        eager.front.seed_dev.copy_(graphed.front.seed_dev - 1)   # the seed the last replay used
+        e1, _ = eager(x)
+        torch.testing.assert_close(g0, e1, rtol=0, atol=1e-10)   # same seed -> same draws -> same local energies
+        first = graphed.front.srec_col.clone()
+        g1, _ = graphed(x)
+        assert not torch.equal(first, graphed.front.srec_col)    # the next replay draws other columns
+        assert float((g1 - g0).abs().max()) > 0 and float((g1 - g0).abs().max()) < 5.0
+        graphed.check()
