@@ -612,7 +612,7 @@ class ReduceVmcStep(Workload):
         del fe0
         torch.cuda.empty_cache()
         self.front = RF.ReduceFrontEnd(self.n, sorb, nele, noA, noB, eps_sample, torch.float64, dev, int(kept_max * 1.25) + 16, int(nu * 1.1) + 1024,
-                                       torch.float64, keep_onv=False)
+                                       torch.float64, keep_onv=False, want_pm1=not fused_amplitudes)
         self.distinct_calibrated = nu
         self.seed = 12345
         self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)

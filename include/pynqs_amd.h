@@ -335,6 +335,9 @@ typedef struct pynqs_reduce_io {
                            largest seg_count of an overflowing segment, reserved */
   const uint64_t *seed_dev; /* optional: a seed in DEVICE memory, added to `seed` (a captured HIP graph replays the launch with
                                the same arguments: the caller bumps this word between replays) */
+  void *row_cache;      /* optional, eps_sample > 0: T[nbatch][ncomb] scratch.  The enumeration stores every matrix element there and the
+                           draws read the row back (L2) instead of visiting the drawn tiles a second time: worth it when the draws are
+                           dense in the row (1000 draws over Fe2S2's 7876 columns hit every tile); leave NULL for long rows */
 } pynqs_reduce_io;
 int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,

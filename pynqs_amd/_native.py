@@ -75,7 +75,7 @@ class ReduceIO(C.Structure):
                 ("rec_col", _vp), ("rec_w", _vp), ("rec_onv", _vp), ("rec_link", _vp), ("seg_count", _vp),
                 ("srec_col", _vp), ("srec_w", _vp), ("srec_onv", _vp), ("srec_link", _vp), ("row_sum", _vp),
                 ("dedup_table", _vp), ("uniq_onv", _vp), ("uniq_pm1", _vp), ("pm1_dtype", C.c_int32), ("lut_is_hash", C.c_int32),
-                ("lut_table", _vp), ("lut_nkeys", _i64), ("counters", _vp), ("seed_dev", _vp)]
+                ("lut_table", _vp), ("lut_nkeys", _i64), ("counters", _vp), ("seed_dev", _vp), ("row_cache", _vp)]
 
 
 SIGNATURES.update({

@@ -83,6 +83,7 @@ struct OnepassOut {
   int32_t *counters;
   uint32_t cap_d, fixed;
   const uint64_t *seed_dev;
+  T *row_cache;    // [nbatch][ncomb] or NULL
   uint32_t debug;  // PYNQS_OP_DEBUG ablations (timing only): 1 no amplitude source, 2 no +-1 rows, 4 no look-back
 };
 
@@ -799,7 +800,7 @@ __device__ __forceinline__ void allocate_batch(const OnepassOut<T> &o, int sorb,
   __syncthreads();
 }
 
-template <int LEN, typename T, bool SAMPLED>
+template <int LEN, typename T, bool SAMPLED, bool CACHED = false>
 struct ListKeepSink {
   T eps;
   uint32_t *list_n;
@@ -809,12 +810,14 @@ struct ListKeepSink {
   double *tsum;
   uint32_t tile;
   double sub;
+  T *__restrict__ hrow;  // CACHED: this walker's row of matrix elements in global memory (the draws read it back instead of a second enumeration)
   __device__ __forceinline__ void add(uint32_t col, T h) {
     const T a = fabs(h);
+    if constexpr (CACHED) hrow[col] = h;
     if (a >= eps) {
       const uint32_t k = atomicAdd(list_n, 1u);
       if (k < cap) { list_col[k] = col; list_h[k] = h; }
-    } else if constexpr (SAMPLED) {
+    } else if constexpr (SAMPLED && !CACHED) {
       sub += (double)a;
     }
   }
@@ -822,7 +825,7 @@ struct ListKeepSink {
   __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&)[LEN], uint32_t c1, T h1, const uint64_t (&)[LEN]) { add(c0, h0); add(c1, h1); }
   __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&)[LEN], const uint64_t (&)[LEN]) { add(col, h0); add(col + 1, h1); }
   __device__ __forceinline__ void flush() {
-    if constexpr (SAMPLED) {
+    if constexpr (SAMPLED && !CACHED) {
       if (tile == 0xffffffffu) return;
       const double s = op_wave_sum(sub);
       if ((threadIdx.x & 63) == 0) tsum[tile] = s;
@@ -974,7 +977,7 @@ __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
 }
 
-template <int LEN, typename T, bool SAMPLED>
+template <int LEN, typename T, bool SAMPLED, bool CACHED = false>
 __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
                                                                      uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
                                                                      uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
@@ -1009,7 +1012,8 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   const LdsLayout L = carve_lds(smem, p);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
   {
-    ListKeepSink<LEN, T, SAMPLED> sink{eps, &list_n, list_col, list_h, cap, tsum, 0xffffffffu, 0.0};
+    ListKeepSink<LEN, T, SAMPLED, CACHED> sink{eps, &list_n, list_col, list_h, cap, tsum, 0xffffffffu, 0.0,
+                                               CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
     visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
     sink.flush();
   }
@@ -1071,6 +1075,25 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
   }
   if constexpr (SAMPLED) {
+    const uint32_t ncomb = p.nsd + 1;
+    const T *__restrict__ hrow = CACHED ? o.row_cache + (size_t)walker * ncomb : nullptr;
+    if constexpr (CACHED) {
+      // sums of the sub-eps |H| per COLUMN tile of 256 from the cached row (written by this workgroup, the barriers above make it
+      // visible): wave w takes tiles w, w + 4, ...; fixed order of additions
+      const uint32_t nct = (ncomb + kOneTileCols - 1) / kOneTileCols;
+      for (uint32_t t = wave; t < nct; t += kBlock / 64) {
+        double sl = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t c = t * kOneTileCols + lane * 4 + j;
+          const T a = c < ncomb ? fabs(hrow[c]) : T(0);
+          sl += a >= eps ? 0.0 : (double)a;
+        }
+        sl = op_wave_sum(sl);
+        if (lane == 0) tsum[t] = sl;
+      }
+      __syncthreads();
+    }
     // ---- phase B (as in the look-back form) ----
     const uint32_t per = (max_tiles + kBlock - 1) / kBlock;
     const uint32_t b0 = min((uint32_t)tid * per, max_tiles), b1 = min(b0 + per, max_tiles);
@@ -1134,7 +1157,75 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     S.cs = reinterpret_cast<uint32_t *>(mine + (size_t)kOneTileCols * 8 + 8);
     S.hits = S.cs + kOneTileCols;
     S.ncols = reinterpret_cast<volatile uint32_t *>(S.hits + kOneTileCols);
-    if (!(o.debug & 16u)) {
+    if constexpr (CACHED) {
+      // the draws inside the column tiles, from the cached row: no second enumeration.  A wave pulls a tile, loads its 256 matrix
+      // elements (4 per lane), forms the running sums with ONE wave scan and hands them to the same draw / hit-count / emission code
+      const uint32_t nct = (ncomb + kOneTileCols - 1) / kOneTileCols;
+      const double scale = Srow / (double)nsample;
+      const int64_t sbase = (int64_t)walker * nsample;
+      for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&next_tile, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= nct) break;
+        const uint32_t info = dinfo[t], draws = info & 0xffffu;
+        if (draws == 0) continue;
+        const uint32_t c0 = t * kOneTileCols + lane * 4;
+        double w4[4];
+        uint32_t neg = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const T h = c0 + j < ncomb ? hrow[c0 + j] : T(0);
+          const T a = fabs(h);
+          w4[j] = a >= eps ? 0.0 : (double)a;
+          neg |= (h < T(0) ? 1u : 0u) << j;
+        }
+        const double ls = (w4[0] + w4[1]) + (w4[2] + w4[3]);
+        const double incl = op_scan(ls, lane);
+        const double total = __shfl(incl, 63);
+        double run = incl - ls;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          run += w4[j];
+          S.prefix[lane * 4 + j] = run;
+          S.cs[lane * 4 + j] = (c0 + j) | (((neg >> j) & 1u) << 31);
+          S.hits[lane * 4 + j] = 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ncols = min((uint32_t)kOneTileCols, ncomb - t * kOneTileCols);
+        if (!(total > 0.0)) continue;
+        for (uint32_t k = lane; k < draws; k += 64) {
+          const uint64_t r = op_mix64(key ^ op_mix64(((uint64_t)t << 32) | k));
+          const double target = (double)(r >> 11) * 0x1.0p-53 * total;
+          uint32_t lo = 0, hi = ncols;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (S.prefix[mid] > target) hi = mid; else lo = mid + 1;
+          }
+          if (lo >= ncols) lo = ncols - 1;
+          while (lo > 0 && !(S.prefix[lo] > S.prefix[lo - 1])) --lo;
+          atomicAdd(&S.hits[lo], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t pos = info >> 16;
+        for (uint32_t i0 = 0; i0 < ncols; i0 += 64) {
+          const uint32_t idx = i0 + lane;
+          const uint32_t hc = idx < ncols ? S.hits[idx] : 0u;
+          const uint64_t m = __ballot(hc != 0u);
+          if (hc) {
+            const uint32_t e = S.cs[idx], col = e & 0x7fffffffu;
+            const uint32_t at = pos + __popcll(m & ((1ull << lane) - 1ull));
+            o.srec_col[sbase + at] = (int32_t)col;
+            const double v = scale * (double)hc;
+            o.srec_w[sbase + at] = (T)((e >> 31) ? -v : v);
+            pend[at] = col;
+          }
+          pos += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if (!(o.debug & 16u)) {
       ListDrawSink<LEN, T> sink{eps, S, dinfo, Srow / (double)nsample, key, (int64_t)walker * nsample, o.srec_col, o.srec_w, pend, 0xffffffffu};
       sink.nodraw = (o.debug & 8u) != 0;
       visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
@@ -1289,6 +1380,7 @@ static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed
   static const uint32_t dbg = getenv("PYNQS_OP_DEBUG") ? (uint32_t)atoi(getenv("PYNQS_OP_DEBUG")) : 0u;
   o.debug = dbg;
   o.seed_dev = io->seed_dev;
+  o.row_cache = (T *)io->row_cache;
   (void)len;
   return o;
 }
@@ -1332,13 +1424,18 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, P, (uint32_t)eps_sample);
   const bool list_fits = seg_cap <= 2048 && lds_list + 256 <= 160 * 1024;
   const bool use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024));
+  // with a row cache (io->row_cache: [nbatch][ncomb] elements of the integral dtype) the draws read the row back instead of visiting the
+  // drawn tiles a second time (PYNQS_OP_CACHE=0 ignores the buffer)
+  static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
+  const bool use_cache = sampled && use_list && io->row_cache != nullptr && cache_env != 0;
   const size_t lds = use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, wl_cap);
   if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
   // eloc.py:257-264: with draws and eps <= 0 nothing is kept (every column can be drawn); without draws |H| >= eps as it stands
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
   do {                                                                                                                               \
-    auto kfn = use_list ? reduce_onepass_list_kernel<LEN, TT, SM> : reduce_onepass_kernel<LEN, TT, SM>;                              \
+    auto kfn = use_list ? (use_cache ? reduce_onepass_list_kernel<LEN, TT, SM, SM> : reduce_onepass_list_kernel<LEN, TT, SM, false>) \
+                        : reduce_onepass_kernel<LEN, TT, SM>;                                                                        \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                                (int)lds) != hipSuccess)                                                              \
       return check_launch("hipFuncSetAttribute");                                                                                   \

@@ -431,21 +431,21 @@ def _draw_seed() -> int:
 
 
 def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
-                 lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None):
+                 lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True):
     """Run the fused REDUCE front end on the walkers x (vmc/energy/eloc.py:243-298 + flip.py:29-63 in one launch) and return
     (front end, number of distinct x').  Buffers are cached per (device, batch size, system, eps_sample) and grown when a call
     reports that it needed more (the call is then repeated); ONE device-to-host read per call, after the kernel has been enqueued."""
     plan = CX.plan_for(h1e, h2e, sorb, x.device)
     n = x.size(0)
     pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
-    key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype)
+    key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype, bool(want_pm1))
     fe = _FRONTS.pop(key, None)
     if fe is None:
         nseg, fixed, _, _ = RF.geometry(n, sorb, nele, noa, nob, eps_sample)
         ncomb = get_Num_SinglesDoubles(sorb, noa, nob) + 1
         per_seg = (ncomb * max(n, 1) + max(nseg, 1) - 1) // max(nseg, 1)
         cap_d = min(per_seg, max(64, per_seg // 32))
-        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, max(4096, 32 * n), pm1_dtype)
+        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, max(4096, 32 * n), pm1_dtype, want_pm1=want_pm1)
     if seed is None:
         seed = _draw_seed() if eps_sample > 0 else 0
     while True:
@@ -460,7 +460,7 @@ def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa:
             cap_u = max(2 * cap_u, int(nu * 1.5))
         elif nu > cap_u:
             cap_u = int(nu * 1.25) + 1024
-        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype)
+        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype, want_pm1=want_pm1)
     _FRONTS[key] = fe  # (most recently used last)
     while len(_FRONTS) > _MAX_FRONTS:
         _FRONTS.pop(next(iter(_FRONTS)))
@@ -582,10 +582,14 @@ def local_energy(
             # the table is asked inside the kernel when it has a GPU hash table and psi is all that is needed on x' (f of the multi-psi
             # form has no table; the projected forms look flip(x') up as well): otherwise on the distinct rows, below
             ht = getattr(WF_LUT, "hashtable", None) if (WF_LUT is not None and plain) else None
-            fe, nu = reduce_front(x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht)
+            # an RBM of the reference's family gets its amplitudes on the distinct x' from the packed bits (pynqs_rbm_forward): no +-1 rows
+            rbm_fwd = FUSED_RBM and not use_multi_psi and not (WF_LUT is not None and ht is None) and (
+                (_real_rbm_params(ansatz) is not None and dtype.is_complex == (_real_rbm_params(ansatz)[3] == "pRBM"))
+                or (_complex_rbm_params(ansatz) is not None and not _complex_rbm_params(ansatz)[4] and dtype.is_complex))
+            fe, nu = reduce_front(x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht, want_pm1=not rbm_fwd)
             t2 = time.time_ns()
             uniq = fe.uniq_onv[:nu]
-            takes_rows = getattr(ansatz_batch, "accepts_pm1_rows", False) and fe.pm1_dtype == torch.get_default_dtype()
+            takes_rows = fe.uniq_pm1 is not None and getattr(ansatz_batch, "accepts_pm1_rows", False) and fe.pm1_dtype == torch.get_default_dtype()
 
             def on_distinct(fn, lut) -> Tensor:
                 """a function of the determinant on the distinct x' (the rows the kernel wrote are the module's input already)"""
@@ -595,7 +599,7 @@ def local_energy(
 
             def rbm_on_distinct():
                 """psi on the distinct x' by one kernel when the ansatz is an RBM of the reference's family (pynqs_rbm_forward), else None"""
-                if not FUSED_RBM or use_multi_psi or (WF_LUT is not None and ht is None):
+                if not rbm_fwd:
                     return None
                 prm = _real_rbm_params(ansatz)
                 if prm is not None and (dtype.is_complex == (prm[3] == "pRBM")):

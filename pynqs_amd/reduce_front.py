@@ -22,6 +22,8 @@ from torch import Tensor
 from . import _native as N
 
 OVERFLOW_DOUBLES, OVERFLOW_TABLE, OVERFLOW_UNIQUE = 1, 2, 4
+ROW_CACHE = True                  # semi-stochastic kernel: cache the row in global memory for the draws (see ReduceFrontEnd)
+ROW_CACHE_MAX_BYTES = 8 << 30
 
 
 def _pow2_at_least(v: int) -> int:
@@ -53,7 +55,7 @@ class ReduceFrontEnd:
     rows for the distinct x'."""
 
     def __init__(self, n: int, sorb: int, nele: int, noa: int, nob: int, eps_sample: int, h_dtype: torch.dtype, device,
-                 cap_doubles: int, cap_unique: int, pm1_dtype: torch.dtype = torch.float64, keep_onv: bool = True) -> None:
+                 cap_doubles: int, cap_unique: int, pm1_dtype: torch.dtype = torch.float64, keep_onv: bool = True, want_pm1: bool = True) -> None:
         if h_dtype not in (torch.float64, torch.float32) or pm1_dtype not in (torch.float64, torch.float32):
             raise TypeError("float32 / float64 only")
         self.n, self.sorb, self.nele, self.noa, self.nob = int(n), sorb, nele, noa, nob
@@ -86,9 +88,18 @@ class ReduceFrontEnd:
         self.uniq_onv = torch.zeros((self.cap_unique, 8 * L), dtype=torch.uint8, device=dev)
         # rows beyond the distinct count keep whatever an earlier call (or the first walker, below) left there: always a valid +-1 row,
         # so that a captured step may run the ansatz on all cap_unique rows
-        self.uniq_pm1 = torch.ones((self.cap_unique, sorb), dtype=pm1_dtype, device=dev)
+        # (want_pm1 = False: the caller evaluates the amplitudes from the packed determinants, e.g. pynqs_rbm_forward: 0.1 ms and 0.47 GB of
+        # writes less per 1.5 M distinct x')
+        self.uniq_pm1 = torch.ones((self.cap_unique, sorb), dtype=pm1_dtype, device=dev) if want_pm1 else None
         self.counters = torch.zeros(4, dtype=torch.int32, device=dev)
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # added to run()'s seed: bump it between the replays of a captured step
+        # row cache of the semi-stochastic kernel: the draws read the row back instead of enumerating the drawn tiles again.  Worth it when
+        # the draws are dense in the row (>= one draw per 64 columns) and the [n, ncomb] scratch is affordable (<= ROW_CACHE_MAX_BYTES)
+        ncomb = int(N.lib().pynqs_num_sd(sorb, noa, nob)) + 1
+        esz = 8 if h_dtype == torch.float64 else 4
+        self.row_cache = None
+        if self.eps_sample > 0 and self.nchunks == 1 and ROW_CACHE and self.eps_sample * 64 >= ncomb and self.n * ncomb * esz <= ROW_CACHE_MAX_BYTES:
+            self.row_cache = torch.empty(max(self.n * ncomb, 1), dtype=h_dtype, device=dev)
         self._lut = None
         self._io = self._make_io()
 
@@ -101,13 +112,15 @@ class ReduceFrontEnd:
         io.srec_col, io.srec_w = self.srec_col.data_ptr(), (self.srec_w if srec_w is None else srec_w).data_ptr()
         io.srec_onv = self.srec_onv.data_ptr() if self.srec_onv is not None else None
         io.srec_link, io.row_sum = self.srec_link.data_ptr(), self.row_sum.data_ptr()
-        io.dedup_table, io.uniq_onv, io.uniq_pm1 = self.table.data_ptr(), self.uniq_onv.data_ptr(), self.uniq_pm1.data_ptr()
+        io.dedup_table, io.uniq_onv = self.table.data_ptr(), self.uniq_onv.data_ptr()
+        io.uniq_pm1 = self.uniq_pm1.data_ptr() if self.uniq_pm1 is not None else None
         io.pm1_dtype = N.PYNQS_F64 if self.pm1_dtype == torch.float64 else N.PYNQS_F32
         io.lut_is_hash = 1
         io.lut_table = lut.table.data_ptr() if lut is not None else None
         io.lut_nkeys = lut.nkeys if lut is not None else 0
         io.counters = self.counters.data_ptr()
         io.seed_dev = self.seed_dev.data_ptr()
+        io.row_cache = self.row_cache.data_ptr() if self.row_cache is not None else None
         return io
 
     # ---- launches -------------------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ x = torch.from_numpy(np.ascontiguousarray(ci[np.arange(n) % ci.shape[0]])).to(de
 h1, h2 = torch.from_numpy(d["h1e"]).to(dev), torch.from_numpy(d["h2e"]).to(dev)
 plan = cx.plan_for(h1, h2, 40, dev).buf
 for N, capu in ((0, 300000), (1000, 1900000)):
-    fe = RF.ReduceFrontEnd(n, 40, 30, 15, 15, N, torch.float64, dev, 246, capu)
+    fe = RF.ReduceFrontEnd(n, 40, 30, 15, 15, N, torch.float64, dev, 246, capu, want_pm1=os.environ.get("NO_PM1") != "1")
     for _ in range(3):
         fe.run(x, plan, 1e-2, 3, None)
     torch.cuda.synchronize()
