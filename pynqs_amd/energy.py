@@ -42,6 +42,17 @@ from .public_function import (SpinProjection, WavefunctionLUT, ansatz_batch, che
 FUSED = True  # use the fused sample-space / reduce kernels when the configuration allows it
 FUSED_SAMPLED = True  # REDUCE with eps_sample > 0: select and draw on chip (reduce_compact_sampled) instead of torch.multinomial on the matrix
 FUSED_RBM = True  # SIMPLE method: evaluate a real RBM ansatz inside the kernel (pynqs_eloc_rbm) instead of calling the module
+OVERLAP = __import__("os").environ.get("PYNQS_OVERLAP", "1") != "0"  # total_energy: front end of the next walker chunk on a second stream
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
+
+
 FUSED_ONEPASS = True  # REDUCE: the one-launch front end (reduce_front.ReduceFrontEnd); False: the multi-pass compaction of round 2
 
 
@@ -419,7 +430,7 @@ def reduce_compact_sampled(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele:
 
 # ---- REDUCE through the one-launch front end ---------------------------------------------------------------------------------
 _FRONTS: "dict[tuple, RF.ReduceFrontEnd]" = {}
-_MAX_FRONTS = 4
+_MAX_FRONTS = 6
 
 
 def _draw_seed() -> int:
@@ -430,29 +441,46 @@ def _draw_seed() -> int:
     return (s ^ ((r + 1) * 0x9E3779B97F4A7C15)) & (2**63 - 1) if r else s
 
 
-def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
-                 lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True):
-    """Run the fused REDUCE front end on the walkers x (vmc/energy/eloc.py:243-298 + flip.py:29-63 in one launch) and return
-    (front end, number of distinct x').  Buffers are cached per (device, batch size, system, eps_sample) and grown when a call
-    reports that it needed more (the call is then repeated); ONE device-to-host read per call, after the kernel has been enqueued."""
-    plan = CX.plan_for(h1e, h2e, sorb, x.device)
-    n = x.size(0)
-    pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
-    key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype, bool(want_pm1))
-    fe = _FRONTS.pop(key, None)
-    if fe is None:
+def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d=None, cap_u=None):
+    if cap_d is None:
         nseg, fixed, _, _ = RF.geometry(n, sorb, nele, noa, nob, eps_sample)
         ncomb = get_Num_SinglesDoubles(sorb, noa, nob) + 1
         per_seg = (ncomb * max(n, 1) + max(nseg, 1) - 1) // max(nseg, 1)
-        cap_d = min(per_seg, max(64, per_seg // 32))
-        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, max(4096, 32 * n), pm1_dtype, want_pm1=want_pm1)
+        cap_d, cap_u = min(per_seg, max(64, per_seg // 32)), max(4096, 32 * n)
+    return RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype, want_pm1=want_pm1)
+
+
+def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
+                        lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True, slot: int = 0):
+    """Enqueue the fused REDUCE front end for the walkers x on the CURRENT stream (buffers cached per (device, batch size, system,
+    eps_sample, slot)) together with an asynchronous copy of its counters to pinned host memory; returns a ticket for reduce_front_finish.
+    Nothing is waited for: a caller can enqueue the front end of the NEXT chunk of walkers on a second stream while the ansatz works on
+    the current one (total_energy does: SURVEY 7.6)."""
+    plan = CX.plan_for(h1e, h2e, sorb, x.device)
+    n = x.size(0)
+    pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
+    key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype, bool(want_pm1), int(slot))
+    fe = _FRONTS.pop(key, None)
+    if fe is None:
+        fe = _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1)
     if seed is None:
         seed = _draw_seed() if eps_sample > 0 else 0
-    while True:
-        fe.run(x, plan.buf, eps, seed, lut)
-        cnt = fe.counters_host()
-        if not fe.overflowed(cnt):
-            break
+    fe.run(x, plan.buf, eps, seed, lut)
+    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+    host.copy_(fe.counters, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(x.device))
+    return dict(fe=fe, key=key, host=host, ev=ev, x=x, plan=plan, eps=eps, seed=seed, lut=lut, args=(h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1))
+
+
+def reduce_front_finish(t):
+    """(front end, number of distinct x') of a ticket: waits for THAT launch only (its event), grows the buffers and repeats the call on
+    the current stream if it reported an overflow."""
+    t["ev"].synchronize()
+    fe, x = t["fe"], t["x"]
+    cnt = tuple(int(v) for v in t["host"].tolist()[:3])
+    h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1 = t["args"]
+    while fe.overflowed(cnt):
         nu, flags, mx = cnt
         cap_d = max(fe.cap_doubles, int(mx * 1.25) + 16) if mx > fe.cap_doubles else fe.cap_doubles
         cap_u = fe.cap_unique
@@ -460,11 +488,37 @@ def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa:
             cap_u = max(2 * cap_u, int(nu * 1.5))
         elif nu > cap_u:
             cap_u = int(nu * 1.25) + 1024
-        fe = RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype, want_pm1=want_pm1)
-    _FRONTS[key] = fe  # (most recently used last)
+        fe = _new_front(x.size(0), x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d, cap_u)
+        fe.run(x, t["plan"].buf, t["eps"], t["seed"], t["lut"])
+        cnt = fe.counters_host()
+    _FRONTS[t["key"]] = fe  # (most recently used last)
     while len(_FRONTS) > _MAX_FRONTS:
         _FRONTS.pop(next(iter(_FRONTS)))
     return fe, cnt[0]
+
+
+def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
+                 lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True):
+    """Run the fused REDUCE front end on the walkers x (vmc/energy/eloc.py:243-298 + flip.py:29-63 in one launch) and return
+    (front end, number of distinct x').  Buffers are cached per (device, batch size, system, eps_sample) and grown when a call
+    reports that it needed more (the call is then repeated); ONE device-to-host read per call, after the kernel has been enqueued."""
+    return reduce_front_finish(reduce_front_launch(x, h1e, h2e, sorb, nele, noa, nob, eps, eps_sample, lut, seed, pm1_dtype, want_pm1))
+
+
+def _reduce_front_options(ansatz, WF_LUT, dtype, use_multi_psi, use_spin_flip):
+    """(wave-function hash table asked inside the kernel or None, amplitudes of the distinct x' by pynqs_rbm_forward?) for local_energy's
+    REDUCE path -- one definition for local_energy and for total_energy's look-ahead."""
+    plain = not (use_multi_psi or use_spin_flip)
+    # the table is asked inside the kernel when it has a GPU hash table and psi is all that is needed on x' (f of the multi-psi
+    # form has no table; the projected forms look flip(x') up as well): otherwise on the distinct rows
+    ht = getattr(WF_LUT, "hashtable", None) if (WF_LUT is not None and plain) else None
+    # an RBM of the reference's family gets its amplitudes on the distinct x' from the packed bits (pynqs_rbm_forward): no +-1 rows
+    rp, cp = _real_rbm_params(ansatz), None
+    if rp is None:
+        cp = _complex_rbm_params(ansatz)
+    rbm_fwd = bool(FUSED_RBM and not use_multi_psi and not (WF_LUT is not None and ht is None) and (
+        (rp is not None and dtype.is_complex == (rp[3] == "pRBM")) or (cp is not None and not cp[4] and dtype.is_complex)))
+    return ht, rbm_fwd
 
 
 def _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample) -> bool:
@@ -477,9 +531,11 @@ def local_energy(
     dtype=torch.double, use_spin_raising: bool = False, h1e_spin: Optional[Tensor] = None, h2e_spin: Optional[Tensor] = None,
     WF_LUT: Optional[WavefunctionLUT] = None, use_unique: bool = True, reduce_psi: bool = False, eps: float = 1e-12,
     eps_sample: int = 0, use_sample_space: bool = False, index: Optional[Tuple[int, int]] = None, alpha: float = 2,
-    use_multi_psi: bool = False, use_spin_flip: bool = False, extra_norm: Optional[Tensor] = None,
+    use_multi_psi: bool = False, use_spin_flip: bool = False, extra_norm: Optional[Tensor] = None, _front_ticket=None,
 ) -> Tuple[Tensor, Tensor, Tensor, Tuple[float, float, float]]:
-    """vmc/energy/eloc.py:23-132.  Returns (eloc[n], sloc[n], psi(x)[n], (t_enumerate, t_hij, t_psi) in ms)."""
+    """vmc/energy/eloc.py:23-132.  Returns (eloc[n], sloc[n], psi(x)[n], (t_enumerate, t_hij, t_psi) in ms).
+    _front_ticket (not in the reference): a reduce_front_launch ticket for exactly these walkers and arguments, enqueued earlier
+    (total_energy's look-ahead on a second stream)."""
     with torch.no_grad():
         check_para(x)
         assert x.dim() == 2
@@ -579,14 +635,11 @@ def local_energy(
         # ---- fast path: REDUCE through the one-launch front end (deterministic and semi-stochastic, every form) ---------------
         if reduce_psi and not use_sample_space and batch > 0 and _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample):
             plain = not (use_multi_psi or use_spin_flip)
-            # the table is asked inside the kernel when it has a GPU hash table and psi is all that is needed on x' (f of the multi-psi
-            # form has no table; the projected forms look flip(x') up as well): otherwise on the distinct rows, below
-            ht = getattr(WF_LUT, "hashtable", None) if (WF_LUT is not None and plain) else None
-            # an RBM of the reference's family gets its amplitudes on the distinct x' from the packed bits (pynqs_rbm_forward): no +-1 rows
-            rbm_fwd = FUSED_RBM and not use_multi_psi and not (WF_LUT is not None and ht is None) and (
-                (_real_rbm_params(ansatz) is not None and dtype.is_complex == (_real_rbm_params(ansatz)[3] == "pRBM"))
-                or (_complex_rbm_params(ansatz) is not None and not _complex_rbm_params(ansatz)[4] and dtype.is_complex))
-            fe, nu = reduce_front(x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht, want_pm1=not rbm_fwd)
+            ht, rbm_fwd = _reduce_front_options(ansatz, WF_LUT, dtype, use_multi_psi, use_spin_flip)
+            if _front_ticket is not None:
+                fe, nu = reduce_front_finish(_front_ticket)
+            else:
+                fe, nu = reduce_front(x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht, want_pm1=not rbm_fwd)
             t2 = time.time_ns()
             uniq = fe.uniq_onv[:nu]
             takes_rows = fe.uniq_pm1 is not None and getattr(ansatz_batch, "accepts_pm1_rows", False) and fe.pm1_dtype == torch.get_default_dtype()
@@ -821,13 +874,44 @@ def total_energy(
 
     _ansatz_batch.accepts_pm1_rows = True  # (public_function.ansatz_batch takes uint8 determinants or ready +-1 rows)
 
+    # REDUCE with several chunks of walkers: the front end of chunk k + 1 runs on a second stream while the ansatz works on the distinct x'
+    # of chunk k ("overlap kernel(i+1) with forward(i) on two HIP streams"); two workspaces take turns.  OVERLAP = False or
+    # PYNQS_OVERLAP=0: everything on the current stream.
+    starts = [0] + list(ends[:-1])
+    look_ahead = (OVERLAP and reduce_psi and not use_sample_space and len(ends) >= 2 and x.is_cuda
+                  and all(_front_ok(x[b:e], h1e, sorb, nele, noa, nob, eps_sample) for b, e in ((starts[0], ends[0]), (starts[-1], ends[-1]))))
+    tickets, done = {}, {}
+    if look_ahead:
+        main = torch.cuda.current_stream(device)
+        side = _side_stream(device)
+        ht_, rbm_fwd_ = _reduce_front_options(ansatz, WF_LUT, dtype, use_multi_psi, use_spin_flip)
+
+        def launch(k: int) -> None:
+            xs = x[starts[k]:ends[k]].contiguous()
+            side.wait_stream(main) if k == 0 else None
+            if k >= 2:
+                side.wait_event(done[k - 2])  # the workspace of slot k % 2 is free once chunk k - 2 has been contracted
+            with torch.cuda.stream(side):
+                tickets[k] = reduce_front_launch(xs, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht_, want_pm1=not rbm_fwd_, slot=k % 2)
+
+        launch(0)
     begin = 0
-    for end in ends:
+    for k, end in enumerate(ends):
+        ticket = None
+        if look_ahead:
+            ticket = tickets.pop(k)
+            ticket["ev"].synchronize()           # (host: the counters of chunk k are there)
+            main.wait_event(ticket["ev"])         # (device: chunk k's records are there before the ansatz / contraction read them)
+            if k + 1 < len(ends):
+                launch(k + 1)                     # runs while the ansatz works on chunk k
         _eloc, _sloc, _psi, _ = local_energy(
-            x[begin:end], h1e, h2e, ansatz, _ansatz_batch, sorb, nele, noa, nob, dtype=dtype, WF_LUT=WF_LUT,
+            ticket["x"] if ticket is not None else x[begin:end], h1e, h2e, ansatz, _ansatz_batch, sorb, nele, noa, nob, dtype=dtype, WF_LUT=WF_LUT,
             use_spin_raising=False if reduce_psi else use_spin_raising, h1e_spin=h1e_spin, h2e_spin=h2e_spin, use_unique=use_unique,
             reduce_psi=reduce_psi, eps=eps, eps_sample=eps_sample, use_sample_space=use_sample_space, index=(begin, end), alpha=alpha,
-            use_multi_psi=use_multi_psi, extra_norm=extra_norm, use_spin_flip=use_spin_flip)
+            use_multi_psi=use_multi_psi, extra_norm=extra_norm, use_spin_flip=use_spin_flip, _front_ticket=ticket)
+        if look_ahead:
+            done[k] = torch.cuda.Event()
+            done[k].record(main)
         if reduce_psi and use_spin_raising:
             # <S-S+> is recomputed in the sample space (etot.py:119-142)
             _sloc, _, _, _ = local_energy(x[begin:end], h1e_spin, h2e_spin, ansatz, _ansatz_batch, sorb, nele, noa, nob, dtype=dtype,

@@ -169,6 +169,29 @@ def test_total_energy_sizes_its_own_chunks(env):
     assert energy.auto_nbatch(env["x"], env["h1e"], 40, 30, 15, 15, env["rbm"], lut, torch.double, False, 0, True, False, False, False) == env["x"].size(0)
 
 
+@pytest.mark.parametrize("eps_sample", [0, 150])
+def test_total_energy_look_ahead_on_a_second_stream(env, eps_sample):
+    """REDUCE over several chunks of walkers: the front end of chunk k + 1 is enqueued on a second stream while the ansatz works on chunk k
+    (SURVEY 7.6); same numbers as everything on one stream, also with draws (the seeds are drawn in chunk order either way)."""
+    energy = env["energy"]
+    args = (env["h1e"], env["h2e"], env["rbm"], 40, 30, 15, 15)
+    out = {}
+    old_rbm, energy.FUSED_RBM = energy.FUSED_RBM, False  # (the module path: the ansatz runs on the main stream)
+    try:
+        for ov in (True, False):
+            old, energy.OVERLAP = energy.OVERLAP, ov
+            try:
+                torch.manual_seed(99)
+                out[ov] = energy.total_energy(env["x"], 5, 100000, *args, reduce_psi=True, eps=1e-2, eps_sample=eps_sample)[0]
+            finally:
+                energy.OVERLAP = old
+    finally:
+        energy.FUSED_RBM = old_rbm
+    assert torch.equal(out[True], out[False])
+    if eps_sample == 0:
+        np.testing.assert_allclose(out[True].cpu().numpy(), env["d"]["eloc_reduce"], rtol=0, atol=TOL)
+
+
 def test_spin_flip_helpers_and_eps0_consistency(env):
     """Helper forms (packed / occupation rows) agree, and REDUCE with eps = 0 equals SIMPLE for the projected form.  (Parity of the
     projected and multi-psi local energies themselves against the reference's Python: test_gpu_energy_flip.py.)"""
