@@ -25,7 +25,10 @@
 
 namespace pynqs {
 
-constexpr int kKeysWalkers = 4;   // walkers per wave
+#ifndef PYNQS_KEYS_W
+#define PYNQS_KEYS_W 4
+#endif
+constexpr int kKeysWalkers = PYNQS_KEYS_W;   // walkers per wave (their 32-bit folds live in scalar registers, the words in LDS)
 constexpr uint32_t kKeysQueue = 128;  // < 64 left over + 64 parked by one comparison
 
 // alpha <-> beta occupations exchanged in place; returns true if eta_m = (-1)^(doubly occupied spatial orbitals) is -1 (the same for
@@ -87,29 +90,22 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
   const int64_t wbase = ((int64_t)group * NW + wave) * W;  // this wave's first walker
   const int sorb = p.sorb;
   // ---- the wave's walkers: words (scalar), occupied lists, <x|H|x>
-  uint64_t x[W][LEN];
-  int nocc[W];
+  uint32_t fx[W];  // 32-bit folds of the walkers (scalar): all the common path needs
 #pragma unroll
   for (int w = 0; w < W; ++w) {
     const bool valid = wbase + w < nbatch;
-    nocc[w] = 0;
+    int nocc = 0;
+    fx[w] = 0;
 #pragma unroll
     for (int i = 0; i < LEN; ++i) {
       const uint64_t v = valid ? bra[(wbase + w) * LEN + i] : ~0ull;  // (no key is within four bits of all-ones)
       const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-      x[w][i] = ((uint64_t)hi << 32) | lo;
-      if (lane == 0) xs[wave][w][i] = x[w][i];
-      if ((x[w][i] >> lane) & 1ull) occ[wave][w][nocc[w] + __popcll(x[w][i] & ((1ull << lane) - 1ull))] = (uint8_t)(64 * i + lane);
-      nocc[w] += __popcll(x[w][i]);
+      const uint64_t xw = ((uint64_t)hi << 32) | lo;
+      if (lane == 0) xs[wave][w][i] = xw;
+      if ((xw >> lane) & 1ull) occ[wave][w][nocc + __popcll(xw & ((1ull << lane) - 1ull))] = (uint8_t)(64 * i + lane);
+      nocc += __popcll(xw);
+      fx[w] ^= lo ^ hi;
     }
-    if (!valid) nocc[w] = 0;  // (no <x|H|x> for the padding walkers: their "orbitals" lie outside the plan)
-  }
-  uint32_t fx[W];  // 32-bit folds of the walkers (scalar)
-#pragma unroll
-  for (int w = 0; w < W; ++w) {
-    fx[w] = 0;
-#pragma unroll
-    for (int i = 0; i < LEN; ++i) fx[w] ^= (uint32_t)x[w][i] ^ (uint32_t)(x[w][i] >> 32);
   }
   __builtin_amdgcn_wave_barrier();
   // <x|H|x> of the wave's walker w, by the whole wave, when (and where) the key equal to x turns up: once per walker over the whole
@@ -235,7 +231,10 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
 
   // ---- the workgroup's chunk of keys: U keys per lane and step, the next step's keys requested before this step's are compared
   // (a wave alone with one dependent load per step waits an L2 round trip per 64 keys: 0.50 ms for 8192 walkers x 2.8e4 keys)
-  constexpr int U = 4;
+#ifndef PYNQS_KEYS_U3
+#define PYNQS_KEYS_U3 2
+#endif
+  constexpr int U = LEN == 3 ? PYNQS_KEYS_U3 : 4;
   const int64_t k_lo = (int64_t)chunk * chunk_len, k_hi = min(k_lo + chunk_len, nkeys);
   uint64_t ynext[U][LEN];
   auto request = [&](int64_t k0) {
@@ -262,9 +261,11 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
       // the cheap test (spin sectors and hole / particle balance are checked by the evaluation).  Common path: the 32-bit FOLD of a
       // determinant (XOR of its 32-bit quarters): folding never increases a Hamming distance, so fold(x) ^ fold(y) with more than four
       // bits set rules the pair out -- one xor and one popcount per (walker, key) whatever the word count, and for the W walkers of a
-      // key together one minimum and ONE wave-wide question (a branch per (walker, key group) cost more than the popcounts).
-      // Unrelated determinants differ in tens of bits and their folds in ~16 +- 3.  (Keys past the chunk's end were loaded as 0;
-      // walkers past the batch's end are all-ones patterns: whatever their folds say, the full comparison below rejects them.)
+      // key together one minimum and ONE wave-wide question (a branch per (walker, key group) cost more than the popcounts; one
+      // question for all U key groups of a step was tried in round 3 and is slower: 0.19 -> 0.22 ms at two words, the folds of
+      // U x W pairs held across the branch).  Unrelated determinants differ in tens of bits and their folds in ~16 +- 3.  (Keys past
+      // the chunk's end were loaded as 0; walkers past the batch's end are all-ones patterns: whatever their folds say, the full
+      // comparison below rejects them.)
       uint32_t fy = 0;
 #pragma unroll
       for (int i = 0; i < LEN; ++i) fy ^= (uint32_t)y[u][i] ^ (uint32_t)(y[u][i] >> 32);
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
         if (!__ballot(folded[w] <= 4)) continue;  // (wave-uniform)
         int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < LEN; ++i) cnt += __popcll(x[w][i] ^ y[u][i]);
+        for (int i = 0; i < LEN; ++i) cnt += __popcll(xs[wave][w][i] ^ y[u][i]);  // (rare path: the walker's words from LDS, one address per wave)
         if (__ballot(cnt <= 4)) {  // (wave-uniform)
           const uint32_t code = ((uint32_t)w << 28) | minus | (uint32_t)k;
           if (__ballot(in && cnt == 0)) {  // the key equal to the walker itself (keys are distinct: one lane, once per walker and launch)
