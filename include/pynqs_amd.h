@@ -161,6 +161,28 @@ int pynqs_eloc_sample_space_keys(const uint64_t *bra, int64_t nbatch, int sorb, 
                                  const uint64_t *keys, int64_t nkeys, const double *wf, int wf_is_complex, int flip, double *eloc,
                                  double *psi0, void *stream);
 
+/* ---- the same behind a BLOCK INDEX of the keys (round 3; kernels_keys_index.hip, kernels_eloc_keys.hip INDEXED): the sorb bits are cut
+ * into 5 blocks; a determinant within a double excitation of x agrees with x in at least one whole block, so only the keys that share a
+ * block value with the walker are loaded and compared (binary searches in the per-block sorted lists), each counted in the first block it
+ * agrees in.  Work per walker ~ the number of such keys (tens for a table of samples at sorb >= 56) instead of nkeys.
+ *   pynqs_keys_index_bytes     : [host] size of the index (60 bytes per key), -1 on bad arguments (sorb even, nkeys < 2^27)
+ *   pynqs_keys_index_workspace : [host] scratch bytes for the build
+ *   pynqs_keys_index_build     : index <- keys uint64[nkeys][len] (any order, distinct); five stable radix sorts: the index, and
+ *                                with it the order of the kernel's additions, is a function of the key array alone
+ *   pynqs_keys_index_density   : *sum_sq (device, uint64) = sum over the runs of equal block values of length^2: a key of the table used
+ *                                as a walker meets sum_sq / nkeys keys through the index (streamed: nkeys).  CAS-like tables share blocks
+ *                                among thousands of keys (Fe2S2: 21.5e3 per walker of 18.5e3 keys) -- the streamed or the column-major
+ *                                form is the one to use there; tables of samples at sorb >= 56 do not (13 of 65.5e3 at sorb 120 / 184)
+ *   pynqs_eloc_sample_space_indexed : pynqs_eloc_sample_space_keys with the index (same arguments, same results up to the order
+ *                                of the additions; no atomics: bit-reproducible)                                                          */
+int64_t pynqs_keys_index_bytes(int64_t nkeys, int sorb);
+int64_t pynqs_keys_index_workspace(int64_t nkeys, int sorb);
+int pynqs_keys_index_build(const uint64_t *keys, int64_t nkeys, int sorb, void *index, void *workspace, void *stream);
+int pynqs_keys_index_density(const void *index, int64_t nkeys, int sorb, uint64_t *sum_sq, void *stream);
+int pynqs_eloc_sample_space_indexed(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                                    const uint64_t *keys, int64_t nkeys, const void *index, const double *wf, int wf_is_complex,
+                                    int flip, double *eloc, double *psi0, void *stream);
+
 /* ---- duplicates among determinants, without a sort (`Func`, vmc/energy/flip.py:44-50: torch.unique(dim=0,
  * return_inverse=True) on the x' that reach the ansatz).  first[i] = smallest j with onv[j] == onv[i] (int32[n]);
  * the rows with first[i] == i are the distinct determinants in order of first appearance.  Deterministic.

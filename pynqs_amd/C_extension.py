@@ -421,6 +421,37 @@ def hash_build(bra_key: Tensor, sorb: int) -> HashTable:
     return HashTable(table, k.size(0), sorb)
 
 
+class KeysIndex:
+    """Block index of a key table for the INDEXED key-major SAMPLE_SPACE kernel (include/pynqs_amd.h: pynqs_keys_index_build): per block
+    of the orbitals the keys' block values sorted, with the key numbers.  `per_walker`: keys a table member meets through the index
+    (the streamed form meets nkeys)."""
+
+    def __init__(self, index: Tensor, nkeys: int, sorb: int, per_walker: float) -> None:
+        self.index, self.nkeys, self.sorb, self.per_walker = index, nkeys, sorb, per_walker
+
+    @property
+    def memory(self) -> int:
+        return self.index.numel() * self.index.element_size()
+
+
+def keys_index_build(bra_key: Tensor, sorb: int) -> KeysIndex:
+    """keys uint8[nkeys, 8*len] (distinct, any order, on the GPU) -> KeysIndex.  One host synchronisation (the density read-back)."""
+    _check_onv(bra_key, "bra_key", sorb, (2,))
+    if not bra_key.is_cuda:
+        raise ValueError("keys_index_build: the keys must be on the GPU")
+    k = bra_key.contiguous()
+    dev, nk, lib = k.device, k.size(0), N.lib()
+    nbytes, wbytes = lib.pynqs_keys_index_bytes(nk, sorb), lib.pynqs_keys_index_workspace(nk, sorb)
+    if nbytes < 0 or wbytes < 0:
+        raise ValueError(f"keys_index_build: sorb must be even and nkeys < 2^27 (sorb {sorb}, {nk} keys)")
+    index = torch.empty(max((nbytes + 7) // 8, 1), dtype=torch.int64, device=dev)
+    work = torch.empty(max(wbytes, 8), dtype=torch.uint8, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    N.check(lib.pynqs_keys_index_build(k.data_ptr(), nk, sorb, index.data_ptr(), work.data_ptr(), _stream(dev)), "keys_index_build")
+    N.check(lib.pynqs_keys_index_density(index.data_ptr(), nk, sorb, total.data_ptr(), _stream(dev)), "keys_index_density")
+    return KeysIndex(index, nk, sorb, float(total.item()) / max(nk, 1))
+
+
 def hash_lookup(ht: HashTable, onv: Tensor) -> Tuple[Tensor, Tensor]:
     """cuda_tensor.cpp:536-559 (hash_lookup): (idx int64[n] or -1, mask bool[n]); same answers as wavefunction_lut
     on the key array the table was built from."""

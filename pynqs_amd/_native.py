@@ -45,6 +45,11 @@ SIGNATURES = {
     "pynqs_eloc_sample_space_flip": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "pynqs_eloc_sample_space_hash_flip": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp]),
     "pynqs_eloc_sample_space_keys": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _int, _int, _vp, _vp, _vp]),
+    "pynqs_keys_index_bytes": (_i64, [_i64, _int]),
+    "pynqs_keys_index_workspace": (_i64, [_i64, _int]),
+    "pynqs_keys_index_build": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
+    "pynqs_keys_index_density": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "pynqs_eloc_sample_space_indexed": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _int, _int, _vp, _vp, _vp]),
     "pynqs_eloc_rbm_supported": (_int, [_int, _int, _int, _int, _int]),
     "pynqs_rbm_table_bytes": (_i64, [_int, _int]),
     "pynqs_rbm_table_build": (_int, [_vp, _vp, _vp, _int, _int, _vp, _vp]),

@@ -285,6 +285,30 @@ __host__ __device__ inline void filter_positions(uint32_t z, uint32_t fbits, uin
   b1 = z >> (uint32_t)__builtin_clz(fbits - 1u);  // 32 - k
 }
 
+// ---- block index of a key table (kernels_keys_index.hip builds it, kernels_eloc_keys.hip's INDEXED form reads it)
+constexpr int kIndexBlocks = 5;  // one more than the bits a double excitation changes: x and x' agree in a whole block
+
+constexpr int kIndexTagShift = 40;  // sorted values carry their block number above the widest block (2 * ceil(96 / 5) = 40 bits)
+
+// first bit of block b (b = kIndexBlocks: sorb).  Even, so that a block holds whole spatial orbitals and the alpha <-> beta exchange of
+// the projected form maps a block onto itself.
+__host__ __device__ inline int index_block_lo(int sorb, int b) { return 2 * ((b * (sorb / 2)) / kIndexBlocks); }
+
+// bits [lo, hi) of a determinant (hi - lo <= 40)
+template <int LEN>
+__host__ __device__ inline uint64_t index_block_value(const uint64_t (&x)[LEN], int lo, int hi) {
+  const int w = lo >> 6, sh = lo & 63;
+  uint64_t a = 0, next = 0;  // (selected, not indexed: x lives in registers)
+#pragma unroll
+  for (int i = 0; i < LEN; ++i) {
+    if (i == w) a = x[i];
+    if (i == w + 1) next = x[i];
+  }
+  uint64_t v = a >> sh;
+  if (sh) v |= next << (64 - sh);
+  return v & ((1ull << (hi - lo)) - 1ull);
+}
+
 // First probe only: the slot content (to let a caller issue several independent first probes back to back).
 template <int LEN>
 struct HashProbe {

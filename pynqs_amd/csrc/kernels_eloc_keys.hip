@@ -15,6 +15,12 @@
 //     rules (plan_dev.h: finish_double); singles add their nele terms from the walker's occupied list in LDS; <x|H|x> is computed by the
 //     wave that meets the key equal to x, when it meets it;
 //   - the keys need not be sorted and no hash table is involved; psi(x) is the table value of the key equal to x (0 if x is not in S).
+// INDEXED (round 3): the same evaluation behind a BLOCK INDEX of the keys instead of the stream over all of them.  The sorb bits are cut
+// into five blocks; a determinant within a double excitation of x differs from it in at most four bits, so it agrees with x in at least
+// one whole block (multi-index hashing).  The index (pynqs_keys_index_build) holds, per block, the keys' block values sorted with the
+// key numbers beside them; a walker looks its own five block values up (binary searches, all walkers and blocks of a wave at once, one
+// per lane), and only the keys found there are loaded and compared -- each counted in the first block it agrees in.  Work per walker is
+// the number of such keys (tens for a table of samples at sorb 120 / 184; ~|S| / 8 for Fe2S2's CAS-like table) instead of |S|.
 // flip: the projected form's partner sum (flip.py:322-418): sum_{x'} <x|H|x'> eta_m(x') psi(flip x') -- the key y stands for x' = flip(y).
 #include "detcore.h"
 #include "launch.h"
@@ -29,6 +35,10 @@ namespace pynqs {
 #define PYNQS_KEYS_W 4
 #endif
 constexpr int kKeysWalkers = PYNQS_KEYS_W;   // walkers per wave (their 32-bit folds live in scalar registers, the words in LDS)
+#ifndef PYNQS_INDEX_W
+#define PYNQS_INDEX_W 1
+#endif
+constexpr int kIndexWalkers = PYNQS_INDEX_W;  // ... of the INDEXED form: nothing is shared between the walkers of a wave there but the queues
 constexpr uint32_t kKeysQueue = 128;  // < 64 left over + 64 parked by one comparison
 
 // alpha <-> beta occupations exchanged in place; returns true if eta_m = (-1)^(doubly occupied spatial orbitals) is -1 (the same for
@@ -72,13 +82,15 @@ __device__ __forceinline__ uint32_t parity_below(const uint64_t (&x)[LEN], int n
   return c & 1u;
 }
 
-template <int LEN, bool CPLX>
+template <int LEN, bool CPLX, bool INDEXED>
 __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const uint64_t *__restrict__ bra, int64_t nbatch, SDParams p, PlanLayout pl,
                                                                         uint32_t nchunks, int64_t chunk_len, const double *__restrict__ plan,
                                                                         const uint64_t *__restrict__ keys, int64_t nkeys,
+                                                                        const uint64_t *__restrict__ svals, const uint32_t *__restrict__ perm,
                                                                         const double *__restrict__ wf, double *__restrict__ acc,
                                                                         double *__restrict__ psi0, bool flip) {
-  constexpr int W = kKeysWalkers, NW = kBlock / 64;
+  constexpr int W = INDEXED ? kIndexWalkers : kKeysWalkers, NW = kBlock / 64, NB = kIndexBlocks;
+  __shared__ uint32_t rng[INDEXED ? NW : 1][W][NB][2];  // INDEXED: [first, last) of the walker's block value in the block's sorted list
   __shared__ uint64_t xs[NW][W][LEN];
   __shared__ uint8_t occ[NW][W][192];
   __shared__ uint32_t queue[NW][2][kKeysQueue];  // [0]: doubles (popcount(x ^ y) == 4), [1]: singles (== 2)
@@ -110,22 +122,38 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
   __builtin_amdgcn_wave_barrier();
   // <x|H|x> of the wave's walker w, by the whole wave, when (and where) the key equal to x turns up: once per walker over the whole
   // grid -- computed up front in every workgroup it cost sorb 184 (4278 terms per walker) a third of the kernel.
-  // The nocc (nocc + 1) / 2 terms h(p,p), <pq||pq> (q < p) are dealt over the lanes: independent loads, one round trip per 64 terms.
+  // h(p,p) for the occupied p, <pq||pq> for the occupied pairs q < p: lane l keeps the orbitals number l, l + 64, l + 128 of the occupied
+  // list and meets every later orbital p of the list in turn -- p is wave-uniform (its row of the table is one base address), the loads of
+  // successive p are independent, nothing is decoded (round 3; until then the nocc (nocc + 1) / 2 terms were dealt over the lanes by a
+  // triangular-number inversion per term: 2.5 x the time at sorb 184, where this sum was a third of the indexed kernel).
   auto diagonal = [&](int w) -> double {
     const double *__restrict__ D1 = plan + pl.offD1;
     const double *__restrict__ D2 = plan + pl.offD2;
-    double s = 0.0;
     int no = 0;
 #pragma unroll
     for (int i = 0; i < LEN; ++i) no += __popcll(xs[wave][w][i]);
-    const int nterms = no * (no + 1) / 2;
-    for (int t = lane; t < nterms; t += 64) {
-      int a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > t) --a;
-      while ((a + 1) * (a + 2) / 2 <= t) ++a;
-      const int pos = t - a * (a + 1) / 2;
-      const uint32_t pa = occ[wave][w][a];
-      s += pos == 0 ? D1[pa] : D2[pa * (uint32_t)sorb + occ[wave][w][pos - 1]];
+    constexpr int SL = LEN;  // occupied orbitals per lane: no <= 64 LEN
+    uint32_t mine[SL];
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      mine[j] = lane + 64 * j < no ? occ[wave][w][lane + 64 * j] : 0u;
+      if (lane + 64 * j < no) s += D1[mine[j]];
+    }
+    constexpr int DU = 4;  // rows in flight per batch (8 / 16: fewer round trips but 4 / 3 waves per SIMD instead of 5 at three words; slower)
+    for (int a0 = 1; a0 < no; a0 += DU) {
+      double v[DU][SL];
+#pragma unroll
+      for (int u = 0; u < DU; ++u) {
+        const int a = a0 + u;
+        const double *__restrict__ row = D2 + (size_t)occ[wave][w][min(a, no - 1)] * (uint32_t)sorb;  // (one LDS address per wave)
+#pragma unroll
+        for (int j = 0; j < SL; ++j) v[u][j] = a < no && lane + 64 * j < a ? row[mine[j]] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < DU; ++u)
+#pragma unroll
+        for (int j = 0; j < SL; ++j) s += v[u][j];
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
@@ -229,6 +257,115 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
   typedef std::integral_constant<int, 0> Doubles;
   typedef std::integral_constant<int, 1> Singles;
 
+  // one (walker w, x' = y) pair per lane with popcount(x ^ y) = cnt <= 4 somewhere in the wave: the key equal to the walker brings <x|H|x>
+  // and psi(x); doubles and singles are parked
+  auto take = [&](int w, uint32_t minus, int64_t k, const uint64_t (&y)[LEN], bool in, int cnt) {
+    const uint32_t code = ((uint32_t)w << 28) | minus | (uint32_t)k;
+    if (__ballot(in && cnt == 0)) {  // the key equal to the walker itself (keys are distinct: one lane, once per walker and launch)
+      const double hd = diagonal(w);
+      if (in && cnt == 0) {
+        double vr, vi = 0.0;
+        if constexpr (CPLX) { vr = wf[2 * k]; vi = wf[2 * k + 1]; }
+        else vr = wf[k];
+        const double hh = minus ? -hd : hd;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+          if (i == w) {  // (w is wave-uniform)
+            are[i] = fma(hh, vr, are[i]);
+            if constexpr (CPLX) aim[i] = fma(hh, vi, aim[i]);
+          }
+        }
+        if (!flip) {
+          double *__restrict__ out = psi0 + (CPLX ? 2 : 1) * (wbase + w);
+          out[0] = vr;
+          if constexpr (CPLX) out[1] = vi;
+        }
+      }
+    }
+    park(Doubles{}, code, y, in && cnt == 4);
+    park(Singles{}, code, y, in && cnt == 2);
+  };
+
+  if constexpr (INDEXED) {
+    // ---- the walkers' block values looked up: lane t = (walker, block, first / one past last), a binary search each
+    int blo[NB + 1];
+#pragma unroll
+    for (int b = 0; b <= NB; ++b) blo[b] = index_block_lo(sorb, b);
+    if (lane < W * NB * 2) {
+      const int w = lane / (2 * NB), b = (lane >> 1) % NB, upper = lane & 1;
+      uint64_t xw[LEN];
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) xw[i] = xs[wave][w][i];
+      if (flip) (void)spin_flip_ket_keys<LEN>(xw);  // flip(key) agrees with x in a block  <=>  the key agrees with flip(x) in it
+      int lo_bit = 0, hi_bit = 0;
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb)
+        if (bb == b) { lo_bit = blo[bb]; hi_bit = blo[bb + 1]; }
+      const uint64_t v = ((uint64_t)b << kIndexTagShift) | index_block_value<LEN>(xw, lo_bit, hi_bit);
+      const uint64_t *__restrict__ sv = svals + (size_t)b * (size_t)nkeys;
+      int64_t first = 0, n = wbase + w < nbatch ? nkeys : 0;
+      while (n > 0) {  // first position with sv[pos] >= v (upper: > v)
+        const int64_t half = n >> 1;
+        const uint64_t m = sv[first + half];
+        const bool right = upper ? m <= v : m < v;
+        first = right ? first + half + 1 : first;
+        n = right ? n - half - 1 : half;
+      }
+      rng[wave][w][b][upper] = (uint32_t)first;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // block masks (wave-uniform): a candidate found through block b counts only if it disagrees with x in every block before b
+    uint64_t bmask[NB - 1][LEN];
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b)
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) {
+        const int lo = max(blo[b] - 64 * i, 0), hi = min(blo[b + 1] - 64 * i, 64);
+        bmask[b][i] = hi > lo ? ((hi == 64 ? 0ull : (1ull << hi)) - (1ull << lo)) : 0ull;
+      }
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+      if (wbase + w >= nbatch) break;  // (wave-uniform)
+      uint32_t first[NB], off[NB + 1];
+      off[0] = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        first[b] = rng[wave][w][b][0];
+        off[b + 1] = off[b] + (rng[wave][w][b][1] - first[b]);
+      }
+      uint64_t xw[LEN];
+#pragma unroll
+      for (int i = 0; i < LEN; ++i) xw[i] = xs[wave][w][i];
+      for (uint32_t j0 = 0; j0 < off[NB]; j0 += 64) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const bool in = j < off[NB];
+        int b = 0;
+        uint32_t pos = first[0] + j;
+#pragma unroll
+        for (int bb = 1; bb < NB; ++bb)
+          if (j >= off[bb]) { b = bb; pos = first[bb] + (j - off[bb]); }
+        const int64_t k = in ? (int64_t)perm[(size_t)b * (size_t)nkeys + pos] : 0;
+        uint64_t y[LEN];
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) y[i] = in ? keys[k * LEN + i] : 0ull;
+        const uint32_t minus = flip && spin_flip_ket_keys<LEN>(y) ? (1u << 27) : 0u;
+        int cnt = 0;
+        bool counted_before = false;
+        uint64_t d[LEN];
+#pragma unroll
+        for (int i = 0; i < LEN; ++i) { d[i] = xw[i] ^ y[i]; cnt += __popcll(d[i]); }
+#pragma unroll
+        for (int bb = 0; bb < NB - 1; ++bb) {
+          uint64_t any = 0;
+#pragma unroll
+          for (int i = 0; i < LEN; ++i) any |= d[i] & bmask[bb][i];
+          counted_before = counted_before || (bb < b && any == 0);
+        }
+        const bool mine = in && !counted_before && cnt <= 4;
+        if (__ballot(mine)) take(w, minus, k, y, mine, cnt);
+      }
+    }
+  } else {
   // ---- the workgroup's chunk of keys: U keys per lane and step, the next step's keys requested before this step's are compared
   // (a wave alone with one dependent load per step waits an L2 round trip per 64 keys: 0.50 ms for 8192 walkers x 2.8e4 keys)
 #ifndef PYNQS_KEYS_U3
@@ -283,28 +420,11 @@ __global__ __launch_bounds__(kBlock) void eloc_sample_space_keys_kernel(const ui
 #pragma unroll
         for (int i = 0; i < LEN; ++i) cnt += __popcll(xs[wave][w][i] ^ y[u][i]);  // (rare path: the walker's words from LDS, one address per wave)
         if (__ballot(cnt <= 4)) {  // (wave-uniform)
-          const uint32_t code = ((uint32_t)w << 28) | minus | (uint32_t)k;
-          if (__ballot(in && cnt == 0)) {  // the key equal to the walker itself (keys are distinct: one lane, once per walker and launch)
-            const double hd = diagonal(w);
-            if (in && cnt == 0) {
-              double vr, vi = 0.0;
-              if constexpr (CPLX) { vr = wf[2 * k]; vi = wf[2 * k + 1]; }
-              else vr = wf[k];
-              const double hh = minus ? -hd : hd;
-              are[w] = fma(hh, vr, are[w]);
-              if constexpr (CPLX) aim[w] = fma(hh, vi, aim[w]);
-              if (!flip) {
-                double *__restrict__ out = psi0 + (CPLX ? 2 : 1) * (wbase + w);
-                out[0] = vr;
-                if constexpr (CPLX) out[1] = vi;
-              }
-            }
-          }
-          park(Doubles{}, code, y[u], in && cnt == 4);
-          park(Singles{}, code, y[u], in && cnt == 2);
+          take(w, minus, k, y[u], in, cnt);
         }
       }
     }
+  }
   }
   while (cnts[0]) evaluate(Doubles{}, min(cnts[0], 64u));
   while (cnts[1]) evaluate(Singles{}, min(cnts[1], 64u));
@@ -348,10 +468,9 @@ __global__ __launch_bounds__(kBlock) void eloc_divide_keys_kernel(double *__rest
 
 using namespace pynqs;
 
-extern "C" int pynqs_eloc_sample_space_keys(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
-                                            const uint64_t *keys, int64_t nkeys, const double *wf, int wf_is_complex, int flip,
-                                            double *eloc, double *psi0, void *stream) {
-  pynqs::DeviceScope device_scope_(bra);
+static int launch_keys(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan, const uint64_t *keys,
+                       int64_t nkeys, const void *index, const double *wf, int wf_is_complex, int flip, double *eloc, double *psi0,
+                       void *stream) {
   SDParams p;
   PlanLayout pl;
   if (!make_sd_params(sorb, nele, noA, noB, &p)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB");
@@ -361,33 +480,56 @@ extern "C" int pynqs_eloc_sample_space_keys(const uint64_t *bra, int64_t nbatch,
   if (!bra || !plan || !eloc || !psi0 || (nkeys > 0 && (!keys || !wf))) return set_error(PYNQS_EINVAL, "null pointer");
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = wf_is_complex ? 16 : 8;
-  constexpr int kPerGroup = (kBlock / 64) * kKeysWalkers;  // walkers per workgroup
+  const int kPerGroup = (kBlock / 64) * (index ? kIndexWalkers : kKeysWalkers);  // walkers per workgroup
   const int64_t groups = (nbatch + kPerGroup - 1) / kPerGroup;
-  // enough workgroups to fill the chip, chunks of at least 2048 keys
+  // streamed form: enough workgroups to fill the chip, chunks of at least 2048 keys (the indexed form has one workgroup per group)
   static const int64_t want = getenv("PYNQS_KEYS_WG") ? atoll(getenv("PYNQS_KEYS_WG")) : 4096;
-  int64_t nchunks = groups >= want ? 1 : (want + groups - 1) / groups;
+  int64_t nchunks = groups >= want || index ? 1 : (want + groups - 1) / groups;
   const int64_t maxc = (nkeys + 2047) / 2048;
   if (nchunks > maxc) nchunks = maxc;
   if (nchunks < 1) nchunks = 1;
   int64_t chunk_len = (nkeys + nchunks - 1) / nchunks;
   chunk_len = (chunk_len + 63) & ~(int64_t)63;
   if (chunk_len < 64) chunk_len = 64;
-  nchunks = nkeys > 0 ? (nkeys + chunk_len - 1) / chunk_len : 1;
+  nchunks = nkeys > 0 && !index ? (nkeys + chunk_len - 1) / chunk_len : 1;
   const uint64_t grid = (uint64_t)groups * (uint64_t)nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   if (!flip && hipMemsetAsync(psi0, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");  // x not in S: psi(x) = 0
   const int len = (sorb - 1) / 64 + 1;
+  const uint64_t *svals = (const uint64_t *)index;
+  const uint32_t *perm = index ? (const uint32_t *)(svals + (size_t)kIndexBlocks * (size_t)nkeys) : nullptr;
+#define PYNQS_KEYS_LAUNCH(C, I)                                                                                                             \
+  hipLaunchKernelGGL((eloc_sample_space_keys_kernel<LEN, C, I>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, nbatch, p, pl, (uint32_t)nchunks, \
+                     chunk_len, (const double *)plan, keys, nkeys, svals, perm, wf, eloc, psi0, flip != 0)
   DISPATCH_LEN(len, {
-    if (wf_is_complex)
-      hipLaunchKernelGGL((eloc_sample_space_keys_kernel<LEN, true>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, nbatch, p, pl, (uint32_t)nchunks,
-                         chunk_len, (const double *)plan, keys, nkeys, wf, eloc, psi0, flip != 0);
-    else
-      hipLaunchKernelGGL((eloc_sample_space_keys_kernel<LEN, false>), dim3((uint32_t)grid), dim3(kBlock), 0, st, bra, nbatch, p, pl, (uint32_t)nchunks,
-                         chunk_len, (const double *)plan, keys, nkeys, wf, eloc, psi0, flip != 0);
+    if (index) {
+      if (wf_is_complex) PYNQS_KEYS_LAUNCH(true, true);
+      else PYNQS_KEYS_LAUNCH(false, true);
+    } else {
+      if (wf_is_complex) PYNQS_KEYS_LAUNCH(true, false);
+      else PYNQS_KEYS_LAUNCH(false, false);
+    }
   });
+#undef PYNQS_KEYS_LAUNCH
   const uint32_t g2 = (uint32_t)((nbatch + kBlock - 1) / kBlock);
   if (wf_is_complex) hipLaunchKernelGGL((eloc_divide_keys_kernel<true>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
   else hipLaunchKernelGGL((eloc_divide_keys_kernel<false>), dim3(g2), dim3(kBlock), 0, st, eloc, psi0, nbatch);
-  return check_launch("eloc_sample_space_keys");
+  return check_launch(index ? "eloc_sample_space_indexed" : "eloc_sample_space_keys");
+}
+
+extern "C" int pynqs_eloc_sample_space_keys(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                                            const uint64_t *keys, int64_t nkeys, const double *wf, int wf_is_complex, int flip,
+                                            double *eloc, double *psi0, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
+  return launch_keys(bra, nbatch, sorb, nele, noA, noB, plan, keys, nkeys, nullptr, wf, wf_is_complex, flip, eloc, psi0, stream);
+}
+
+extern "C" int pynqs_eloc_sample_space_indexed(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
+                                               const uint64_t *keys, int64_t nkeys, const void *index, const double *wf,
+                                               int wf_is_complex, int flip, double *eloc, double *psi0, void *stream) {
+  pynqs::DeviceScope device_scope_(bra);
+  if (nkeys > 0 && !index) return set_error(PYNQS_EINVAL, "null index");
+  if (nkeys == 0) return launch_keys(bra, nbatch, sorb, nele, noA, noB, plan, keys, nkeys, nullptr, wf, wf_is_complex, flip, eloc, psi0, stream);
+  return launch_keys(bra, nbatch, sorb, nele, noA, noB, plan, keys, nkeys, index, wf, wf_is_complex, flip, eloc, psi0, stream);
 }

@@ -251,11 +251,63 @@ def _key_major(nkeys: int, sorb: int, noa: int, nob: int, probe: Optional[Callab
     return _SS_CHOICE[key]
 
 
+# Key-major, streamed or INDEXED (round 3)?  The index (C_extension.keys_index_build: the keys sorted by each of five blocks of the
+# orbitals) turns "compare with every key" into "compare with the keys that agree with the walker in a whole block": 13 instead of 65 536
+# per walker for a table of samples at sorb 120 / 184 (0.043 / 0.059 ms per 8192 walkers instead of 0.20 / 0.29), but 21.5e3 of 18.5e3 for
+# Fe2S2's CAS-like table, whose members share every block with thousands of others.  Building it costs ~0.06 ms + 1 us per 1000 keys and one
+# host synchronisation, per table: it is bought when the (walker, key) pairs streamed against this table so far would have paid for it
+# (the ski-rental rule: never worse than twice the better choice), and used when it is sparse enough.
+SS_INDEX: Optional[bool] = None  # True / False (or PYNQS_SS_INDEX=1 / 0): always / never; None: the rule above
+SS_INDEX_PAIR_COST = {1: 2.4e-13, 2: 3.7e-13, 3: 5.3e-13}  # seconds per streamed (walker, key) pair, by words per determinant (measured)
+SS_INDEX_CANDIDATE_COST = 6.0e-12  # seconds per (walker, key met through the index)
+
+
+def _keys_index_for(WF_LUT, n: int, sorb: int):
+    """The table's KeysIndex if the INDEXED form should run this call, else None (the streamed form runs and the call is counted)."""
+    import os
+
+    force = SS_INDEX if SS_INDEX is not None else {"1": True, "0": False}.get(os.environ.get("PYNQS_SS_INDEX", ""), None)
+    if force is False or sorb % 2:
+        return None
+    keys = WF_LUT.bra_key
+    nk, words = keys.size(0), (sorb - 1) // 64 + 1
+    cached = getattr(WF_LUT, "_keys_index", None)
+    if cached is not None and (cached.nkeys != nk or cached.index.device != keys.device or getattr(WF_LUT, "_keys_index_of", None) != keys.data_ptr()):
+        cached = None  # (the table was moved or rebuilt)
+    if cached is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None  # (the build synchronises)
+        pairs = getattr(WF_LUT, "_keys_streamed_pairs", 0) + n * nk
+        if force is None and pairs * SS_INDEX_PAIR_COST[words] < 5.5e-5 + 1.1e-9 * nk:
+            try:
+                WF_LUT._keys_streamed_pairs = pairs
+            except AttributeError:  # (a table object that takes no attributes: stay with the streamed form)
+                pass
+            return None
+        cached = CX.keys_index_build(keys, sorb)
+        try:
+            WF_LUT._keys_index, WF_LUT._keys_index_of = cached, keys.data_ptr()
+        except AttributeError:
+            pass
+    if force is None and cached.per_walker * SS_INDEX_CANDIDATE_COST > nk * SS_INDEX_PAIR_COST[words]:
+        return None  # dense: a walker would meet more keys through the index than it is worth
+    return cached
+
+
 def _launch_sample_space(key_major: bool, x, n, sorb, nele, noa, nob, plan, WF_LUT, wf, cplx, flip, eloc, psi0, part, st) -> None:
     lib = N.lib()
     ht = getattr(WF_LUT, "hashtable", None)
     if key_major:
         keys = WF_LUT.bra_key
+        ki = _keys_index_for(WF_LUT, n, sorb)
+        if ki is not None:
+            rc = lib.pynqs_eloc_sample_space_indexed(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0),
+                                                     ki.index.data_ptr(), wf.data_ptr(), int(cplx), 0, eloc.data_ptr(), psi0.data_ptr(), st)
+            if rc == 0 and flip:
+                rc = lib.pynqs_eloc_sample_space_indexed(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0),
+                                                         ki.index.data_ptr(), wf.data_ptr(), int(cplx), 1, part.data_ptr(), psi0.data_ptr(), st)
+            N.check(rc, "pynqs_eloc_sample_space_indexed")
+            return
         rc = lib.pynqs_eloc_sample_space_keys(x.data_ptr(), n, sorb, nele, noa, nob, plan.data_ptr(), keys.data_ptr(), keys.size(0), wf.data_ptr(),
                                               int(cplx), 0, eloc.data_ptr(), psi0.data_ptr(), st)
         if rc == 0 and flip:

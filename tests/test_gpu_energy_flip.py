@@ -216,14 +216,15 @@ def test_spin_raising_matches_reference_python(env, fused):
         energy.FUSED, energy.FUSED_RBM = old
 
 
-@pytest.mark.parametrize("key_major", [True, False])
+@pytest.mark.parametrize("key_major", [True, False, "indexed"])
 def test_sample_space_kernels_key_major_and_column_major(env, key_major):
-    """The two fused SAMPLE_SPACE kernels -- walking the table (pynqs_eloc_sample_space_keys) or the excitation lists
-    (pynqs_eloc_sample_space[_hash][_flip]) -- forced in turn (the energy layer otherwise picks by table size against ncomb):
+    """The fused SAMPLE_SPACE kernels -- walking the table (pynqs_eloc_sample_space_keys: every key; pynqs_eloc_sample_space_indexed: the
+    keys that share a block of orbitals with the walker) or the excitation lists (pynqs_eloc_sample_space[_hash][_flip]) -- forced in
+    turn (the energy layer otherwise picks by table size against ncomb and by the index's density):
     every projected / multi-psi / complex sample-space fixture, <S-S+>, and random 1-3-word systems with and without hits."""
     energy, pf, T, dev = env["energy"], env["pf"], env["T"], env["dev"]
-    old = energy.SS_KEYS
-    energy.SS_KEYS = key_major
+    old = energy.SS_KEYS, energy.SS_INDEX
+    energy.SS_KEYS, energy.SS_INDEX = bool(key_major), key_major == "indexed"
     try:
         for name in ("ss_flip", "ss_flip_c", "ss_multi", "ss_flip_multi", "ss_flip_multi_c"):
             key, dt, kw = CASES[name]
@@ -239,7 +240,7 @@ def test_sample_space_kernels_key_major_and_column_major(env, key_major):
         for args in ((40, 5, 300, True), (72, 6, 200, True), (136, 4, 3000, True), (72, 6, 300, False)):
             test_spin_flip_kernel_all_filter_levels(*args)
     finally:
-        energy.SS_KEYS = old
+        energy.SS_KEYS, energy.SS_INDEX = old
 
 
 def test_key_major_kernel_edge_cases(env):
