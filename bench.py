@@ -295,6 +295,20 @@ class SampleSpaceFused(Workload):
             self.roofline_note = ("key-major kernel: the table is walked instead of the excitation lists (work ~ walkers x keys, not walkers x ncomb); "
                                   "popcount(x ^ key) <= 4 decides per pair, the few keys within a double excitation are evaluated from the bit patterns; "
                                   "bound by vector-ALU instruction issue, HBM traffic negligible")
+        self.index = E_._keys_index_for(self.lut, self.n, sorb) if self.key_major else None  # (the energy layer's own rule, energy.py)
+        if self.index is not None:
+            import time as _t
+
+            torch.cuda.synchronize(dev); t0 = _t.perf_counter()
+            from pynqs_amd import C_extension as CX_
+
+            CX_.keys_index_build(self.lut.bra_key, sorb)
+            self.index_build_ms = (_t.perf_counter() - t0) * 1e3  # once per table, like the hash table of the column-major form; not in the step
+            self.pmc_name = f"{tag}_eloc_sample_space_indexed"
+            self.roofline_note = (f"INDEXED key-major kernel: the keys are indexed by five blocks of the orbitals (built once per table, {self.index_build_ms:.2f} ms incl. "
+                                  f"the host read-back of its density); a walker meets {self.index.per_walker:.1f} of the {self.lut.bra_key.size(0)} keys instead of all of them. "
+                                  "What is left is a chain of dependent memory round trips per walker (17-step binary searches, key -> integral / psi gathers, the "
+                                  "nele (nele + 1) / 2 gathers of <x|H|x>): latency-bound, neither HBM nor vector-ALU issue is near its roof")
         if not self.key_major:
             self.roofline_note = ("filter-first kernel: a column whose Zobrist hash the filter rejects never has its integral gathered; HBM traffic is "
                                   "negligible and the kernel is bound by vector-ALU instruction issue (see valu_instructions_per_launch: ~1.5 wave64 instructions per column incl. the per-walker set-up and the evaluation of the candidates)")
@@ -302,6 +316,11 @@ class SampleSpaceFused(Workload):
 
     def launch_eloc(self, st):
         """the fused SAMPLE_SPACE local energy: key-major or column-major, the choice pynqs_amd.energy.local_energy makes"""
+        if self.index is not None:
+            keys = self.lut.bra_key
+            return self.lib.pynqs_eloc_sample_space_indexed(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB, self.plan.data_ptr(),
+                                                            keys.data_ptr(), keys.size(0), self.index.index.data_ptr(), self.lut.wf_value.data_ptr(), 1, 0,
+                                                            self.eloc.data_ptr(), self.psi0.data_ptr(), st.cuda_stream)
         if self.key_major:
             keys = self.lut.bra_key
             return self.lib.pynqs_eloc_sample_space_keys(self.x.data_ptr(), self.n, self.sorb, self.nele, self.noA, self.noB, self.plan.data_ptr(),
@@ -1042,6 +1061,8 @@ def main():
                     else "synthetic (seeded dense integrals, random walkers)",
             "config": {"workload": wl.name, "sorb": wl.sorb, "nele": wl.nele, "ncomb": wl.ncomb,
                        "walkers_per_gpu": wl.n, "integral_layout": wl.path, "plan_build_ms": wl.plan_build_ms,
+                       **({"keys_index_build_ms": wl.index_build_ms, "keys_met_per_walker": wl.index.per_walker, "keys": wl.index.nkeys}
+                          if getattr(wl, "index", None) is not None else {}),
                        "parallelism": f"walker-sharded x{world} (one process per GPU)" + (
                            ("; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p); gradient estimator: " +
                             ("HIP-graph replay + one RCCL all-reduce of the flat gradient buffer (mean over ranks, as DDP)" if wl.graphed is not None

@@ -35,21 +35,27 @@ __global__ __launch_bounds__(kBlock) void index_block_values_kernel(const uint64
 }
 
 // sum over the runs of equal values of (run length)^2, all blocks together: a key of the table used as a walker finds that many keys
-// through the index, on average sum / nkeys -- against nkeys for the streamed form.  The last element of a run finds the run's start.
+// through the index, on average sum / nkeys -- against nkeys for the streamed form.  The first element of a run measures it: a few steps
+// forward (tables of samples: runs of one or two), a binary search for the end of a long run (CAS-like tables: thousands).
 __global__ __launch_bounds__(kBlock) void index_density_kernel(const uint64_t *__restrict__ svals, int64_t total, unsigned long long *__restrict__ sum) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned long long sq = 0;
   if (i < total) {
     const uint64_t v = svals[i];
-    if (i + 1 == total || svals[i + 1] != v) {
-      int64_t first = 0, n = i;  // first position with svals[pos] >= v, in [0, i]
-      while (n > 0) {
-        const int64_t half = n >> 1;
-        const bool right = svals[first + half] < v;
-        first = right ? first + half + 1 : first;
-        n = right ? n - half - 1 : half;
+    if (i == 0 || svals[i - 1] != v) {
+      int64_t end = i + 1;
+      while (end < total && end < i + 8 && svals[end] == v) ++end;
+      if (end == i + 8 && end < total && svals[end] == v) {  // first position in (end, total] with svals[pos] > v
+        int64_t first = end + 1, n = total - first;
+        while (n > 0) {
+          const int64_t half = n >> 1;
+          const bool right = svals[first + half] <= v;
+          first = right ? first + half + 1 : first;
+          n = right ? n - half - 1 : half;
+        }
+        end = first;
       }
-      const unsigned long long len = (unsigned long long)(i + 1 - first);
+      const unsigned long long len = (unsigned long long)(end - i);
       sq = len * len;
     }
   }
