@@ -487,7 +487,11 @@ class VmcStep(SampleSpaceFused):
         self.phase_events = []
         # gradient estimator: forward + backward replayed from a HIP graph, then ONE RCCL all-reduce of the flat gradient buffer
         # (pynqs_amd.grad.GraphedGrad; mean over the ranks = DistributedDataParallel's convention); --eager-grad: grad() under DDP
-        self.graphed = G.GraphedGrad(m, self.n, sorb, torch.complex128, dev) if graphed else None
+        # the estimator's gradient: for an RBM analytically from the packed walkers (pynqs_rbm_grad; --autograd-grad: the module's forward +
+        # backward replayed from a HIP graph, what any other ansatz gets); either way one all-reduce of the flat gradient buffer
+        self.graphed = (G.FusedRbmGrad(m, sorb) if os.environ.get("PYNQS_BENCH_AUTOGRAD_GRAD") != "1" else
+                        G.GraphedGrad(m, self.n, sorb, torch.complex128, dev)) if graphed else None
+        self.fused_grad = isinstance(self.graphed, G.FusedRbmGrad)
         if self.graphed is not None:
             self.graphed.events = []
 
@@ -503,11 +507,11 @@ class VmcStep(SampleSpaceFused):
 
         self.stats = dist_stats_moments(self.eloc, self.prob, None, get_world_size())
         ev[2].record(st)
-        states = self.cx.onv_to_tensor(self.x, self.sorb)
+        states = None if self.fused_grad else self.cx.onv_to_tensor(self.x, self.sorb)
         for p in self.module.parameters():
             p.grad = None
         if self.graphed is not None:
-            self.loss = self.graphed(states, self.prob, self.eloc, self.stats[0])
+            self.loss = self.graphed(self.x if self.fused_grad else states, self.prob, self.eloc, self.stats[0])
         else:
             self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, torch.complex128, self.micro_batch)
         ev[3].record(st)
@@ -633,9 +637,15 @@ class ReduceVmcStep(Workload):
         self.front = RF.ReduceFrontEnd(self.n, sorb, nele, noA, noB, eps_sample, torch.float64, dev, int(kept_max * 1.25) + 16, int(nu * 1.1) + 1024,
                                        torch.float64, keep_onv=False, want_pm1=not fused_amplitudes)
         self.distinct_calibrated = nu
+        self.from_parents = os.environ.get("PYNQS_BENCH_RBM_FROM_SCRATCH") != "1" and cx.rbm_forward_children_supported(sorb, sorb, "complex")
+        self.psi_u = torch.zeros(self.front.cap_unique, dtype=torch.complex128, device=dev)
         self.seed = 12345
         self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
-        self.graphed = G.GraphedGrad(m, self.n, sorb, torch.complex128, dev) if graphed else None
+        # the estimator's gradient: for an RBM analytically from the packed walkers (pynqs_rbm_grad; --autograd-grad: the module's forward +
+        # backward replayed from a HIP graph, what any other ansatz gets); either way one all-reduce of the flat gradient buffer
+        self.graphed = (G.FusedRbmGrad(m, sorb) if os.environ.get("PYNQS_BENCH_AUTOGRAD_GRAD") != "1" else
+                        G.GraphedGrad(m, self.n, sorb, torch.complex128, dev)) if graphed else None
+        self.fused_grad = isinstance(self.graphed, G.FusedRbmGrad)
         if self.graphed is not None:
             self.graphed.events = []
         self.phase_events = []
@@ -656,7 +666,11 @@ class ReduceVmcStep(Workload):
             # the RBM amplitudes of the distinct x' by one kernel from the packed bits (pynqs_rbm_forward: what energy.local_energy does for an
             # RBM ansatz); all rows: static shape, nothing read back (rows beyond the distinct count are valid and unused)
             m_ = self.module
-            psi_u = self.cx.rbm_forward(fe.uniq_onv, m_.params_weights, m_.params_hidden_bias, m_.params_visible_bias, self.sorb, "complex")
+            if self.from_parents:  # theta(x') from theta(parent walker): 4 updates per hidden unit instead of sorb; only the rows the front end filled
+                psi_u = self.cx.rbm_forward_children(fe.uniq_onv, fe.uniq_parent, self.x, m_.params_weights, m_.params_hidden_bias, m_.params_visible_bias,
+                                                     self.sorb, "complex", count=fe.counters, out=self.psi_u)
+            else:
+                psi_u = self.cx.rbm_forward(fe.uniq_onv, m_.params_weights, m_.params_hidden_bias, m_.params_visible_bias, self.sorb, "complex")
         else:
             with torch.no_grad():
                 psi_u = self.module(fe.uniq_pm1)
@@ -668,11 +682,11 @@ class ReduceVmcStep(Workload):
 
         self.stats = dist_stats_moments(self.eloc, self.prob, None, get_world_size())
         ev[4].record(st)
-        states = self.cx.onv_to_tensor(self.x, self.sorb)
+        states = None if self.fused_grad else self.cx.onv_to_tensor(self.x, self.sorb)
         for p in self.module.parameters():
             p.grad = None
         if self.graphed is not None:
-            self.loss = self.graphed(states, self.prob, self.eloc, self.stats[0])
+            self.loss = self.graphed(self.x if self.fused_grad else states, self.prob, self.eloc, self.stats[0])
         else:
             self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, torch.complex128, self.micro_batch)
         ev[5].record(st)
@@ -895,6 +909,7 @@ def main():
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
     ap.add_argument("--no-comb", action="store_true", help="diagnostic: skip the comb output (Hmat only)")
     ap.add_argument("--eager-grad", action="store_true", help="fe2s2_vmc_step: gradient estimator by grad() under DistributedDataParallel instead of the HIP-graph replay")
+    ap.add_argument("--autograd-grad", action="store_true", help="fe2s2_[reduce_]vmc_step: gradient estimator by the module's forward + backward replayed from a HIP graph instead of the analytic RBM gradient kernel")
     ap.add_argument("--torch-amplitudes", action="store_true", help="fe2s2_reduce_vmc_step: psi on the distinct x' by the PyTorch module instead of the fused RBM forward kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under 'extra'")
@@ -939,6 +954,8 @@ def main():
 
     if args.torch_amplitudes:
         os.environ["PYNQS_BENCH_TORCH_AMPLITUDES"] = "1"
+    if args.autograd_grad:
+        os.environ["PYNQS_BENCH_AUTOGRAD_GRAD"] = "1"
     wl = make_workload(args.workload, args.walkers, rank, dev, args.path, args.keys, not args.eager_grad)
     if args.no_comb:
         wl.comb_ptr = None
@@ -1065,7 +1082,8 @@ def main():
                           if getattr(wl, "index", None) is not None else {}),
                        "parallelism": f"walker-sharded x{world} (one process per GPU)" + (
                            ("; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p); gradient estimator: " +
-                            ("HIP-graph replay + one RCCL all-reduce of the flat gradient buffer (mean over ranks, as DDP)" if wl.graphed is not None
+                            ("analytic RBM gradient kernel (pynqs_rbm_grad) + one RCCL all-reduce of the flat gradient buffer (mean over ranks, as DDP)" if getattr(wl, "fused_grad", False)
+                             else "HIP-graph replay + one RCCL all-reduce of the flat gradient buffer (mean over ranks, as DDP)" if wl.graphed is not None
                              else "DDP bucketed RCCL all-reduce in the last micro-batch's backward"))
                            if isinstance(wl, (VmcStep, ReduceVmcStep)) else "; packed RCCL all-reduce of (sum p E_loc, sum p |E_loc|^2, sum p)" if hasattr(wl, "stats")
                            else "; no data-path collective")},

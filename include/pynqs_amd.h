@@ -360,6 +360,9 @@ typedef struct pynqs_reduce_io {
   void *row_cache;      /* optional, eps_sample > 0: T[nbatch][ncomb] scratch.  The enumeration stores every matrix element there and the
                            draws read the row back (L2) instead of visiting the drawn tiles a second time: worth it when the draws are
                            dense in the row (1000 draws over Fe2S2's 7876 columns hit every tile); leave NULL for long rows */
+  int32_t *uniq_parent; /* optional, [cap_unique]: the walker whose record put the row on the distinct list -- the row is that walker or a
+                           single / double excitation of it, which lets an amplitude with cheap updates start from the walker's
+                           intermediate values (pynqs_rbm_forward_children) */
 } pynqs_reduce_io;
 int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
@@ -379,6 +382,41 @@ int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA, int noB, 
 #define PYNQS_RBM_COMPLEX 4
 int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const double *weights, const double *hidden_bias,
                       const double *visible_bias, int nhidden, int flavour, double *psi, void *stream);
+
+/* ---- the energy-gradient estimator for RBM amplitudes, analytically (kernels_rbm_grad.hip; vmc/grad/energy_grad.py:118-184, "AD" method:
+ *   loss = 2 Re sum_n p_n conj(ln psi(x_n)) (E_loc(x_n) - <E> c_n); the reference calls loss.backward() on it).
+ * For psi = exp(a.x) prod_h 2cosh(theta_h), theta = b + W x (vmc/ansatz/rbm/rbm.py:186-211):
+ *   d loss / d theta_k = 2 Re G_k (real parameters) or (2 Re G_k, -2 Im G_k) for a complex parameter stored as (re, im),
+ *   G_k = sum_n conj(f_n) O_k(x_n),  f_n = p_n (E_loc(x_n) - <E> c_n),  O = (x_o, tanh theta_h, tanh theta_h x_o).
+ *   flavour: PYNQS_RBM_REAL (parameters double[nhidden][sorb], [nhidden], [sorb]) or PYNQS_RBM_COMPLEX (the same with a trailing [2]);
+ *   prob double[n]; eloc double[n] or (eloc_is_complex) double[n][2]; e_total: DEVICE pointer to <E> (1 or 2 doubles, as eloc);
+ *   pow: c_n double[n] (extra_psi_pow) or NULL for 1; visible_bias / grad_visible_bias may be NULL.
+ *   grad_*: same shapes as the parameters (overwritten); loss (may be NULL): the loss above, ln psi on torch.log's principal branch.
+ *   workspace: pynqs_rbm_grad_workspace(n, sorb, nhidden, flavour) bytes.  Sums run in a fixed order: bit-reproducible.               */
+/* ---- RBM amplitudes of the DISTINCT x' of a REDUCE front end, from their parents (kernels_rbm_forward.hip): row r of the distinct list is
+ * walker parent[r] with at most four orbitals flipped, and  prod_h 2cosh(theta_h) = exp(sum_h theta_h) prod_h (1 + q_h),  q_h = exp(-2 theta_h):
+ * flipping orbital o to x'_o = +-1 multiplies q_h by the table entry exp(-+4 W_ho).  A child costs 4 table multiplications per hidden unit:
+ * no exponential, no sine, no loop over the orbitals (Fe2S2, 1.5 M rows x 40 complex hidden units: 0.60 ms from scratch).
+ *   pynqs_rbm_children_table_bytes : [host] size of the table for nwalkers parents (-1 on bad arguments)
+ *   pynqs_rbm_children_prepare     : table <- the parents' q_h, sum_h theta_h, a.x and the parameters' factor table
+ *   pynqs_rbm_forward_children     : psi[r] for r < min(*count_dev, n) (count_dev may be NULL: all n rows; rows past the count are left alone)
+ *   pynqs_rbm_forward_children_supported : 1 if the factor table ((2 sorb + 1) x (nhidden + 2) entries) fits 64 KB of LDS, else 0: the
+ *                                    caller then uses pynqs_rbm_forward
+ * Flavours and parameter layouts as pynqs_rbm_forward; |Re theta_h| must stay below ~350 (exp(-2 theta) is formed).  Values agree with
+ * pynqs_rbm_forward to rounding (typically 1e-14 relative; a factor 2cosh(theta_h) near zero amplifies it).                           */
+int64_t pynqs_rbm_children_table_bytes(int64_t nwalkers, int sorb, int nhidden, int flavour);
+int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalkers, int sorb, const double *weights, const double *hidden_bias,
+                               const double *visible_bias, int nhidden, int flavour, void *table, void *stream);
+int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const int32_t *count_dev, const int32_t *parent,
+                               const uint64_t *walkers, int64_t nwalkers, const void *table, int sorb, int nhidden, int flavour,
+                               double *psi, void *stream);
+int pynqs_rbm_forward_children_supported(int sorb, int nhidden, int flavour);
+
+int64_t pynqs_rbm_grad_workspace(int64_t n, int sorb, int nhidden, int flavour);
+int pynqs_rbm_grad(const uint64_t *onv, int64_t n, int sorb, const double *weights, const double *hidden_bias,
+                   const double *visible_bias, int nhidden, int flavour, const double *prob, const double *eloc,
+                   int eloc_is_complex, const double *e_total, const double *pow, double *grad_weights,
+                   double *grad_hidden_bias, double *grad_visible_bias, double *loss, void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -559,6 +559,55 @@ def rbm_forward(onv: Tensor, weights: Tensor, hidden_bias: Tensor, visible_bias:
     return psi
 
 
+def _rbm_params(weights, hidden_bias, visible_bias, sorb, rbm_type):
+    flav = {"real": N.RBM_REAL, "tanh": N.RBM_TANH, "pRBM": N.RBM_PHASE, "complex": N.RBM_COMPLEX}.get(rbm_type)
+    if flav is None:
+        raise RuntimeError(f"rbm_type {rbm_type!r} has no fused forward")
+    cplx_par = rbm_type == "complex"
+    W = weights.detach().double().contiguous()
+    hb = hidden_bias.detach().double().contiguous()
+    vb = visible_bias.detach().double().contiguous() if visible_bias is not None else None
+    H = W.size(0)
+    if W.shape[:2] != (H, sorb) or W.dim() != (3 if cplx_par else 2) or hb.numel() != H * (2 if cplx_par else 1) or \
+            (vb is not None and vb.numel() != sorb * (2 if cplx_par else 1)):
+        raise RuntimeError("RBM parameter shapes do not match sorb / num_hidden")
+    if not (W.is_cuda and hb.is_cuda and (vb is None or vb.is_cuda)):
+        raise RuntimeError("RBM parameters must be on the GPU")
+    return flav, W, hb, vb, H
+
+
+def rbm_forward_children_supported(sorb: int, num_hidden: int, rbm_type: str = "real") -> bool:
+    flav = {"real": N.RBM_REAL, "tanh": N.RBM_TANH, "pRBM": N.RBM_PHASE, "complex": N.RBM_COMPLEX}.get(rbm_type)
+    return flav is not None and bool(N.lib().pynqs_rbm_forward_children_supported(sorb, num_hidden, flav))
+
+
+def rbm_forward_children(onv: Tensor, parent: Tensor, walkers: Tensor, weights: Tensor, hidden_bias: Tensor, visible_bias: "Tensor | None",
+                         sorb: int, rbm_type: str = "real", count: "Tensor | None" = None, out: "Tensor | None" = None) -> Tensor:
+    """psi of the reference's RBM amplitudes (vmc/ansatz/rbm/rbm.py:186-211) on the DISTINCT x' of a REDUCE front end, each from its parent
+    walker: onv[r] is walkers[parent[r]] with at most four orbitals flipped (ReduceFrontEnd.uniq_onv / .uniq_parent), so the factors
+    1 + exp(-2 theta_h(x')) follow from the walker's by 4 table multiplications per hidden unit -- no exponential, no loop over the orbitals
+    (pynqs_rbm_children_prepare on the walkers + pynqs_rbm_forward_children).  count: int32 device tensor whose
+    first element is the number of valid rows (the front end's counters; rows past it are not computed), or None for all rows."""
+    _check_onv(onv, "onv", sorb, (2,))
+    _check_onv(walkers, "walkers", sorb, (2,))
+    flav, W, hb, vb, H = _rbm_params(weights, hidden_bias, visible_bias, sorb, rbm_type)
+    dev = onv.device
+    if not (onv.is_cuda and walkers.device == dev and parent.device == dev and parent.dtype == torch.int32 and parent.numel() >= onv.size(0)):
+        raise RuntimeError("rbm_forward_children: onv, walkers and parent (int32) on one GPU")
+    n, nw = onv.size(0), walkers.size(0)
+    nbytes = N.lib().pynqs_rbm_children_table_bytes(nw, sorb, H, flav)
+    table = torch.empty(max(nbytes // 8, 1), dtype=torch.float64, device=dev)
+    st = _stream(dev)
+    wk = walkers.contiguous()
+    N.check(N.lib().pynqs_rbm_children_prepare(wk.data_ptr(), nw, sorb, W.data_ptr(), hb.data_ptr(), vb.data_ptr() if vb is not None else None,
+                                               H, flav, table.data_ptr(), st), "pynqs_rbm_children_prepare")
+    out_c = rbm_type in ("pRBM", "complex")
+    psi = out if out is not None else torch.empty(n, dtype=torch.complex128 if out_c else torch.float64, device=dev)
+    N.check(N.lib().pynqs_rbm_forward_children(onv.contiguous().data_ptr(), n, count.data_ptr() if count is not None else None, parent.data_ptr(),
+                                               wk.data_ptr(), nw, table.data_ptr(), sorb, H, flav, psi.data_ptr(), st), "pynqs_rbm_forward_children")
+    return psi
+
+
 class CRBMTable:
     """Device-resident re-layout of an RBM with COMPLEX parameters for the fused SIMPLE local energy (pynqs_crbm_table_build;
     rbm.py:199-211, rbm_type "complex").  weights [num_hidden, sorb], hidden_bias [num_hidden], visible_bias [sorb] or None:

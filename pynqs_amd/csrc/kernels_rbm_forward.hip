@@ -18,36 +18,11 @@
 // 1.6 M determinants with 40 complex hidden units.
 #include "detcore.h"
 #include "launch.h"
+#include "rbm_math.h"
 
 namespace pynqs {
 
 constexpr int kHChunk = 8;
-
-template <int LEN>
-__device__ __forceinline__ double pm1_of(const uint64_t (&ket)[LEN], int o) {
-  // +1.0 / -1.0 from the occupation bit: only the sign bit of the double differs
-  const uint32_t bit = (uint32_t)(ket[o >> 6] >> (o & 63)) & 1u;
-  const uint64_t u = 0x3ff0000000000000ull | ((uint64_t)(bit ^ 1u) << 63);
-  return __longlong_as_double((long long)u);
-}
-
-// x = k pi/2 + r by two fmas (pi/2 split in two doubles), then the fdlibm kernels on |r| <= pi/4: the arguments here are sums of a few
-// dozen parameters, far from the library sincos' large-argument path
-__device__ __forceinline__ void sincos_mod(double x, double &sn, double &cs) {
-  const double k = rint(x * 0.63661977236758134308);  // 2 / pi
-  double r = fma(-k, 1.57079632679489655800e+00, x);
-  r = fma(-k, 6.12323399573676603587e-17, r);
-  const double z = r * r;
-  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
-  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                                     2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
-  const double s0 = fma(r * z, ps, r), c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
-  const int q = (int)k;
-  const double a = (q & 1) ? c0 : s0, b = (q & 1) ? s0 : c0;
-  sn = (q & 2) ? -a : a;
-  cs = ((q + 1) & 2) ? -b : b;
-}
 
 // running product of the bounded factors with its binary exponent split off (renormalised by the caller every few factors)
 struct Prod {
@@ -60,7 +35,47 @@ struct Prod {
     re = ldexp(re, -k); im = ldexp(im, -k);
     e2 += k;
   }
+  // *= 2cosh(x + iy) = e^{s(x + iy)} (1 + e^{-2s(x + iy)}),  s = sign(x)
+  template <bool CPLX>
+  __device__ __forceinline__ void times_2cosh(double x, double y) {
+    const double ax = fabs(x);
+    const double rho = exp(-2.0 * ax);
+    lin += ax;
+    if constexpr (CPLX) {
+      const double sy = x < 0.0 ? -y : y;
+      double sn, cs;
+      sincos_mod(-2.0 * sy, sn, cs);
+      const double u = fma(rho, cs, 1.0), v = rho * sn;
+      const double nr = re * u - im * v;
+      im = fma(re, v, im * u);
+      re = nr;
+      ang += sy;
+    } else {
+      re *= 1.0 + rho;
+    }
+  }
 };
+
+// psi from the product of the hidden units' factors and a.x = axr + i axi
+template <int FLAVOUR>
+__device__ __forceinline__ void write_psi(double *__restrict__ psi, int64_t i, const Prod &P, double axr, double axi) {
+  const double kLn2 = 0.693147180559945309417;
+  if constexpr (FLAVOUR == PYNQS_RBM_REAL) {
+    psi[i] = P.re * exp(axr + P.lin + kLn2 * (double)P.e2);
+  } else if constexpr (FLAVOUR == PYNQS_RBM_TANH) {
+    psi[i] = tanh(axr) * P.re * exp(P.lin + kLn2 * (double)P.e2);
+  } else if constexpr (FLAVOUR == PYNQS_RBM_PHASE) {
+    double sn, cs;
+    sincos(axr + P.lin + log(P.re) + kLn2 * (double)P.e2, &sn, &cs);  // (the phase IS the logarithm of the real flavour's amplitude)
+    psi[2 * i] = cs; psi[2 * i + 1] = sn;
+  } else {
+    const double m = exp(axr + P.lin + kLn2 * (double)P.e2);
+    double sn, cs;
+    sincos(axi + P.ang, &sn, &cs);
+    psi[2 * i] = m * (P.re * cs - P.im * sn);
+    psi[2 * i + 1] = m * (P.re * sn + P.im * cs);
+  }
+}
 
 template <int LEN, int FLAVOUR>
 __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__restrict__ onv, int64_t n, int sorb, int H,
@@ -95,26 +110,8 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__r
       }
     }
 #pragma unroll
-    for (int j = 0; j < kHChunk; ++j) {
-      if (h0 + j < H) {
-        // 2cosh(x + iy) = e^{s(x + iy)} (1 + e^{-2s(x + iy)}),  s = sign(x)
-        const double ax = fabs(tr[j]);
-        const double rho = exp(-2.0 * ax);
-        P.lin += ax;
-        if constexpr (CPLX) {
-          const double sy = tr[j] < 0.0 ? -ti[j] : ti[j];
-          double sn, cs;
-          sincos_mod(-2.0 * sy, sn, cs);
-          const double u = fma(rho, cs, 1.0), v = rho * sn;
-          const double nr = P.re * u - P.im * v;
-          P.im = fma(P.re, v, P.im * u);
-          P.re = nr;
-          P.ang += sy;
-        } else {
-          P.re *= 1.0 + rho;
-        }
-      }
-    }
+    for (int j = 0; j < kHChunk; ++j)
+      if (h0 + j < H) P.template times_2cosh<CPLX>(tr[j], ti[j]);
     P.renorm();
   }
   double axr = 0.0, axi = 0.0;
@@ -126,21 +123,199 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__r
     }
   }
   if (i >= n) return;
-  const double kLn2 = 0.693147180559945309417;
-  if constexpr (FLAVOUR == PYNQS_RBM_REAL) {
-    psi[i] = P.re * exp(axr + P.lin + kLn2 * (double)P.e2);
-  } else if constexpr (FLAVOUR == PYNQS_RBM_TANH) {
-    psi[i] = tanh(axr) * P.re * exp(P.lin + kLn2 * (double)P.e2);
-  } else if constexpr (FLAVOUR == PYNQS_RBM_PHASE) {
-    double sn, cs;
-    sincos(axr + P.lin + log(P.re) + kLn2 * (double)P.e2, &sn, &cs);  // (the phase IS the logarithm of the real flavour's amplitude)
-    psi[2 * i] = cs; psi[2 * i + 1] = sn;
-  } else {
-    const double m = exp(axr + P.lin + kLn2 * (double)P.e2);
-    double sn, cs;
-    sincos(axi + P.ang, &sn, &cs);
-    psi[2 * i] = m * (P.re * cs - P.im * sn);
-    psi[2 * i + 1] = m * (P.re * sn + P.im * cs);
+  write_psi<FLAVOUR>(psi, i, P, axr, axi);
+}
+
+// ---- psi on the distinct x' of a REDUCE front end, each from its parent walker -----------------------------------------------------
+// x' = x with <= 4 orbitals flipped, and   prod_h 2cosh(theta_h) = exp(sum_h theta_h) prod_h (1 + q_h),   q_h = exp(-2 theta_h).
+// Flipping orbital o to x'_o = +-1 changes theta_h by +-2 W_ho:  q_h *= exp(-+4 W_ho),  sum_h theta_h += +-2 sum_h W_ho,  a.x += +-2 a_o.
+// So a child costs, per hidden unit, 4 (complex) multiplications by table entries and one by (1 + q): no exponential, no sine, no loop over
+// the orbitals.  The table (caller-owned, pynqs_rbm_children_table_bytes) holds
+//   parents [nwalkers][H + 2] : q_h(x) for h < H, then sum_h theta_h(x), then a.x
+//   factors [2 sorb + 1][HP]  : row 2 o (x'_o = +1) / 2 o + 1 (x'_o = -1): exp(-+4 W_ho) for h < H, +-2 sum_h W_ho, +-2 a_o;
+//                               the last row (1, ..., 1, 0, 0) stands for "no flip"; HP = H + 2 made odd (rows start in different banks)
+// all entries real or (re, im) by the flavour.  |Re theta| must stay below ~350 (exp(-2 theta) is formed, not exp(-2 |theta|)).
+__host__ __device__ inline int children_hp(int H) { return (H + 2) | 1; }
+
+template <bool CPLX>
+__global__ __launch_bounds__(kBlock) void rbm_children_factors_kernel(int sorb, int H, const double *__restrict__ W, const double *__restrict__ vb,
+                                                                      double *__restrict__ factors) {
+  constexpr int C = CPLX ? 2 : 1;
+  const int HP = children_hp(H);
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (2 * sorb + 1) * HP) return;
+  const int row = idx / HP, h = idx - row * HP, o = row >> 1;
+  const double sign = (row & 1) ? -1.0 : 1.0;  // x'_o
+  double re = 0.0, im = 0.0;
+  if (row == 2 * sorb) {
+    re = h < H ? 1.0 : 0.0;
+  } else if (h < H) {
+    const double wr = W[((size_t)h * sorb + o) * C], wi = CPLX ? W[((size_t)h * sorb + o) * C + 1] : 0.0;
+    const double m = exp(-4.0 * sign * wr);
+    if constexpr (CPLX) {
+      double sn, cs;
+      sincos(-4.0 * sign * wi, &sn, &cs);
+      re = m * cs; im = m * sn;
+    } else {
+      re = m;
+    }
+  } else if (h == H) {
+    for (int k = 0; k < H; ++k) {
+      re += W[((size_t)k * sorb + o) * C];
+      if constexpr (CPLX) im += W[((size_t)k * sorb + o) * C + 1];
+    }
+    re *= 2.0 * sign; im *= 2.0 * sign;
+  } else if (h == H + 1 && vb) {
+    re = 2.0 * sign * vb[(size_t)o * C];
+    if constexpr (CPLX) im = 2.0 * sign * vb[(size_t)o * C + 1];
+  }
+  factors[(size_t)idx * C] = re;
+  if constexpr (CPLX) factors[(size_t)idx * C + 1] = im;
+}
+
+template <int LEN, bool CPLX>
+__global__ __launch_bounds__(kBlock) void rbm_children_parents_kernel(const uint64_t *__restrict__ onv, int64_t n, int sorb, int H,
+                                                                      const double *__restrict__ W, const double *__restrict__ hb,
+                                                                      const double *__restrict__ vb, double *__restrict__ table) {
+  constexpr int C = CPLX ? 2 : 1;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t row = i < n ? i : n - 1;
+  uint64_t ket[LEN];
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) ket[w] = onv[row * LEN + w];
+  double *__restrict__ out = table + (size_t)row * (size_t)(H + 2) * C;
+  double sr = 0.0, si = 0.0;
+  for (int h0 = 0; h0 < H; h0 += kHChunk) {
+    double tr[kHChunk], ti[kHChunk];
+#pragma unroll
+    for (int j = 0; j < kHChunk; ++j) {
+      const int h = min(h0 + j, H - 1);
+      tr[j] = CPLX ? hb[2 * h] : hb[h];
+      ti[j] = CPLX ? hb[2 * h + 1] : 0.0;
+    }
+    for (int o = 0; o < sorb; ++o) {
+      const double x = pm1_of<LEN>(ket, o);
+#pragma unroll
+      for (int j = 0; j < kHChunk; ++j) {
+        const int h = min(h0 + j, H - 1);  // (wave-uniform address: a scalar load)
+        tr[j] = fma(x, W[((size_t)h * sorb + o) * C], tr[j]);
+        if constexpr (CPLX) ti[j] = fma(x, W[((size_t)h * sorb + o) * C + 1], ti[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kHChunk; ++j) {
+      if (h0 + j < H && i < n) {
+        sr += tr[j]; si += ti[j];
+        const double m = exp(-2.0 * tr[j]);
+        if constexpr (CPLX) {
+          double sn, cs;
+          sincos_mod(-2.0 * ti[j], sn, cs);
+          out[(size_t)(h0 + j) * 2] = m * cs;
+          out[(size_t)(h0 + j) * 2 + 1] = m * sn;
+        } else {
+          out[h0 + j] = m;
+        }
+      }
+    }
+  }
+  double axr = 0.0, axi = 0.0;
+  if (vb) {
+    for (int o = 0; o < sorb; ++o) {
+      const double x = pm1_of<LEN>(ket, o);
+      axr = fma(x, vb[(size_t)o * C], axr);
+      if constexpr (CPLX) axi = fma(x, vb[(size_t)o * C + 1], axi);
+    }
+  }
+  if (i >= n) return;
+  out[(size_t)H * C] = sr;
+  out[(size_t)(H + 1) * C] = axr;
+  if constexpr (CPLX) { out[(size_t)H * C + 1] = si; out[(size_t)(H + 1) * C + 1] = axi; }
+}
+
+template <int LEN, int FLAVOUR>
+__global__ __launch_bounds__(kBlock) void rbm_forward_children_kernel(const uint64_t *__restrict__ onv, int64_t n, const int32_t *__restrict__ count_dev,
+                                                                      const int32_t *__restrict__ parent, const uint64_t *__restrict__ walkers,
+                                                                      int64_t nwalkers, const double *__restrict__ table,
+                                                                      const double *__restrict__ factors, int sorb, int H, double *__restrict__ psi) {
+  constexpr bool CPLX = FLAVOUR == PYNQS_RBM_COMPLEX;
+  constexpr int C = CPLX ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) double wl[];
+  const int HP = children_hp(H);
+  for (int idx = threadIdx.x; idx < (2 * sorb + 1) * HP * C; idx += kBlock) wl[idx] = factors[idx];
+  __syncthreads();
+  int64_t cnt = n;
+  if (count_dev) cnt = min((int64_t)max(*count_dev, 0), n);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * kBlock) {
+    int64_t p = parent[i];
+    p = p < 0 || p >= nwalkers ? 0 : p;
+    // the rows of the factor table for the flipped orbitals ("no flip" for the unused slots)
+    int at[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) at[q] = 2 * sorb * HP;
+    int k = 0;
+#pragma unroll
+    for (int w = 0; w < LEN; ++w) {
+      const uint64_t xc = onv[i * LEN + w];
+      uint64_t d = xc ^ walkers[p * LEN + w];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (d && k < 4) {
+          const int b = __builtin_ctzll(d);
+          d &= d - 1;
+          const int r = (2 * (64 * w + b) + (((xc >> b) & 1ull) ? 0 : 1)) * HP;
+          // (k is a small per-lane counter: the slots are selected, not indexed)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == k) at[q] = r;
+          ++k;
+        }
+      }
+    }
+    const double *__restrict__ tp = table + (size_t)p * (size_t)(H + 2) * C;
+    Prod P;
+    for (int h0 = 0; h0 < H; h0 += kHChunk) {
+#pragma unroll
+      for (int j = 0; j < kHChunk; ++j) {
+        const int h = h0 + j;
+        if (h < H) {
+          double qr = tp[(size_t)h * C], qi = CPLX ? tp[(size_t)h * C + 1] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double fr = wl[(size_t)(at[q] + h) * C];
+            if constexpr (CPLX) {
+              const double fi = wl[(size_t)(at[q] + h) * C + 1];
+              const double nr = qr * fr - qi * fi;
+              qi = fma(qr, fi, qi * fr);
+              qr = nr;
+            } else {
+              qr *= fr;
+            }
+          }
+          if constexpr (CPLX) {  // P *= 1 + q
+            const double u = 1.0 + qr;
+            const double nr = P.re * u - P.im * qi;
+            P.im = fma(P.re, qi, P.im * u);
+            P.re = nr;
+          } else {
+            P.re *= 1.0 + qr;
+          }
+        }
+      }
+      P.renorm();
+    }
+    double axr = tp[(size_t)(H + 1) * C], axi = CPLX ? tp[(size_t)(H + 1) * C + 1] : 0.0;
+    P.lin = tp[(size_t)H * C];
+    P.ang = CPLX ? tp[(size_t)H * C + 1] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      P.lin += wl[(size_t)(at[q] + H) * C];
+      axr += wl[(size_t)(at[q] + H + 1) * C];
+      if constexpr (CPLX) {
+        P.ang += wl[(size_t)(at[q] + H) * C + 1];
+        axi += wl[(size_t)(at[q] + H + 1) * C + 1];
+      }
+    }
+    write_psi<FLAVOUR>(psi, i, P, axr, axi);
   }
 }
 
@@ -170,4 +345,81 @@ extern "C" int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const
   });
 #undef PYNQS_RF
   return check_launch("rbm_forward");
+}
+
+static size_t children_lds_bytes(int sorb, int nhidden, int flavour) {
+  return (size_t)(2 * sorb + 1) * (size_t)children_hp(nhidden) * (flavour == PYNQS_RBM_COMPLEX ? 16 : 8);
+}
+
+static bool children_flavour_ok(int flavour) {
+  return flavour == PYNQS_RBM_REAL || flavour == PYNQS_RBM_TANH || flavour == PYNQS_RBM_PHASE || flavour == PYNQS_RBM_COMPLEX;
+}
+
+extern "C" int pynqs_rbm_forward_children_supported(int sorb, int nhidden, int flavour) {
+  if (sorb < 1 || sorb > kMaxSorb || nhidden < 1 || !children_flavour_ok(flavour)) return 0;
+  return children_lds_bytes(sorb, nhidden, flavour) <= 64 * 1024 ? 1 : 0;
+}
+
+extern "C" int64_t pynqs_rbm_children_table_bytes(int64_t nwalkers, int sorb, int nhidden, int flavour) {
+  if (nwalkers < 0 || sorb < 1 || sorb > kMaxSorb || nhidden < 1 || !children_flavour_ok(flavour)) return -1;
+  const int64_t c = flavour == PYNQS_RBM_COMPLEX ? 16 : 8;
+  return nwalkers * (nhidden + 2) * c + (int64_t)children_lds_bytes(sorb, nhidden, flavour);
+}
+
+extern "C" int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalkers, int sorb, const double *weights, const double *hidden_bias,
+                                          const double *visible_bias, int nhidden, int flavour, void *table, void *stream) {
+  pynqs::DeviceScope device_scope_(table);
+  if (nwalkers < 0 || nwalkers > 0x7fffffffll * kBlock || sorb < 1 || sorb > kMaxSorb || nhidden < 1 || !children_flavour_ok(flavour))
+    return set_error(PYNQS_EINVAL, "bad nwalkers/sorb/nhidden/flavour");
+  if (!weights || !hidden_bias || !table || (nwalkers > 0 && !walkers)) return set_error(PYNQS_EINVAL, "null pointer");
+  const bool cplx = flavour == PYNQS_RBM_COMPLEX;
+  const int len = (sorb - 1) / 64 + 1;
+  hipStream_t st = (hipStream_t)stream;
+  double *parents = (double *)table;
+  double *factors = parents + (size_t)nwalkers * (size_t)(nhidden + 2) * (cplx ? 2 : 1);
+  const uint32_t gf = (uint32_t)(((2 * sorb + 1) * children_hp(nhidden) + kBlock - 1) / kBlock);
+  if (cplx) hipLaunchKernelGGL((rbm_children_factors_kernel<true>), dim3(gf), dim3(kBlock), 0, st, sorb, nhidden, weights, visible_bias, factors);
+  else hipLaunchKernelGGL((rbm_children_factors_kernel<false>), dim3(gf), dim3(kBlock), 0, st, sorb, nhidden, weights, visible_bias, factors);
+  if (nwalkers > 0) {
+    const uint32_t grid = (uint32_t)((nwalkers + kBlock - 1) / kBlock);
+    DISPATCH_LEN(len, {
+      if (cplx)
+        hipLaunchKernelGGL((rbm_children_parents_kernel<LEN, true>), dim3(grid), dim3(kBlock), 0, st, walkers, nwalkers, sorb, nhidden, weights,
+                           hidden_bias, visible_bias, parents);
+      else
+        hipLaunchKernelGGL((rbm_children_parents_kernel<LEN, false>), dim3(grid), dim3(kBlock), 0, st, walkers, nwalkers, sorb, nhidden, weights,
+                           hidden_bias, visible_bias, parents);
+    });
+  }
+  return check_launch("rbm_children_prepare");
+}
+
+extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const int32_t *count_dev, const int32_t *parent,
+                                          const uint64_t *walkers, int64_t nwalkers, const void *table, int sorb, int nhidden, int flavour,
+                                          double *psi, void *stream) {
+  pynqs::DeviceScope device_scope_(onv);
+  if (n < 0 || n > 0x7fffffffll * kBlock || nwalkers < 0 || sorb < 1 || sorb > kMaxSorb || nhidden < 1) return set_error(PYNQS_EINVAL, "bad n/sorb/nhidden");
+  if (!pynqs_rbm_forward_children_supported(sorb, nhidden, flavour))
+    return set_error(PYNQS_EINVAL, "rbm_forward_children: unsupported (bad flavour, or the factor table exceeds the LDS: use pynqs_rbm_forward)");
+  if (n == 0) return PYNQS_OK;
+  if (!onv || !parent || !walkers || !table || !psi || nwalkers == 0) return set_error(PYNQS_EINVAL, "null pointer");
+  const int len = (sorb - 1) / 64 + 1;
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;  // (a workgroup copies the factor table once and strides over the rows)
+  const uint32_t grid = (uint32_t)blocks;
+  const size_t lds = children_lds_bytes(sorb, nhidden, flavour);
+  const double *parents = (const double *)table;
+  const double *factors = parents + (size_t)nwalkers * (size_t)(nhidden + 2) * (flavour == PYNQS_RBM_COMPLEX ? 2 : 1);
+  hipStream_t st = (hipStream_t)stream;
+#define PYNQS_RC(F) hipLaunchKernelGGL((rbm_forward_children_kernel<LEN, F>), dim3(grid), dim3(kBlock), lds, st, onv, n, count_dev, parent, walkers, nwalkers, parents, factors, sorb, nhidden, psi)
+  DISPATCH_LEN(len, {
+    switch (flavour) {
+      case PYNQS_RBM_REAL: PYNQS_RC(PYNQS_RBM_REAL); break;
+      case PYNQS_RBM_TANH: PYNQS_RC(PYNQS_RBM_TANH); break;
+      case PYNQS_RBM_PHASE: PYNQS_RC(PYNQS_RBM_PHASE); break;
+      default: PYNQS_RC(PYNQS_RBM_COMPLEX); break;
+    }
+  });
+#undef PYNQS_RC
+  return check_launch("rbm_forward_children");
 }

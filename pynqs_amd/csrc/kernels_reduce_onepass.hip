@@ -84,6 +84,8 @@ struct OnepassOut {
   uint32_t cap_d, fixed;
   const uint64_t *seed_dev;
   T *row_cache;    // [nbatch][ncomb] or NULL
+  int32_t *uniq_parent;  // [ucap] or NULL: the walker whose record put the row on the distinct list (x' is a single / double excitation of it)
+  int32_t parent;        // this workgroup's walker (set by the kernel)
   uint32_t debug;  // PYNQS_OP_DEBUG ablations (timing only): 1 no amplitude source, 2 no +-1 rows, 4 no look-back
 };
 
@@ -198,6 +200,7 @@ __device__ __forceinline__ bool assign_row(const OnepassOut<T> &o, uint32_t s, i
   reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN))[dedup_row_offset(LEN)] = r;
 #pragma unroll
   for (int i = 0; i < LEN; ++i) o.uniq_onv[(size_t)r * LEN + i] = ket[i];
+  if (o.uniq_parent) o.uniq_parent[r] = o.parent;
   return true;
 }
 
@@ -624,6 +627,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
   uint64_t walker;
   uint32_t chunk;
   map_workgroup(nchunks, false, walker, chunk);
+  o.parent = (int32_t)walker;
   const uint64_t slot = walker * nchunks + chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t seg_base = (int64_t)slot * ((int64_t)o.fixed + o.cap_d);
@@ -1027,6 +1031,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   uint64_t walker;
   uint32_t chunk;
   map_workgroup(nchunks, false, walker, chunk);
+  o.parent = (int32_t)walker;
   const uint64_t slot = walker * nchunks + chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P)
@@ -1420,6 +1425,7 @@ static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed
   o.srec_col = io->srec_col; o.srec_w = (T *)io->srec_w; o.srec_onv = io->srec_onv; o.srec_link = io->srec_link; o.row_sum = io->row_sum;
   o.dedup = (uint64_t *)io->dedup_table; o.dedup_mask = (uint32_t)(io->dedup_slots - 1);
   o.lut = (const uint64_t *)io->lut_table; o.lut_cap = io->lut_table ? hash_capacity(io->lut_nkeys) : 0;
+  o.uniq_parent = io->uniq_parent; o.parent = 0;
   o.uniq_onv = io->uniq_onv; o.uniq_pm1 = io->uniq_pm1; o.pm1_f32 = io->pm1_dtype == PYNQS_F32; o.ucap = (uint32_t)io->cap_unique;
   o.counters = io->counters; o.cap_d = (uint32_t)io->cap_doubles; o.fixed = fixed;
   static const uint32_t dbg = getenv("PYNQS_OP_DEBUG") ? (uint32_t)atoi(getenv("PYNQS_OP_DEBUG")) : 0u;

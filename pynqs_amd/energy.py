@@ -257,6 +257,7 @@ def _key_major(nkeys: int, sorb: int, noa: int, nob: int, probe: Optional[Callab
 # Fe2S2's CAS-like table, whose members share every block with thousands of others.  Building it costs ~0.06 ms + 1 us per 1000 keys and one
 # host synchronisation, per table: it is bought when the (walker, key) pairs streamed against this table so far would have paid for it
 # (the ski-rental rule: never worse than twice the better choice), and used when it is sparse enough.
+RBM_FROM_PARENTS = True  # REDUCE with an RBM ansatz: psi(x') of the distinct x' from theta(parent walker) (pynqs_rbm_forward_children)
 SS_INDEX: Optional[bool] = None  # True / False (or PYNQS_SS_INDEX=1 / 0): always / never; None: the rule above
 SS_INDEX_PAIR_COST = {1: 2.4e-13, 2: 3.7e-13, 3: 5.3e-13}  # seconds per streamed (walker, key) pair, by words per determinant (measured)
 SS_INDEX_CANDIDATE_COST = 6.0e-12  # seconds per (walker, key met through the index)
@@ -706,12 +707,19 @@ def local_energy(
                 """psi on the distinct x' by one kernel when the ansatz is an RBM of the reference's family (pynqs_rbm_forward), else None"""
                 if not rbm_fwd:
                     return None
+                def fwd(W, hb, vb, kind):
+                    # every distinct x' is its parent walker with <= 4 orbitals flipped (the front end notes the parent): theta(x') from
+                    # theta(x) by 4 updates per hidden unit when the parameters fit the LDS, else from scratch
+                    if RBM_FROM_PARENTS and CX.rbm_forward_children_supported(sorb, W.size(0), kind):
+                        return CX.rbm_forward_children(uniq, fe.uniq_parent, x, W, hb, vb, sorb, kind)
+                    return CX.rbm_forward(uniq, W, hb, vb, sorb, kind)
+
                 prm = _real_rbm_params(ansatz)
                 if prm is not None and (dtype.is_complex == (prm[3] == "pRBM")):
-                    return CX.rbm_forward(uniq, prm[0], prm[1], prm[2], sorb, prm[3]).to(dtype)
+                    return fwd(prm[0], prm[1], prm[2], prm[3]).to(dtype)
                 cprm = _complex_rbm_params(ansatz)
                 if cprm is not None and not cprm[4] and dtype.is_complex:
-                    return CX.rbm_forward(uniq, cprm[0], cprm[1], cprm[2], sorb, "complex").to(dtype)
+                    return fwd(cprm[0], cprm[1], cprm[2], "complex").to(dtype)
                 return None
 
             psi_u = rbm_on_distinct()

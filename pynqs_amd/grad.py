@@ -148,3 +148,81 @@ class GraphedGrad:
         for p, v in zip(self.params, self.views):
             p.grad = v
         return all_reduce_packed([self.loss], ws)[0]
+
+
+class FusedRbmGrad:
+    """The estimator of grad() for the reference's RBM amplitudes (vmc/ansatz/rbm/rbm.py:186-211), analytically from the packed
+    determinants: ONE kernel pair (pynqs_rbm_grad) instead of the forward + backward of the module -- d loss / d theta_k = 2 Re G_k
+    (complex parameters stored as (re, im): (2 Re G_k, -2 Im G_k)), G_k = sum_n conj(p_n (E_loc,n - <E> c_n)) O_k(x_n), O = d ln psi / d theta
+    = (x_o, tanh theta_h, tanh theta_h x_o).  Same calling convention and the same cross-rank reduction as GraphedGrad (one all-reduce of the
+    flat gradient buffer, mean over the ranks; every p.grad is a view into it), but the walkers come as packed onv (uint8 [n, 8 len]) and
+    nothing has a fixed shape.  Modules: pynqs_amd.rbm.RealRBM with rbm_type "real", pynqs_amd.rbm.ComplexRBM (anything else: ValueError --
+    use grad() / GraphedGrad).  The sums run in a fixed order: the gradient is bit-reproducible."""
+
+    def __init__(self, nqs: nn.Module, sorb: int) -> None:
+        from . import _native as N
+        from .rbm import ComplexRBM, RealRBM
+
+        m = getattr(nqs, "module", nqs)
+        if isinstance(m, ComplexRBM):
+            self.flavour, self.names = N.RBM_COMPLEX, ("params_weights", "params_hidden_bias", "params_visible_bias")
+        elif isinstance(m, RealRBM) and getattr(m, "rbm_type", "real") == "real":
+            self.flavour, self.names = N.RBM_REAL, ("weights", "hidden_bias", "visible_bias")
+        else:
+            raise ValueError("FusedRbmGrad: the module is not a real (rbm_type 'real') or complex-parameter RBM")
+        self.N, self.module, self.sorb = N, m, sorb
+        self.params = [getattr(m, nm) for nm in self.names]
+        if any(p.dtype != torch.float64 or not p.is_cuda for p in self.params):
+            raise ValueError("FusedRbmGrad: float64 parameters on the GPU")
+        dev = self.params[0].device
+        self.H = self.params[0].size(0)
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float64, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.loss = torch.zeros(1, dtype=torch.double, device=dev)
+        self.work = None
+        self.events = None
+
+    def __call__(self, onv: Tensor, state_prob: Tensor, eloc: Tensor, e_total, extra_psi_pow=1.0) -> Tensor:
+        N, dev = self.N, self.flat.device
+        n = onv.size(0)
+        if onv.dtype != torch.uint8 or onv.dim() != 2 or onv.size(1) != 8 * ((self.sorb - 1) // 64 + 1) or onv.device != dev:
+            raise ValueError("FusedRbmGrad: walkers as packed onv uint8[n, 8 len] on the parameters' device")
+        cplx = eloc.is_complex()
+        prob = (state_prob.real if state_prob.is_complex() else state_prob).to(torch.float64).contiguous()
+        el = eloc.to(torch.complex128 if cplx else torch.float64).contiguous()
+        et = (e_total if isinstance(e_total, Tensor) else torch.as_tensor(e_total)).to(device=dev, dtype=el.dtype).reshape(1).contiguous()
+        pw = None
+        if isinstance(extra_psi_pow, Tensor):
+            if extra_psi_pow.is_complex():
+                raise ValueError("FusedRbmGrad: extra_psi_pow must be real")
+            pw = extra_psi_pow.to(torch.float64).contiguous()
+        elif float(extra_psi_pow) != 1.0:
+            pw = torch.full((n,), float(extra_psi_pow), dtype=torch.float64, device=dev)
+        need = N.lib().pynqs_rbm_grad_workspace(n, self.sorb, self.H, self.flavour)
+        if self.work is None or self.work.numel() * 8 < need:
+            self.work = torch.empty(max(need // 8, 1), dtype=torch.float64, device=dev)
+        W, hb, vb = (p.detach().contiguous() for p in self.params)
+        gw, ghb, gvb = self.views
+        N.check(N.lib().pynqs_rbm_grad(onv.contiguous().data_ptr(), n, self.sorb, W.data_ptr(), hb.data_ptr(), vb.data_ptr(), self.H, self.flavour,
+                                       prob.data_ptr(), el.data_ptr(), int(cplx), et.data_ptr(), pw.data_ptr() if pw is not None else None,
+                                       gw.data_ptr(), ghb.data_ptr(), gvb.data_ptr(), self.loss.data_ptr(), self.work.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream), "pynqs_rbm_grad")
+        ws = get_world_size()
+        ev = None
+        if self.events is not None:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+        if ws > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.flat, dist.ReduceOp.SUM)
+            self.flat.div_(ws)
+        if ev is not None:
+            ev[1].record()
+            self.events.append(ev)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return all_reduce_packed([self.loss], ws)[0]

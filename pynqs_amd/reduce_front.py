@@ -91,6 +91,7 @@ class ReduceFrontEnd:
         # (want_pm1 = False: the caller evaluates the amplitudes from the packed determinants, e.g. pynqs_rbm_forward: 0.1 ms and 0.47 GB of
         # writes less per 1.5 M distinct x')
         self.uniq_pm1 = torch.ones((self.cap_unique, sorb), dtype=pm1_dtype, device=dev) if want_pm1 else None
+        self.uniq_parent = torch.zeros(self.cap_unique, dtype=torch.int32, device=dev)  # the walker each distinct row descends from
         self.counters = torch.zeros(4, dtype=torch.int32, device=dev)
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # added to run()'s seed: bump it between the replays of a captured step
         # row cache of the semi-stochastic kernel: the draws read the row back instead of enumerating the drawn tiles again.  Worth it when
@@ -121,6 +122,7 @@ class ReduceFrontEnd:
         io.counters = self.counters.data_ptr()
         io.seed_dev = self.seed_dev.data_ptr()
         io.row_cache = self.row_cache.data_ptr() if self.row_cache is not None else None
+        io.uniq_parent = self.uniq_parent.data_ptr()
         return io
 
     # ---- launches -------------------------------------------------------------------------------------------------------

@@ -102,3 +102,40 @@ def test_rbm_forward_kernel_matches_the_module(kind, sorb, H):
         want = m(x)
     assert got.dtype == want.dtype
     torch.testing.assert_close(got, want, rtol=1e-11, atol=0 if kind != "pRBM" else 1e-11)
+
+
+@pytest.mark.parametrize("rbm_type,sorb,no,H", [("complex", 40, 15, 40), ("real", 40, 15, 80), ("tanh", 12, 3, 7), ("pRBM", 72, 6, 9), ("complex", 136, 4, 11)])
+def test_rbm_forward_children_matches_the_plain_forward(rbm_type, sorb, no, H):
+    """pynqs_rbm_theta + pynqs_rbm_forward_children on the distinct x' of a REDUCE front end (each row from its parent walker, <= 4 orbitals
+    flipped) against pynqs_rbm_forward on the same rows: 1e-11 relative (the additions run in a different order; typical 5e-15, the worst rows have a factor 2cosh theta_h near zero); rows past the device
+    count are left alone; the parents really are parents."""
+    import bench as B
+    from pynqs_amd import C_extension as cx, energy as E
+
+    dev = torch.device("cuda")
+    n = 96
+    x = B.synth_walkers(n, sorb, no, no, 3).to(dev)
+    h1, h2 = B.synth_integrals(sorb)
+    fe, nu = E.reduce_front(x, h1.to(dev), h2.to(dev), sorb, 2 * no, no, no, 0.3, 40, None, seed=5, pm1_dtype=torch.float64)
+    assert nu > n
+    par = fe.uniq_parent[:nu].long()
+    d = (fe.uniq_onv[:nu] ^ x[par]).cpu().numpy()
+    assert int(np.unpackbits(d, axis=1).sum(1).max()) <= 4 and int(par.min()) >= 0 and int(par.max()) < n
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: (0.4 * (torch.rand(*s, generator=g, dtype=torch.float64) - 0.5)).to(dev)  # noqa: E731
+    if rbm_type == "complex":
+        W, hb, vb = r(H, sorb, 2), r(H, 2), r(sorb, 2)
+    else:
+        W, hb, vb = r(H, sorb), r(H), r(sorb)
+    assert cx.rbm_forward_children_supported(sorb, H, rbm_type)
+    # (absolute part: "tanh" multiplies by tanh(a.x), whose zero crossings make a relative bound meaningless)
+    close = lambda a, b: bool(((a - b).abs() <= 1e-11 * b.abs() + 1e-13 * b.abs().max()).all())  # noqa: E731
+    for vbias in (vb, None):
+        want = cx.rbm_forward(fe.uniq_onv[:nu].contiguous(), W, hb, vbias, sorb, rbm_type)
+        got = cx.rbm_forward_children(fe.uniq_onv[:nu].contiguous(), fe.uniq_parent, x, W, hb, vbias, sorb, rbm_type)
+        assert close(got, want)
+    out = torch.full((fe.cap_unique,), 7.0, dtype=want.dtype, device=dev)
+    cx.rbm_forward_children(fe.uniq_onv, fe.uniq_parent, x, W, hb, vb, sorb, rbm_type, count=fe.counters, out=out)
+    assert close(out[:nu], cx.rbm_forward(fe.uniq_onv[:nu].contiguous(), W, hb, vb, sorb, rbm_type))
+    assert bool((out[nu:] == 7.0).all())
+    assert not cx.rbm_forward_children_supported(184, 368, "complex")
