@@ -271,6 +271,29 @@ inline uint32_t hash_filter2_bits(int64_t nkeys) {  // host side
   return (uint32_t)b;
 }
 
+// String filters (round 3): one Bloom filter over the ALPHA strings of the keys and one over their BETA strings (the Zobrist hash of the
+// even / of the odd orbitals; two positions each), appended after the second-level filter.  An alpha single of x can only lead into the
+// table -- alone or combined with any beta single -- if alpha(x) with that single applied is the alpha string of some key, so the
+// alpha-beta class (71 % of Fe2S2's columns) shrinks to (passing alpha singles) x (passing beta singles) before any column is visited.
+// At most 1/8 full: a string that is not in the table passes with probability < 2 %.
+inline uint32_t hash_string_bits(int64_t nkeys) {  // host side; per spin
+  if (nkeys <= 0) return 0;
+  uint64_t b = 1u << 13;
+  while (b < 16ull * (uint64_t)nkeys && b < (1u << 22)) b <<= 1;
+  return (uint32_t)b;
+}
+
+template <int LEN>
+__host__ __device__ inline void zobrist_strings(const uint64_t (&q)[LEN], uint32_t &za, uint32_t &zb) {
+  za = 0; zb = 0;
+  for (int w = 0; w < LEN; ++w)
+    for (uint64_t b = q[w]; b; b &= b - 1) {
+      const uint32_t o = 64u * w + (uint32_t)__builtin_ctzll(b);
+      if (o & 1u) zb ^= zobrist32(o);
+      else za ^= zobrist32(o);
+    }
+}
+
 // The second-level filter is blocked: both bits of a key lie in ONE 32-bit word (word from the low bits of the hash, the
 // two bit numbers from its top 10 bits), so a query is one load.  (At 32 bits per key the false-positive rate stays
 // below 1 %; the LDS filter, with 2-8 bits per key, keeps two independent positions.)

@@ -409,13 +409,20 @@ struct Candidates {
 };
 
 // SWEEP: the doubles are scanned in block sweeps (long rows) instead of rank by rank; the host picks by the alpha-beta class's row length
-template <int LEN, bool CPLX, bool TWO, int BLOCK, bool SWEEP>
+// PRE (round 3; rank-by-rank scan only): the alpha-beta class is visited as (alpha singles whose new alpha string is in the table) x
+// (beta singles whose new beta string is) -- two short lists made per walker from the table's string filters (detcore.h) -- instead of
+// all nSa x nSb pairs: Fe2S2's 5625 columns become ~850, nearly all of them hits.
+__host__ __device__ inline size_t pre_lds_bytes(const SDParams &p) { return (8 + 2 * ((size_t)p.nSa + (size_t)p.nSb) + 15) & ~(size_t)15; }
+
+template <int LEN, bool CPLX, bool TWO, int BLOCK, bool SWEEP, bool PRE = false>
 __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl,
                                                                             uint32_t nchunks, uint32_t chunk_len, bool xcd_map,
                                                                             const double *__restrict__ plan,
                                                                             const uint64_t *__restrict__ table, int64_t cap,
                                                                             const double *__restrict__ wf, double *__restrict__ acc,
-                                                                            double *__restrict__ psi0, bool flip, uint32_t fbits, uint32_t f2bits) {
+                                                                            double *__restrict__ psi0, bool flip, uint32_t fbits, uint32_t f2bits,
+                                                                            uint32_t sbits) {
+  static_assert(!(PRE && SWEEP), "the string prefilter belongs to the rank-by-rank scan");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double red[2][BLOCK / 64];
   __shared__ uint32_t next_tile;
@@ -457,6 +464,45 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
   const uint32_t dyn = __builtin_amdgcn_groupstaticsize();  // LDS address of smem[0]
   Candidates<LEN, CPLX, TWO> cand{p, pl, L, wk, nocc, plan, table, (uint64_t)cap, wf, gf + fbits / 32, f2bits, dyn + filt_off, fbits, dyn + z_off,
                              dyn + (uint32_t)lds_tab_bytes(p), dyn + q_off + (uint32_t)(tid >> 6) * queue_bytes(TWO), zx, zx2, {0u, 0u}, {0u, 0u}, 0.0, 0.0, flip};
+
+  // ---- PRE: the two lists.  Wave 0 tests the alpha singles, wave 1 the beta singles (ballot compaction: ascending, reproducible)
+  uint32_t nA = 0, nB = 0;
+  const uint16_t *listA = nullptr, *listB = nullptr;
+  if constexpr (PRE) {
+    uint32_t zxa = 0;  // the alpha part of zx
+#pragma unroll
+    for (int w = 0; w < LEN; ++w)
+      if (((wk.w[w] >> lane) & 1ull) && !(lane & 1)) zxa ^= zobrist32((64u * w + (uint32_t)lane) ^ (flip ? 1u : 0u));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zxa ^= __shfl_xor(zxa, o);
+    uint32_t *pre = reinterpret_cast<uint32_t *>(smem + q_off + (BLOCK / 64) * queue_bytes(TWO));
+    uint16_t *la = reinterpret_cast<uint16_t *>(pre + 2), *lb = la + p.nSa;
+    const int wv = tid >> 6;
+    if (wv < 2) {
+      // flip: the table is asked for flip(x'), whose beta string is the alpha string of x' (in the partner orbitals' Zobrist values)
+      const uint32_t *__restrict__ sf = gf + fbits / 32 + f2bits / 32 + ((wv == 0) != flip ? 0u : sbits / 32);
+      const uint32_t n = wv == 0 ? (uint32_t)p.nSa : (uint32_t)p.nSb, off = wv == 0 ? (uint32_t)p.offSa : (uint32_t)p.offSb;
+      const uint32_t zs = wv == 0 ? zxa : zx ^ zxa;
+      uint16_t *list = wv == 0 ? la : lb;
+      uint32_t cnt = 0;
+      for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        bool pass = false;
+        if (i < n) {
+          uint32_t b0, b1;
+          filter_positions(zs ^ cand.flipped_at(off + i), sbits, b0, b1);
+          pass = ((sf[b0 >> 5] >> (b0 & 31u)) & (sf[b1 >> 5] >> (b1 & 31u)) & 1u) != 0u;
+        }
+        const uint64_t m = __ballot(pass);
+        if (pass) list[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        cnt += (uint32_t)__popcll(m);
+      }
+      if (lane == 0) pre[wv] = cnt;
+    }
+    __syncthreads();
+    nA = pre[0]; nB = pre[1];
+    listA = la; listB = lb;
+  }
 
   // tiles: 0 = column 0; 1 = this workgroup's share of the singles (blocks of 64 dealt round-robin over the walker's
   // workgroups, as in plan_tiles.h) -- one wave takes them all, so that its singles queue fills; then 256 ranks of one
@@ -503,7 +549,7 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
                    rO = class_range<false>(p.d3, p.nsd, rlo, rhi, 0u);
   constexpr bool swA = SWEEP, swB = SWEEP, swO = SWEEP;  // one mode per launch: two scan loops in one kernel cost Fe2S2 10 %
   const uint32_t tA = swA ? gA.nitems : (rA.npairs + kRanks - 1) / kRanks, tB = swB ? gB.nitems : (rB.npairs + kRanks - 1) / kRanks,
-                 tO = swO ? gO.nitems : (rO.npairs + kRanks - 1) / kRanks;
+                 tO = PRE ? (rO.npairs ? (nA * nB + kRanks - 1) / kRanks : 0u) : (swO ? gO.nitems : (rO.npairs + kRanks - 1) / kRanks);
   const uint32_t ntiles = 2 + tA + tB + tO;
   for (;;) {
     uint32_t tile = 0;
@@ -546,7 +592,32 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
     const uint32_t item = tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB));
     const DoubleClass c = k == 2 ? make_opp_spin(p, pl) : make_same_spin(p, pl, k);
     const uint32_t nslow = (uint32_t)(k == 0 ? p.nvAA : (k == 1 ? p.nvBB : p.nSb));
-    if constexpr (!SWEEP) {
+    if (PRE && k == 2) {
+      // ---- the alpha-beta class from the two lists: pair t = (t / nA)-th passing beta single x (t % nA)-th passing alpha single
+      const uint32_t npair = nA * nB, first = item * kRanks;
+      const uint32_t q64 = 64u / nA, r64 = 64u - q64 * nA;
+      uint32_t i = (first + (uint32_t)lane) / nA, j = first + (uint32_t)lane - i * nA;
+      uint32_t rr[4];
+      bool pass[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const uint32_t m = first + 64u * g4 + (uint32_t)lane;
+        const uint32_t slow = listB[min(i, nB - 1u)], f = listA[j];
+        const uint32_t r = p.d3 + slow * (uint32_t)p.nSa + f;  // (no rotation in this class)
+        rr[g4] = TWO ? cand.pack(2, slow, f) : r;
+        const uint32_t z = zx ^ cand.flipped_at((uint32_t)p.offSa + f) ^ cand.flipped_at((uint32_t)p.offSb + slow);
+        pass[g4] = (m < npair) & (r >= rlo) & (r < rhi) & cand.maybe(z);
+        j += r64;
+        i += q64 + (j >= nA ? 1u : 0u);
+        j = j >= nA ? j - nA : j;
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        cand.template park<false, 1>(rr[g4], pass[g4]);
+        if constexpr (!TWO) cand.template pump<false>();
+      }
+      if constexpr (TWO) cand.template pump<false>();
+    } else if constexpr (!SWEEP) {
       // ---- rank-by-rank scan of 256 consecutive ranks: rank -> (slow, fast) by one division for the lane's first rank, then
       // 64 further per group
       const ClassRange g = k == 0 ? rA : (k == 1 ? rB : rO);
@@ -629,11 +700,14 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
   store_walker_sum<CPLX, BLOCK / 64>(cand.re, cand.im, red, nchunks, walker, acc, psi0);
 }
 
+// the string filters exist beside an LDS filter only (they share its Zobrist values)
+static inline uint32_t hash_string_bits_if(int64_t nkeys) { return hash_filter_bits(nkeys) ? hash_string_bits(nkeys) : 0u; }
+
 // Insert key i of the sorted key array: claim a slot by CAS on its index word, then write the key words
 // (lookups only start after the build kernel has finished).
 template <int LEN>
 __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__restrict__ keys, int64_t nkeys, uint64_t cap,
-                                                            uint64_t *__restrict__ table, uint32_t fbits, uint32_t f2bits) {
+                                                            uint64_t *__restrict__ table, uint32_t fbits, uint32_t f2bits, uint32_t sbits) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nkeys) return;
   uint64_t q[LEN];
@@ -661,6 +735,18 @@ __global__ __launch_bounds__(kBlock) void hash_build_kernel(const uint64_t *__re
         if (f2bits) {  // second level
           filter2_position(z2, f2bits, b0, b1);
           atomicOr(filter + b0, b1);
+          filter += f2bits / 32;
+        }
+        if (sbits) {  // the key's alpha and beta strings
+          uint32_t za, zb;
+          zobrist_strings<LEN>(q, za, zb);
+          filter_positions(za, sbits, b0, b1);
+          atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
+          atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
+          filter += sbits / 32;
+          filter_positions(zb, sbits, b0, b1);
+          atomicOr(filter + (b0 >> 5), 1u << (b0 & 31u));
+          atomicOr(filter + (b1 >> 5), 1u << (b1 & 31u));
         }
       }
       return;
@@ -854,16 +940,20 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
       }
     }
   }
-  const size_t lds = lds_fixed + (filtered ? filtered_extra_lds(fbits, sorb, two_level, block) : 0);
+  // block sweeps once the rows of the alpha-beta class (nSa positions) are long: sorb 120 / 184 gain 20-23 %, Fe2S2 (75) would lose 12 %
+  static const int sweep_env = getenv("PYNQS_SS_SWEEP") ? atoi(getenv("PYNQS_SS_SWEEP")) : -1;
+  const bool sweep = sweep_env >= 0 ? sweep_env != 0 : p.nSa >= 256;
+  // string prefilter of the alpha-beta class: the rank-by-rank scan in 256-thread workgroups (PYNQS_SS_PRE=0: off)
+  static const bool pre_env = !(getenv("PYNQS_SS_PRE") && atoi(getenv("PYNQS_SS_PRE")) == 0);
+  const uint32_t sbits = hash && fbits ? hash_string_bits(nkeys) : 0u;
+  const bool pre = pre_env && filtered && sbits && !sweep && block == kBlock && p.nSa > 0 && p.nSb > 0;
+  const size_t lds = lds_fixed + (filtered ? filtered_extra_lds(fbits, sorb, two_level, block) : 0) + (pre ? pre_lds_bytes(p) : 0);
   const uint64_t grid = (uint64_t)nbatch * nchunks;
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   const size_t esz = wf_is_complex ? 16 : 8;
   if (nchunks > 1 && hipMemsetAsync(eloc, 0, esz * (size_t)nbatch, st) != hipSuccess) return check_launch("memset");
   const double *pd = (const double *)plan;
   const int64_t size_arg = hash ? (int64_t)hash_capacity(nkeys) : nkeys;
-  // block sweeps once the rows of the alpha-beta class (nSa positions) are long: sorb 120 / 184 gain 20-23 %, Fe2S2 (75) would lose 12 %
-  static const int sweep_env = getenv("PYNQS_SS_SWEEP") ? atoi(getenv("PYNQS_SS_SWEEP")) : -1;
-  const bool sweep = sweep_env >= 0 ? sweep_env != 0 : p.nSa >= 256;
 #define PYNQS_SS_ARGS dim3((uint32_t)grid), dim3(block), lds, st, bra, p, pl, nchunks, chunk_len, xcd_mapping(nchunks), pd, keys, size_arg, wf, eloc, psi0, flip
 #define PYNQS_SS_LAUNCH(KERNEL, ...)                                                                                              \
   do {                                                                                                                            \
@@ -872,20 +962,23 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
       return check_launch("hipFuncSetAttribute");                                                                                \
     hipLaunchKernelGGL((KERNEL), PYNQS_SS_ARGS, ##__VA_ARGS__);                                                                   \
   } while (0)
-#define PYNQS_SS_FILTERED2(B, SW)                                                                                      \
-  do {                                                                                                                 \
-    if (two_level) {                                                                                                   \
-      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, true, B, SW>), fbits, f2bits);   \
-      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, true, B, SW>), fbits, f2bits);               \
-    } else {                                                                                                           \
-      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, false, B, SW>), fbits, f2bits);  \
-      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, false, B, SW>), fbits, f2bits);              \
-    }                                                                                                                  \
+#define PYNQS_SS_FILTERED2(B, SW, PR)                                                                                              \
+  do {                                                                                                                             \
+    if (two_level) {                                                                                                               \
+      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, true, B, SW, PR>), fbits, f2bits, sbits);    \
+      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, true, B, SW, PR>), fbits, f2bits, sbits);                \
+    } else {                                                                                                                       \
+      if (wf_is_complex) PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, true, false, B, SW, PR>), fbits, f2bits, sbits);   \
+      else PYNQS_SS_LAUNCH((eloc_sample_space_filtered_kernel<LEN, false, false, B, SW, PR>), fbits, f2bits, sbits);               \
+    }                                                                                                                              \
   } while (0)
-#define PYNQS_SS_FILTERED(B) do { if (sweep) PYNQS_SS_FILTERED2(B, true); else PYNQS_SS_FILTERED2(B, false); } while (0)
+#define PYNQS_SS_FILTERED(B) do { if (sweep) PYNQS_SS_FILTERED2(B, true, false); else PYNQS_SS_FILTERED2(B, false, false); } while (0)
+#define PYNQS_SS_FILTERED_PRE() PYNQS_SS_FILTERED2(kBlock, false, true)
   DISPATCH_LEN(len, {
     if (filtered) {  // hash table with its filters
-      if constexpr (LEN >= 2) {
+      if (pre) {
+        PYNQS_SS_FILTERED_PRE();
+      } else if constexpr (LEN >= 2) {
         if (block == 1024) PYNQS_SS_FILTERED(1024);
         else if (block == kBigBlock) PYNQS_SS_FILTERED(kBigBlock);
         else PYNQS_SS_FILTERED(kBlock);
@@ -898,6 +991,7 @@ static int eloc_sample_space_impl(const uint64_t *bra, int64_t nbatch, int sorb,
       if (hash) PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, false, true>)); else PYNQS_SS_LAUNCH((eloc_sample_space_kernel<LEN, false, false>));
     }
   });
+#undef PYNQS_SS_FILTERED_PRE
 #undef PYNQS_SS_FILTERED
 #undef PYNQS_SS_FILTERED2
 #undef PYNQS_SS_ARGS
@@ -946,7 +1040,8 @@ extern "C" int pynqs_eloc_sample_space_hash_flip(const uint64_t *bra, int64_t nb
 extern "C" int64_t pynqs_hash_bytes(int64_t nkeys, int sorb) {
   if (nkeys < 0 || sorb < 1 || sorb > kMaxSorb) return -1;
   const int len = (sorb - 1) / 64 + 1;
-  return (int64_t)(hash_capacity(nkeys) * (uint64_t)hash_slot_words(len) * 8 + hash_filter_bits(nkeys) / 8 + hash_filter2_bits(nkeys) / 8);
+  return (int64_t)(hash_capacity(nkeys) * (uint64_t)hash_slot_words(len) * 8 + hash_filter_bits(nkeys) / 8 + hash_filter2_bits(nkeys) / 8 +
+                   2 * (size_t)hash_string_bits_if(nkeys) / 8);
 }
 
 extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, void *table, void *stream) {
@@ -960,11 +1055,12 @@ extern "C" int pynqs_hash_build(const uint64_t *keys, int64_t nkeys, int sorb, v
   const size_t slot_bytes = cap * (size_t)hash_slot_words(len) * 8;
   const uint32_t fbits = hash_filter_bits(nkeys);
   if (hipMemsetAsync(table, 0xFF, slot_bytes, st) != hipSuccess) return check_launch("hash memset");
-  const uint32_t f2bits = hash_filter2_bits(nkeys);
-  if ((fbits || f2bits) && hipMemsetAsync((char *)table + slot_bytes, 0, fbits / 8 + f2bits / 8, st) != hipSuccess) return check_launch("filter memset");
+  const uint32_t f2bits = hash_filter2_bits(nkeys), sbits = hash_string_bits_if(nkeys);
+  if ((fbits || f2bits) && hipMemsetAsync((char *)table + slot_bytes, 0, fbits / 8 + f2bits / 8 + 2 * (size_t)sbits / 8, st) != hipSuccess)
+    return check_launch("filter memset");
   if (nkeys == 0) return PYNQS_OK;
   const uint32_t grid = (uint32_t)((nkeys + kBlock - 1) / kBlock);
-  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table, fbits, f2bits));
+  DISPATCH_LEN(len, hipLaunchKernelGGL((hash_build_kernel<LEN>), dim3(grid), dim3(kBlock), 0, st, keys, nkeys, cap, (uint64_t *)table, fbits, f2bits, sbits));
   return check_launch("hash_build");
 }
 

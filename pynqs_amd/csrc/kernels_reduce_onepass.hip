@@ -86,7 +86,11 @@ struct OnepassOut {
   T *row_cache;    // [nbatch][ncomb] or NULL
   int32_t *uniq_parent;  // [ucap] or NULL: the walker whose record put the row on the distinct list (x' is a single / double excitation of it)
   int32_t parent;        // this workgroup's walker (set by the kernel)
-  uint32_t debug;  // PYNQS_OP_DEBUG ablations (timing only): 1 no amplitude source, 2 no +-1 rows, 4 no look-back
+  uint32_t debug;  // PYNQS_OP_DEBUG ablations (timing only): 1 no amplitude source, 2 no +-1 rows, 4 no look-back, 8 no in-tile draws,
+                   // 16 no phase C, 32 phase A only; row-cache form: 64 no tile draws, 128 no search inside a tile, 256 no emission.
+                   // Fe2S2, 8192 walkers, 1000 draws (round 3, row-cache form, no +-1 rows): 794 us = enumeration 184 + row cache
+                   // written 80 + kept list sorted and resolved 66 + tile sums, tile-level draws, scans 117 + draws inside the tiles
+                   // 209 (search 10, emission and resolution of the drawn records 75) + de-duplication 146
 };
 
 // ---- de-duplication table ----------------------------------------------------------------------------------------
@@ -1212,7 +1216,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= nct) break;
         const uint32_t info = dinfo[t], draws = info & 0xffffu;
-        if (draws == 0) continue;
+        if (draws == 0 || (o.debug & 64u)) continue;
         const uint32_t c0 = t * kOneTileCols + lane * 4;
         double w4[4];
         uint32_t neg = 0;
@@ -1242,6 +1246,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
           const uint64_t r = op_mix64(key ^ op_mix64(((uint64_t)t << 32) | k));
           const double target = (double)(r >> 11) * 0x1.0p-53 * total;
           uint32_t lo = 0, hi = ncols;
+          if (o.debug & 128u) { lo = (uint32_t)(r % ncols); hi = lo; }
           while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             if (S.prefix[mid] > target) hi = mid; else lo = mid + 1;
@@ -1252,6 +1257,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t pos = info >> 16;
+        if (o.debug & 256u) continue;
         for (uint32_t i0 = 0; i0 < ncols; i0 += 64) {
           const uint32_t idx = i0 + lane;
           const uint32_t hc = idx < ncols ? S.hits[idx] : 0u;
