@@ -160,7 +160,8 @@ __global__ __launch_bounds__(kBlock) void rbm_children_factors_kernel(int sorb, 
       re = m;
     }
   } else if (h == H) {
-    for (int k = 0; k < H; ++k) {
+#pragma unroll 16
+    for (int k = 0; k < H; ++k) {  // (independent loads: 16 in flight)
       re += W[((size_t)k * sorb + o) * C];
       if constexpr (CPLX) im += W[((size_t)k * sorb + o) * C + 1];
     }
@@ -173,58 +174,66 @@ __global__ __launch_bounds__(kBlock) void rbm_children_factors_kernel(int sorb, 
   if constexpr (CPLX) factors[(size_t)idx * C + 1] = im;
 }
 
+// one lane per (walker, chunk of kHChunk hidden units): blockIdx.y is the chunk, so that W_ho stays wave-uniform and 8192 walkers are
+// 5 x 128 waves, not 128 (80 -> 10 us for Fe2S2).  Chunk 0 also leaves sum_h theta_h = sum_h b_h + sum_o x_o sum_h W_ho (from the factor
+// table's sum_h W_ho, built by the launch before this one) and a.x.
 template <int LEN, bool CPLX>
 __global__ __launch_bounds__(kBlock) void rbm_children_parents_kernel(const uint64_t *__restrict__ onv, int64_t n, int sorb, int H,
                                                                       const double *__restrict__ W, const double *__restrict__ hb,
-                                                                      const double *__restrict__ vb, double *__restrict__ table) {
+                                                                      const double *__restrict__ vb, const double *__restrict__ factors,
+                                                                      double *__restrict__ table) {
   constexpr int C = CPLX ? 2 : 1;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t row = i < n ? i : n - 1;
+  const int h0 = (int)blockIdx.y * kHChunk;
   uint64_t ket[LEN];
 #pragma unroll
   for (int w = 0; w < LEN; ++w) ket[w] = onv[row * LEN + w];
   double *__restrict__ out = table + (size_t)row * (size_t)(H + 2) * C;
-  double sr = 0.0, si = 0.0;
-  for (int h0 = 0; h0 < H; h0 += kHChunk) {
-    double tr[kHChunk], ti[kHChunk];
+  double tr[kHChunk], ti[kHChunk];
+#pragma unroll
+  for (int j = 0; j < kHChunk; ++j) {
+    const int h = min(h0 + j, H - 1);
+    tr[j] = CPLX ? hb[2 * h] : hb[h];
+    ti[j] = CPLX ? hb[2 * h + 1] : 0.0;
+  }
+  for (int o = 0; o < sorb; ++o) {
+    const double x = pm1_of<LEN>(ket, o);
 #pragma unroll
     for (int j = 0; j < kHChunk; ++j) {
-      const int h = min(h0 + j, H - 1);
-      tr[j] = CPLX ? hb[2 * h] : hb[h];
-      ti[j] = CPLX ? hb[2 * h + 1] : 0.0;
+      const int h = min(h0 + j, H - 1);  // (wave-uniform address: a scalar load)
+      tr[j] = fma(x, W[((size_t)h * sorb + o) * C], tr[j]);
+      if constexpr (CPLX) ti[j] = fma(x, W[((size_t)h * sorb + o) * C + 1], ti[j]);
     }
-    for (int o = 0; o < sorb; ++o) {
-      const double x = pm1_of<LEN>(ket, o);
+  }
 #pragma unroll
-      for (int j = 0; j < kHChunk; ++j) {
-        const int h = min(h0 + j, H - 1);  // (wave-uniform address: a scalar load)
-        tr[j] = fma(x, W[((size_t)h * sorb + o) * C], tr[j]);
-        if constexpr (CPLX) ti[j] = fma(x, W[((size_t)h * sorb + o) * C + 1], ti[j]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < kHChunk; ++j) {
-      if (h0 + j < H && i < n) {
-        sr += tr[j]; si += ti[j];
-        const double m = exp(-2.0 * tr[j]);
-        if constexpr (CPLX) {
-          double sn, cs;
-          sincos_mod(-2.0 * ti[j], sn, cs);
-          out[(size_t)(h0 + j) * 2] = m * cs;
-          out[(size_t)(h0 + j) * 2 + 1] = m * sn;
-        } else {
-          out[h0 + j] = m;
-        }
+  for (int j = 0; j < kHChunk; ++j) {
+    if (h0 + j < H && i < n) {
+      const double m = exp(-2.0 * tr[j]);
+      if constexpr (CPLX) {
+        double sn, cs;
+        sincos_mod(-2.0 * ti[j], sn, cs);
+        out[(size_t)(h0 + j) * 2] = m * cs;
+        out[(size_t)(h0 + j) * 2 + 1] = m * sn;
+      } else {
+        out[h0 + j] = m;
       }
     }
   }
-  double axr = 0.0, axi = 0.0;
-  if (vb) {
-    for (int o = 0; o < sorb; ++o) {
-      const double x = pm1_of<LEN>(ket, o);
-      axr = fma(x, vb[(size_t)o * C], axr);
-      if constexpr (CPLX) axi = fma(x, vb[(size_t)o * C + 1], axi);
-    }
+  if (blockIdx.y != 0) return;
+  const int HP = children_hp(H);
+  double sr = 0.0, si = 0.0, axr = 0.0, axi = 0.0;
+  for (int h = 0; h < H; ++h) {
+    sr += hb[(size_t)h * C];
+    if constexpr (CPLX) si += hb[(size_t)h * C + 1];
+  }
+  for (int o = 0; o < sorb; ++o) {
+    const double x = pm1_of<LEN>(ket, o);
+    // rows 2 o of the factor table: entry H = +2 sum_h W_ho, entry H + 1 = +2 a_o  (wave-uniform addresses)
+    const double *__restrict__ f = factors + ((size_t)(2 * o) * HP + H) * C;
+    sr = fma(0.5 * x, f[0], sr);
+    axr = fma(0.5 * x, f[C], axr);
+    if constexpr (CPLX) { si = fma(0.5 * x, f[1], si); axi = fma(0.5 * x, f[C + 1], axi); }
   }
   if (i >= n) return;
   out[(size_t)H * C] = sr;
@@ -232,8 +241,13 @@ __global__ __launch_bounds__(kBlock) void rbm_children_parents_kernel(const uint
   if constexpr (CPLX) { out[(size_t)H * C + 1] = si; out[(size_t)(H + 1) * C + 1] = axi; }
 }
 
+#ifndef PYNQS_CHILD_BLOCK
+#define PYNQS_CHILD_BLOCK 1024
+#endif
+constexpr int kChildBlock = PYNQS_CHILD_BLOCK;  // the factor table (up to 64 KB of LDS) is shared by the workgroup's waves: large workgroups, more waves per CU
+
 template <int LEN, int FLAVOUR>
-__global__ __launch_bounds__(kBlock) void rbm_forward_children_kernel(const uint64_t *__restrict__ onv, int64_t n, const int32_t *__restrict__ count_dev,
+__global__ __launch_bounds__(kChildBlock) void rbm_forward_children_kernel(const uint64_t *__restrict__ onv, int64_t n, const int32_t *__restrict__ count_dev,
                                                                       const int32_t *__restrict__ parent, const uint64_t *__restrict__ walkers,
                                                                       int64_t nwalkers, const double *__restrict__ table,
                                                                       const double *__restrict__ factors, int sorb, int H, double *__restrict__ psi) {
@@ -241,11 +255,11 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_children_kernel(const uint
   constexpr int C = CPLX ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double wl[];
   const int HP = children_hp(H);
-  for (int idx = threadIdx.x; idx < (2 * sorb + 1) * HP * C; idx += kBlock) wl[idx] = factors[idx];
+  for (int idx = threadIdx.x; idx < (2 * sorb + 1) * HP * C; idx += kChildBlock) wl[idx] = factors[idx];
   __syncthreads();
   int64_t cnt = n;
   if (count_dev) cnt = min((int64_t)max(*count_dev, 0), n);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * kBlock) {
+  for (int64_t i = (int64_t)blockIdx.x * kChildBlock + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * kChildBlock) {
     int64_t p = parent[i];
     p = p < 0 || p >= nwalkers ? 0 : p;
     // the rows of the factor table for the flipped orbitals ("no flip" for the unused slots)
@@ -381,14 +395,15 @@ extern "C" int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalk
   if (cplx) hipLaunchKernelGGL((rbm_children_factors_kernel<true>), dim3(gf), dim3(kBlock), 0, st, sorb, nhidden, weights, visible_bias, factors);
   else hipLaunchKernelGGL((rbm_children_factors_kernel<false>), dim3(gf), dim3(kBlock), 0, st, sorb, nhidden, weights, visible_bias, factors);
   if (nwalkers > 0) {
-    const uint32_t grid = (uint32_t)((nwalkers + kBlock - 1) / kBlock);
+    const dim3 grid((uint32_t)((nwalkers + kBlock - 1) / kBlock), (uint32_t)((nhidden + kHChunk - 1) / kHChunk));
+    if (grid.y > 65535u) return set_error(PYNQS_EINVAL, "too many hidden units");
     DISPATCH_LEN(len, {
       if (cplx)
-        hipLaunchKernelGGL((rbm_children_parents_kernel<LEN, true>), dim3(grid), dim3(kBlock), 0, st, walkers, nwalkers, sorb, nhidden, weights,
-                           hidden_bias, visible_bias, parents);
+        hipLaunchKernelGGL((rbm_children_parents_kernel<LEN, true>), grid, dim3(kBlock), 0, st, walkers, nwalkers, sorb, nhidden, weights,
+                           hidden_bias, visible_bias, factors, parents);
       else
-        hipLaunchKernelGGL((rbm_children_parents_kernel<LEN, false>), dim3(grid), dim3(kBlock), 0, st, walkers, nwalkers, sorb, nhidden, weights,
-                           hidden_bias, visible_bias, parents);
+        hipLaunchKernelGGL((rbm_children_parents_kernel<LEN, false>), grid, dim3(kBlock), 0, st, walkers, nwalkers, sorb, nhidden, weights,
+                           hidden_bias, visible_bias, factors, parents);
     });
   }
   return check_launch("rbm_children_prepare");
@@ -404,14 +419,14 @@ extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const 
   if (n == 0) return PYNQS_OK;
   if (!onv || !parent || !walkers || !table || !psi || nwalkers == 0) return set_error(PYNQS_EINVAL, "null pointer");
   const int len = (sorb - 1) / 64 + 1;
-  int64_t blocks = (n + kBlock - 1) / kBlock;
-  if (blocks > 2048) blocks = 2048;  // (a workgroup copies the factor table once and strides over the rows)
+  int64_t blocks = (n + kChildBlock - 1) / kChildBlock;
+  if (blocks > 1024) blocks = 1024;  // (a workgroup copies the factor table once and strides over the rows)
   const uint32_t grid = (uint32_t)blocks;
   const size_t lds = children_lds_bytes(sorb, nhidden, flavour);
   const double *parents = (const double *)table;
   const double *factors = parents + (size_t)nwalkers * (size_t)(nhidden + 2) * (flavour == PYNQS_RBM_COMPLEX ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
-#define PYNQS_RC(F) hipLaunchKernelGGL((rbm_forward_children_kernel<LEN, F>), dim3(grid), dim3(kBlock), lds, st, onv, n, count_dev, parent, walkers, nwalkers, parents, factors, sorb, nhidden, psi)
+#define PYNQS_RC(F) hipLaunchKernelGGL((rbm_forward_children_kernel<LEN, F>), dim3(grid), dim3(kChildBlock), lds, st, onv, n, count_dev, parent, walkers, nwalkers, parents, factors, sorb, nhidden, psi)
   DISPATCH_LEN(len, {
     switch (flavour) {
       case PYNQS_RBM_REAL: PYNQS_RC(PYNQS_RBM_REAL); break;

@@ -461,6 +461,9 @@ struct DrawLds {
   volatile double *run;
 };
 constexpr size_t kDrawLdsPerWave = (size_t)kOneTileCols * (8 + 4 + 4) + 16;
+// ... of the row-cache form: running sums f64[cols], hit counts u16[cols] (pairs in 32-bit words: LDS atomics are 32-bit), signs (1 bit per
+// column).  The column of an entry is its position: nothing else is stored.  (16.4 -> 10.4 KB per workgroup: more workgroups per CU.)
+constexpr size_t kCachedDrawLdsPerWave = (size_t)kOneTileCols * (8 + 2) + kOneTileCols / 8;
 
 template <int LEN, typename T>
 struct DrawSink {
@@ -1005,19 +1008,25 @@ struct ListDrawSink {
 #define PYNQS_LIST_Q_SAMPLED 256
 #endif
 __host__ __device__ constexpr int list_quarter(bool sampled) { return sampled ? PYNQS_LIST_Q_SAMPLED : kDiagTile / 4; }
-__host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, bool sampled) {
-  return (lds_fixed_bytes(p) + esz * (size_t)(list_quarter(sampled) * (kBlock / 64)) + 15) & ~(size_t)15;
+// `cached` (row-cache form): the draws read the row back and never enumerate again, so the waves' draw areas share the memory of the
+// staging scratch of phase A (barriers lie between the two uses): 8 KB less per workgroup, 5 instead of 4 workgroups per CU for Fe2S2
+__host__ __device__ inline size_t list_scratch_offset(const SDParams &p) { return (lds_fixed_bytes(p) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, bool sampled, bool cached) {
+  const size_t scratch = esz * (size_t)(list_quarter(sampled) * (kBlock / 64)), draw = (kBlock / 64) * kCachedDrawLdsPerWave;
+  if (cached) return (list_scratch_offset(p) + (scratch > draw ? scratch : draw) + 15) & ~(size_t)15;
+  return (lds_fixed_bytes(p) + scratch + 15) & ~(size_t)15;
 }
 
 // LDS of the LIST form after the walker tables and the staging scratch:
 //   (SAMPLED) tsum[max_tiles] f64 | dinfo[max_tiles] u32 | draw areas ;  then the list: col[P] u32, h[P] T  (P = power of two >= capacity),
 //   which the draw slots' columns (pend[N] u32) re-use in phase C
-__host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample) {
-  size_t b = list_base_lds(p, esz, sampled);
+__host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample,
+                                                   bool cached) {
+  size_t b = list_base_lds(p, esz, sampled, cached);
   if (sampled) {
     b += (size_t)max_tiles * 8;
     b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
-    b += (kBlock / 64) * kDrawLdsPerWave;
+    if (!cached) b += (kBlock / 64) * kDrawLdsPerWave;
   }
   const size_t list = (size_t)P * (4 + esz), pend = (size_t)nsample * 4;
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
@@ -1041,12 +1050,12 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P)
   const int64_t seg_base = (int64_t)slot * cap;
   if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; }
-  unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED);
+  unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED, CACHED);
   double *tsum = reinterpret_cast<double *>(extra);
   uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
   unsigned char *after = SAMPLED ? reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) : extra;
-  unsigned char *draw0 = after;
-  if (SAMPLED) after += (kBlock / 64) * kDrawLdsPerWave;
+  unsigned char *draw0 = CACHED ? smem + list_scratch_offset(p) : after;  // (CACHED: over the staging scratch, see list_base_lds)
+  if (SAMPLED && !CACHED) after += (kBlock / 64) * kDrawLdsPerWave;
   T *list_h = reinterpret_cast<T *>(after);                       // h first: 8-byte aligned
   uint32_t *list_col = reinterpret_cast<uint32_t *>(list_h + P);
   uint32_t *pend = reinterpret_cast<uint32_t *>(after);           // phase C re-uses the list's memory
@@ -1197,7 +1206,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     if (tid == 0) next_tile = 0;
     __syncthreads();
     // ---- phase C: the draws inside the tiles ----
-    unsigned char *mine = draw0 + (size_t)wave * kDrawLdsPerWave;
+    unsigned char *mine = draw0 + (size_t)wave * (CACHED ? kCachedDrawLdsPerWave : kDrawLdsPerWave);
     DrawLds S;
     S.prefix = reinterpret_cast<double *>(mine);
     S.run = reinterpret_cast<volatile double *>(mine + (size_t)kOneTileCols * 8);
@@ -1232,12 +1241,18 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
         const double total = __shfl(incl, 63);
         double run = incl - ls;
         __builtin_amdgcn_wave_barrier();
+        uint32_t *hits2 = reinterpret_cast<uint32_t *>(mine + (size_t)kOneTileCols * 8);   // [cols / 2]: two 16-bit counts per word
+        uint32_t *negs = hits2 + kOneTileCols / 2;                                          // [cols / 32]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           run += w4[j];
           S.prefix[lane * 4 + j] = run;
-          S.cs[lane * 4 + j] = (c0 + j) | (((neg >> j) & 1u) << 31);
-          S.hits[lane * 4 + j] = 0u;
+        }
+        hits2[lane * 2] = 0u; hits2[lane * 2 + 1] = 0u;
+        {  // lane l holds the signs of columns 4 l .. 4 l + 3: eight lanes make a word
+          uint32_t word = neg << (4 * (lane & 7));
+          word |= __shfl_xor(word, 1); word |= __shfl_xor(word, 2); word |= __shfl_xor(word, 4);
+          if ((lane & 7) == 0) negs[lane >> 3] = word;
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t ncols = min((uint32_t)kOneTileCols, ncomb - t * kOneTileCols);
@@ -1253,21 +1268,22 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
           }
           if (lo >= ncols) lo = ncols - 1;
           while (lo > 0 && !(S.prefix[lo] > S.prefix[lo - 1])) --lo;
-          atomicAdd(&S.hits[lo], 1u);
+          atomicAdd(&hits2[lo >> 1], 1u << (16u * (lo & 1u)));  // (a column is drawn < 2^16 times: nsample < 2^16)
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t pos = info >> 16;
         if (o.debug & 256u) continue;
         for (uint32_t i0 = 0; i0 < ncols; i0 += 64) {
           const uint32_t idx = i0 + lane;
-          const uint32_t hc = idx < ncols ? S.hits[idx] : 0u;
+          const uint32_t hc = idx < ncols ? (hits2[idx >> 1] >> (16u * (idx & 1u))) & 0xffffu : 0u;
           const uint64_t m = __ballot(hc != 0u);
           if (hc) {
-            const uint32_t e = S.cs[idx], col = e & 0x7fffffffu;
+            const uint32_t col = t * kOneTileCols + idx;
+            const bool minus = (negs[idx >> 5] >> (idx & 31u)) & 1u;
             const uint32_t at = pos + __popcll(m & ((1ull << lane) - 1ull));
             o.srec_col[sbase + at] = (int32_t)col;
             const double v = scale * (double)hc;
-            o.srec_w[sbase + at] = (T)((e >> 31) ? -v : v);
+            o.srec_w[sbase + at] = (T)(minus ? -v : v);
             pend[at] = col;
           }
           pos += __popcll(m);
@@ -1478,15 +1494,20 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   const uint64_t seg_cap = (uint64_t)fixed + (uint64_t)io->cap_doubles;
   uint32_t P = 64;
   while (P < seg_cap && P < (1u << 20)) P <<= 1;
-  const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, P, (uint32_t)eps_sample);
+  static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
+  const bool want_cache = sampled && io->row_cache != nullptr && cache_env != 0;
+  const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, P, (uint32_t)eps_sample, want_cache);
   const bool list_fits = seg_cap <= 2048 && lds_list + 256 <= 160 * 1024;
   const bool use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024));
   // with a row cache (io->row_cache: [nbatch][ncomb] elements of the integral dtype) the draws read the row back instead of visiting the
   // drawn tiles a second time (PYNQS_OP_CACHE=0 ignores the buffer)
-  static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
-  const bool use_cache = sampled && use_list && io->row_cache != nullptr && cache_env != 0;
+  const bool use_cache = want_cache && use_list;
   const size_t lds = use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, wl_cap);
   if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
+  static const bool verbose = getenv("PYNQS_OP_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "pynqs_reduce_onepass: %s form%s, LDS %zu bytes per workgroup (walker tables %zu, max_tiles %u, list P %u), %u chunk(s) per walker\n",
+            use_list ? "LIST" : "look-back", use_cache ? " with row cache" : "", lds, (size_t)lds_fixed_bytes(p), max_tiles, P, nchunks);
   // eloc.py:257-264: with draws and eps <= 0 nothing is kept (every column can be drawn); without draws |H| >= eps as it stands
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
