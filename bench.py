@@ -721,7 +721,8 @@ class ReduceVmcStep(Workload):
         fe = self.front
         walker, col, w, link, _, drawn = fe.records()
         sel = walker < m
-        walker, col, w, link, drawn = walker[sel].cpu(), col[sel].cpu().long(), w[sel].cpu(), link[sel].cpu().long(), drawn[sel].cpu()
+        rows = fe.rows_of(link[sel]).cpu()
+        walker, col, w, drawn = walker[sel].cpu(), col[sel].cpu().long(), w[sel].cpu(), drawn[sel].cpu()
         co, ho = O.comb_hij_fused(self.x[:m].cpu().numpy(), self.h1.cpu().numpy(), self.h2.cpu().numpy(), self.sorb, self.nele, self.noA, self.noB)
         ho = torch.from_numpy(ho)
         keep = ho.abs() >= self.eps
@@ -733,7 +734,6 @@ class ReduceVmcStep(Workload):
         exact = exact and bool(torch.allclose(hits, hits.round(), atol=1e-6)) and not bool(keep[walker[drawn], col[drawn]].any())
         tot = torch.zeros(m, dtype=torch.float64).index_add_(0, walker[drawn], hits.round())
         exact = exact and bool((tot == self.eps_sample).all())
-        rows = fe.table_rows().cpu().long()[link]
         kets = torch.from_numpy(co).reshape(m, self.ncomb, -1)[walker, col]
         assert bool(torch.equal(fe.uniq_onv.cpu()[rows], kets)), "a record's link does not lead to its determinant"
         mod = type(self.module)(*(p.detach().cpu() for p in (self.module.params_weights, self.module.params_hidden_bias, self.module.params_visible_bias)))

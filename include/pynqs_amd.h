@@ -330,12 +330,14 @@ int pynqs_reduce_sample(const uint64_t *bra, int64_t nbatch, int sorb, int nele,
  *                                   psi_x[x] = A(x), from the records (io->rec_w / srec_w: any weights in the records' slot
  *                                   layout) and the values A of the distinct list (psi_unique) and of the table (psi_table);
  *                                   one wave per walker, fixed order of additions.
- * Record link: >= 0 slot of the de-duplication table (its row number is stored in the slot), <= -2 : table position
- * -(link + 2) of the wave-function table, -1 : no amplitude (capacity overflow). */
+ * Record link: >= 2^30 : row (link - 2^30) of the distinct list (the row was known when the record was written: the record's own new
+ * determinant, or one whose winner had already published its row); 0 .. 2^30 - 1 : slot of the de-duplication table (its row number is
+ * stored in the slot: the contraction looks it up); <= -2 : position -(link + 2) of the wave-function table; -1 : no amplitude
+ * (capacity overflow).  Which of the first two forms a record gets depends on the launch's timing; both lead to the same row. */
 typedef struct pynqs_reduce_io {
   int64_t cap_doubles;  /* in: compacted slots per segment after the fixed ones */
   int64_t cap_unique;   /* in: rows of uniq_onv / uniq_pm1 */
-  int64_t dedup_slots;  /* in: power of two >= 2 * cap_unique */
+  int64_t dedup_slots;  /* in: power of two >= 2 * cap_unique, <= 2^30 */
   int32_t *rec_col;     /* [segments][fixed + cap_doubles] column of the record, -1 = empty slot */
   void *rec_w;          /* T, same shape: <x|H|x'> */
   uint64_t *rec_onv;    /* same shape x len (may be NULL) */

@@ -30,6 +30,7 @@ constexpr uint32_t kStatMask = 0x3fffffffu;
 constexpr int kFixedHead = 8;             // slot 0: column 0; slots 1..6: unpaired doubles; 7: unused
 constexpr int kOneTileCols = 128 * PYNQS_U;
 constexpr uint32_t kProbeLimit = 512;     // a de-duplication table at most half full never needs that many
+constexpr int32_t kDirectLink = 1 << 30;  // link >= kDirectLink: row of the distinct list = link - kDirectLink (no look at the de-duplication slot)
 
 __device__ __forceinline__ uint64_t op_mix64(uint64_t z) {
   z += 0x9e3779b97f4a7c15ull;
@@ -201,11 +202,31 @@ __device__ __forceinline__ bool assign_row(const OnepassOut<T> &o, uint32_t s, i
     atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 4u);
     return false;
   }
-  reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN))[dedup_row_offset(LEN)] = r;
+  // (agent scope: other workgroups, on other XCDs, read the row of a determinant they find already inserted -- slot_row() -- to point their
+  // records at it directly; one that still reads -1 keeps the slot as its link and the contraction looks the row up)
+  __hip_atomic_store(reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN)) + dedup_row_offset(LEN), r, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int i = 0; i < LEN; ++i) o.uniq_onv[(size_t)r * LEN + i] = ket[i];
   if (o.uniq_parent) o.uniq_parent[r] = o.parent;
   return true;
+}
+
+// the row a de-duplication slot has been given so far (-1: none yet)
+template <int LEN, typename T>
+__device__ __forceinline__ int32_t slot_row(const OnepassOut<T> &o, uint32_t s) {
+  return __hip_atomic_load(reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN)) + dedup_row_offset(LEN), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The final link of a record whose determinant sits in de-duplication slot `link` (>= 0): the row itself when it is known -- this
+// lane's new row `mine`, or the row another record's winner has already written --, else the slot.  Half of the contraction's time was
+// the slot look-up: a dependent 4-byte gather from a 64 MB table in front of the amplitude gather.
+template <int LEN, typename T>
+__device__ __forceinline__ int32_t final_link(const OnepassOut<T> &o, int32_t link, int32_t mine) {
+  if (link < 0) return link;
+  const int32_t r = mine >= 0 ? mine : slot_row<LEN, T>(o, (uint32_t)link);
+  return r >= 0 && (uint32_t)r < o.ucap ? (r | kDirectLink) : link;
 }
 
 // The wave writes the +1/-1 rows of the lanes flagged `flag` (all lanes of the wave must call): one coalesced store per row.
@@ -790,8 +811,9 @@ __device__ __forceinline__ int32_t probe_amplitude(const OnepassOut<T> &o, const
 // The lanes of the WORKGROUP flagged `won` own new determinants (de-duplication slot `slot`): one global atomic for all of them,
 // then the slots' rows, the determinants and the +-1 rows.  Every thread of the block must call; contains barriers.
 template <int LEN, typename T>
-__device__ __forceinline__ void allocate_batch(const OnepassOut<T> &o, int sorb, bool won, uint32_t slot, const uint64_t (&ket)[LEN],
-                                               uint32_t *bw_cnt, int32_t *bw_base) {
+__device__ __forceinline__ int32_t allocate_batch(const OnepassOut<T> &o, int sorb, bool won, uint32_t slot, const uint64_t (&ket)[LEN],
+                                                  uint32_t *bw_cnt, int32_t *bw_base) {
+  int32_t mine = -1;  // the row this lane's determinant got
   const int lane = threadIdx.x & 63;
   const uint64_t m = __ballot(won);
   uint32_t woff = 0;
@@ -805,10 +827,12 @@ __device__ __forceinline__ void allocate_batch(const OnepassOut<T> &o, int sorb,
     const int32_t r = *bw_base + (int32_t)woff + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
     const bool ok = won && assign_row<LEN, T>(o, slot, r, ket);
     emit_rows<LEN, T>(o, sorb, ok, ket, r);
+    if (ok) mine = r;
   }
   __syncthreads();
   if (threadIdx.x == 0) *bw_cnt = 0u;
   __syncthreads();
+  return mine;
 }
 
 // The same for K records per thread (flags won[k], slots slot[k], kets ket[k]): ONE global atomic for up to K * blockDim new determinants.
@@ -816,7 +840,9 @@ __device__ __forceinline__ void allocate_batch(const OnepassOut<T> &o, int sorb,
 // paid once instead of four times (semi-stochastic kernel: -100 us per 8192 Fe2S2 walkers).
 template <int LEN, typename T, int K>
 __device__ __forceinline__ void allocate_batch_k(const OnepassOut<T> &o, int sorb, const bool (&won)[K], const uint32_t (&slot)[K],
-                                                 const uint64_t (&ket)[K][LEN], uint32_t *bw_cnt, int32_t *bw_base) {
+                                                 const uint64_t (&ket)[K][LEN], uint32_t *bw_cnt, int32_t *bw_base, int32_t (&rows)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) rows[k] = -1;
   const int lane = threadIdx.x & 63;
   uint32_t mine = 0;
 #pragma unroll
@@ -841,6 +867,7 @@ __device__ __forceinline__ void allocate_batch_k(const OnepassOut<T> &o, int sor
     for (int k = 0; k < K; ++k) {
       const bool ok = won[k] && assign_row<LEN, T>(o, slot[k], r, ket[k]);
       emit_rows<LEN, T>(o, sorb, ok, ket[k], r);
+      if (ok) rows[k] = r;
       r += won[k] ? 1 : 0;
     }
   }
@@ -1126,9 +1153,9 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
         for (int w = 0; w < LEN; ++w) o.rec_onv[g * LEN + w] = ket[w];
       }
       link = probe_amplitude<LEN, T>(o, ket, won);
-      o.rec_link[g] = link;
     }
-    allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
+    const int32_t mine = allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
+    if (i < n) o.rec_link[seg_base + i] = final_link<LEN, T>(o, link, mine);
   }
   if constexpr (SAMPLED) {
     const uint32_t ncomb = p.nsd + 1;
@@ -1300,14 +1327,17 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     // ---- the drawn records: kets, links, rows -- four draw slots per thread and round, one row allocation per round ----
     constexpr int K = 4;
     for (uint32_t i0 = 0; i0 < nsample; i0 += K * kBlock) {
+      constexpr int32_t kNoRecord = -0x7fffffff;
       bool won[K];
       uint32_t slot[K];
+      int32_t lk[K];
       uint64_t ket[K][LEN];
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const uint32_t i = i0 + k * kBlock + tid;
         won[k] = false;
         slot[k] = 0;
+        lk[k] = kNoRecord;
 #pragma unroll
         for (int w = 0; w < LEN; ++w) ket[k][w] = wk.w[w];
         const uint32_t col = i < nsample ? pend[i] : 0xffffffffu;
@@ -1321,12 +1351,17 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
 #pragma unroll
             for (int w = 0; w < LEN; ++w) o.srec_onv[at * LEN + w] = ket[k][w];
           }
-          const int32_t link = probe_amplitude<LEN, T>(o, ket[k], won[k]);
-          o.srec_link[at] = link;
-          slot[k] = (uint32_t)link;
+          lk[k] = probe_amplitude<LEN, T>(o, ket[k], won[k]);
+          slot[k] = (uint32_t)lk[k];
         }
       }
-      allocate_batch_k<LEN, T, K>(o, p.sorb, won, slot, ket, &bw_cnt, &bw_base);
+      int32_t mine[K];
+      allocate_batch_k<LEN, T, K>(o, p.sorb, won, slot, ket, &bw_cnt, &bw_base, mine);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const uint32_t i = i0 + k * kBlock + tid;
+        if (lk[k] != kNoRecord) o.srec_link[(int64_t)walker * nsample + i] = final_link<LEN, T>(o, lk[k], mine[k]);
+      }
     }
   }
 }
@@ -1353,7 +1388,10 @@ __global__ __launch_bounds__(kBlock) void reduce_contract_kernel(int64_t nbatch,
   auto amp = [&](int32_t link, double &re, double &im) {
     const double *src;
     int64_t at;
-    if (link >= 0) {
+    if (link >= kDirectLink) {
+      src = psi_u; at = link - kDirectLink;
+      if ((uint32_t)at >= ucap) { bad = true; re = im = 0.0; return; }
+    } else if (link >= 0) {
       const int32_t row = dedup_i32[(int64_t)link * slot_i32 + row_off];
       if (row < 0 || (uint32_t)row >= ucap) { bad = true; re = im = 0.0; return; }
       src = psi_u; at = row;
@@ -1471,7 +1509,7 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   if (!io->counters || !io->dedup_table || !io->uniq_onv || !io->rec_col || !io->rec_w || !io->rec_link || !io->seg_count ||
       (sampled && (!io->srec_col || !io->srec_w || !io->srec_link)))
     return set_error(PYNQS_EINVAL, "null pointer");
-  if (io->dedup_slots < 64 || (io->dedup_slots & (io->dedup_slots - 1)) || io->dedup_slots > (1ll << 31) || io->cap_unique < 1 ||
+  if (io->dedup_slots < 64 || (io->dedup_slots & (io->dedup_slots - 1)) || io->dedup_slots > (1ll << 30) || io->cap_unique < 1 ||
       2 * io->cap_unique > io->dedup_slots || io->cap_doubles < 0 || io->cap_doubles >= (1ll << 30))
     return set_error(PYNQS_EINVAL, "bad capacities (dedup_slots: power of two >= 2 * cap_unique)");
   if (io->pm1_dtype != PYNQS_F32 && io->pm1_dtype != PYNQS_F64) return set_error(PYNQS_EINVAL, "bad pm1_dtype");

@@ -174,6 +174,15 @@ class ReduceFrontEnd:
         """int32 view [dedup_slots]: the distinct-list row of every de-duplication slot (-1: empty)."""
         return self.table.view(self.dedup_slots, self.slot_i32)[:, self.row_off]
 
+    def rows_of(self, link: Tensor) -> Tensor:
+        """Distinct-list rows (int64) of record links >= 0: direct links (>= 2^30) carry the row, the others the de-duplication slot."""
+        link = link.long()
+        direct = link >= (1 << 30)
+        rows = torch.where(direct, link - (1 << 30), torch.zeros_like(link))
+        if not bool(direct.all()):
+            rows = torch.where(direct, rows, self.table_rows().long()[torch.where(direct, torch.zeros_like(link), link)])
+        return rows
+
     def records(self):
         """Flat view of the valid records, for the host-side algebra of the projected / multi-psi forms and for tests (synchronises):
         (walker int64[m], col int32[m], w[m], link int32[m], onv uint8[m, 8 len] or None, is_drawn bool[m]); kept records first

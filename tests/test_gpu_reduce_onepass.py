@@ -42,7 +42,7 @@ def _check_distinct(fe, nu, walker, onv, link, sorb):
 
     uniq = fe.uniq_onv[:nu]
     own = link >= 0
-    rows = fe.table_rows()[link[own].long()].long()
+    rows = fe.rows_of(link[own])
     assert int(rows.min()) >= 0 and int(rows.max()) < nu
     assert torch.equal(uniq[rows], onv[own])                                    # every record finds its determinant
     want = torch.unique(onv[own], dim=0)
@@ -88,7 +88,7 @@ def test_kept_records_are_exact(sorb, noA, noB, n, eps, fe2s2):
             amp = amp * torch.exp(1j * torch.rand(nu2, generator=g, dtype=torch.float64).cuda())
         e, px = fe.contract(amp)
         wk2, col2, ww, lk, _, _ = fe.records()
-        rows = fe.table_rows()[lk.long()].long()
+        rows = fe.rows_of(lk)
         num = torch.zeros(n, dtype=amp.dtype, device="cuda").index_add_(0, wk2, ww.to(amp.dtype) * amp[rows])
         first = col2 == 0
         p0 = torch.zeros(n, dtype=amp.dtype, device="cuda")
