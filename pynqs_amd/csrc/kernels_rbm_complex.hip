@@ -12,7 +12,9 @@
 // class's fast table x 4 of its slow table) with 8 complex running products:
 //   per hidden unit and lane: 12 ds_read_b128, 6 complex products for the pairs, 8 x (complex fma + complex product)
 //   = 88 f64 instructions per 8 columns (the real kernel: 40 per 16).
-// Resident rows only: sorb x num_hidden must fit the LDS (pynqs_eloc_crbm_supported), else callers take the module path.
+// When sorb x num_hidden rows do not fit the LDS the kernel runs WINDOWED (round 3), like the real-parameter kernel: the workgroup
+// streams q' through the LDS `hw` hidden units at a time, and in every round each wave keeps the 8 x 64 running products of ONE tile in
+// registers across the windows (two barriers per window; the rows of a window are rebuilt every round: ~1 % of a round's work).
 #include "detcore.h"
 #include "launch.h"
 #include "plan.h"
@@ -93,15 +95,17 @@ static inline CrbmBlocks make_crbm_blocks(const SDParams &p) {
 // LDS after the walker tables (16-byte aligned): q [sorb + 1][Hs] cplx | m [Hs] cplx | n4 [Hs] cplx | Cq [sorb + 2] cplx |
 // sh [Hs] double | hs [d1 + 2] double | rowaddr [sorb + 2] u32 | red [2 * 16] double, counters
 __host__ __device__ inline size_t crbm_q_offset(const SDParams &p) { return (lds_fixed_bytes(p) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t lds_bytes_crbm(const SDParams &p, const CrbmLayout &cl) {
-  return crbm_q_offset(p) + 16 * ((size_t)(p.sorb + 1) * cl.Hs + 2 * (size_t)cl.Hs + (size_t)(p.sorb + 2)) +
+// `hw`: hidden units of q' resident at a time (even): cl.Hloop (all of them) or the window of the WINDOWED kernel; row stride hw + 1
+__host__ __device__ inline size_t lds_bytes_crbm(const SDParams &p, const CrbmLayout &cl, uint32_t hw) {
+  return crbm_q_offset(p) + 16 * ((size_t)(p.sorb + 1) * (hw + 1) + 2 * (size_t)cl.Hs + (size_t)(p.sorb + 2)) +
          8 * ((size_t)cl.Hs + (size_t)(p.d1 + 2) + 1) + 4 * (((size_t)p.sorb + 2 + 3) & ~(size_t)3) + 8 * 32 + 16;
 }
 
-template <int LEN>
+template <int LEN, bool WINDOWED>
 __global__ __launch_bounds__(512) void eloc_crbm_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, CrbmLayout cl, CrbmBlocks B,
-                                                        uint32_t nchunks, const double *__restrict__ plan, const cplx *__restrict__ rbm,
-                                                        double log_scale, double *__restrict__ eloc, double *__restrict__ psi) {
+                                                        uint32_t nchunks, uint32_t hw, const double *__restrict__ plan,
+                                                        const cplx *__restrict__ rbm, double log_scale, double *__restrict__ eloc,
+                                                        double *__restrict__ psi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint64_t wg = blockIdx.x;
   const uint64_t walker = wg / nchunks;
@@ -110,14 +114,15 @@ __global__ __launch_bounds__(512) void eloc_crbm_kernel(const uint64_t *__restri
   const int nthreads = blockDim.x, nwaves = nthreads >> 6;
   const int sorb = p.sorb, H = cl.H, Hs = cl.Hs;
   const uint32_t K = (uint32_t)sorb >> 1;
+  const uint32_t stride = hw + 1;  // complex elements per q' row
   cplx *q = reinterpret_cast<cplx *>(smem + crbm_q_offset(p));
-  cplx *mm = q + (size_t)(sorb + 1) * Hs;
+  cplx *mm = q + (size_t)(sorb + 1) * stride;
   cplx *n4 = mm + Hs;
   cplx *Cq = n4 + Hs;
   double *sh = reinterpret_cast<double *>(Cq + (sorb + 2));
   double *hs = sh + Hs;
   uint32_t *rowaddr = reinterpret_cast<uint32_t *>(hs + (p.d1 + 2) + 1);
-  double *red = reinterpret_cast<double *>(smem + lds_bytes_crbm(p, cl) - (8 * 32 + 16));
+  double *red = reinterpret_cast<double *>(smem + lds_bytes_crbm(p, cl, hw) - (8 * 32 + 16));
   uint32_t *next_tile_p = reinterpret_cast<uint32_t *>(red + 32);
   uint32_t *next_single_p = next_tile_p + 1;
   if (tid == 0) { *next_tile_p = 0; *next_single_p = 0; }
@@ -172,32 +177,50 @@ __global__ __launch_bounds__(512) void eloc_crbm_kernel(const uint64_t *__restri
     }
   }
   __syncthreads();
-  // ---- phase B: q'[o][h] = (m_h rho_h)^(1/4) exp(4 s_h x_o W[h][o]), a wave per row, and sum_h s_h W[h][o]
+  // ---- phase B: q'[o][h] = (m_h rho_h)^(1/4) exp(4 s_h x_o W[h][o]) for the hidden units [h0, h0 + hw), a wave per row, and (with_sum:
+  // the window is all of them) sum_h s_h W[h][o]
   const cplx *__restrict__ E4 = rbm + cl.offE4p;
   const uint32_t dE4 = (uint32_t)(cl.offE4m - cl.offE4p);
   auto rbm_row = [&](uint32_t o) { return o < (uint32_t)sorb ? (o >> 1) + ((o & 1u) ? K : 0u) : (uint32_t)sorb; };
-  for (int o = wave; o <= sorb; o += nwaves) {
-    const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
-    cplx S = {0.0, 0.0};
-    for (int h = lane; h < Hs; h += 64) {
-      cplx v = {0.0, 0.0};
-      if (h < H) {
-        const double s = sh[h];
-        v = n4[h];
-        if (o < sorb) {
-          const uint32_t idx = (uint32_t)o * (uint32_t)Hs + (uint32_t)h;
-          v = cmul(v, E4[idx + ((s > 0.0) == occ ? 0u : dE4)]);
-          S += s * Wt[idx];
+  auto build_window = [&](uint32_t h0, bool with_sum) {
+    for (int o = wave; o <= sorb; o += nwaves) {
+      const bool occ = o < sorb && bit_of<LEN>(wk.w, o);
+      cplx S = {0.0, 0.0};
+      for (uint32_t j = lane; j < stride; j += 64) {
+        const uint32_t h = h0 + j;
+        cplx v = {0.0, 0.0};
+        if (j < hw && h < (uint32_t)H) {
+          const double s = sh[h];
+          v = n4[h];
+          if (o < sorb) {
+            const uint32_t idx = (uint32_t)o * (uint32_t)Hs + h;
+            v = cmul(v, E4[idx + ((s > 0.0) == occ ? 0u : dE4)]);
+            if (with_sum) S += s * Wt[idx];
+          }
         }
+        q[(size_t)rbm_row((uint32_t)o) * stride + j] = v;
       }
-      q[(size_t)rbm_row((uint32_t)o) * Hs + h] = v;
-    }
+      if (with_sum) {
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { S.x += __shfl_xor(S.x, d); S.y += __shfl_xor(S.y, d); }
-    if (lane == 0) Cq[o] = S;
+        for (int d = 32; d > 0; d >>= 1) { S.x += __shfl_xor(S.x, d); S.y += __shfl_xor(S.y, d); }
+        if (lane == 0) Cq[o] = S;
+      }
+    }
+  };
+  if constexpr (!WINDOWED) {
+    build_window(0u, true);
+  } else {
+    for (int o = wave; o <= sorb; o += nwaves) {  // sum_h s_h W[h][o] over ALL hidden units (the windows are built inside the rounds)
+      cplx S = {0.0, 0.0};
+      if (o < sorb)
+        for (int h = lane; h < H; h += 64) S += sh[h] * Wt[(uint32_t)o * (uint32_t)Hs + (uint32_t)h];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) { S.x += __shfl_xor(S.x, d); S.y += __shfl_xor(S.y, d); }
+      if (lane == 0) Cq[o] = S;
+    }
   }
   __syncthreads();
-  const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)crbm_q_offset(p), rowB = (uint32_t)Hs * 16u;
+  const uint32_t qbase = __builtin_amdgcn_groupstaticsize() + (uint32_t)crbm_q_offset(p), rowB = stride * 16u;
   for (int o = tid; o <= sorb; o += nthreads) {
     rowaddr[o] = qbase + rbm_row((uint32_t)o) * rowB;
     cplx c = {1.0, 0.0};
@@ -216,12 +239,19 @@ __global__ __launch_bounds__(512) void eloc_crbm_kernel(const uint64_t *__restri
   const double *__restrict__ Vab = plan + pl.offVab;
   const uint32_t my_tiles = B.ntiles > chunk ? (B.ntiles - chunk + nchunks - 1) / nchunks : 0;
   cplx esum = {0.0, 0.0};
-  for (;;) {
+  for (uint32_t round = 0;; ++round) {
     uint32_t lt = 0;
-    if (lane == 0) lt = atomicAdd(next_tile_p, 1u);
-    lt = __builtin_amdgcn_readfirstlane(lt);
-    if (lt >= my_tiles) break;
-    const uint32_t id = (chunk + lt * nchunks) * 64u + (uint32_t)lane;
+    bool active = true;  // (WINDOWED: wave-uniform; a wave without a tile still meets the round's barriers)
+    if constexpr (WINDOWED) {
+      if (round * (uint32_t)nwaves >= my_tiles) break;  // workgroup-uniform
+      lt = round * (uint32_t)nwaves + (uint32_t)wave;
+      active = lt < my_tiles;
+    } else {
+      if (lane == 0) lt = atomicAdd(next_tile_p, 1u);
+      lt = __builtin_amdgcn_readfirstlane(lt);
+      if (lt >= my_tiles) break;
+    }
+    const uint32_t id = active ? (chunk + lt * nchunks) * 64u + (uint32_t)lane : 0xffffffffu;
     int cls = 4;
     uint32_t bid = 0, nbf = 1, offF = 0, offS = 0, nF = 1, nS = 1;
     MagicDiv dv = B.dv[0];
@@ -236,39 +266,52 @@ __global__ __launch_bounds__(512) void eloc_crbm_kernel(const uint64_t *__restri
     for (int i = 0; i < 2; ++i) ef[i] = real_fast ? L.tab[offF + min(2 * bf + i, nF - 1)] : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) es[j] = real_slow ? L.tab[offS + min(4 * bs + j, nS - 1)] : 0u;
-    uint32_t rb[12];  // LDS addresses of the q' rows: fast entry i -> rb[2i], rb[2i+1]; slow entry j -> rb[4+2j], rb[5+2j]
+    uint32_t rb0[12];  // LDS addresses of the q' rows: fast entry i -> rb[2i], rb[2i+1]; slow entry j -> rb[4+2j], rb[5+2j]
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      rb[2 * i] = rowaddr[real_fast ? (ef[i] & 0xff) : (uint32_t)sorb];
-      rb[2 * i + 1] = rowaddr[real_fast ? ((ef[i] >> 8) & 0xff) : (uint32_t)sorb];
+      rb0[2 * i] = rowaddr[real_fast ? (ef[i] & 0xff) : (uint32_t)sorb];
+      rb0[2 * i + 1] = rowaddr[real_fast ? ((ef[i] >> 8) & 0xff) : (uint32_t)sorb];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      rb[4 + 2 * j] = rowaddr[real_slow ? (es[j] & 0xff) : (uint32_t)sorb];
-      rb[5 + 2 * j] = rowaddr[real_slow ? ((es[j] >> 8) & 0xff) : (uint32_t)sorb];
+      rb0[4 + 2 * j] = rowaddr[real_slow ? (es[j] & 0xff) : (uint32_t)sorb];
+      rb0[5 + 2 * j] = rowaddr[real_slow ? ((es[j] >> 8) & 0xff) : (uint32_t)sorb];
     }
     cplx acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = cplx{1.0, 0.0};
-    for (uint32_t h = 0; h < (uint32_t)cl.Hloop; h += 2) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        cplx v[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = *reinterpret_cast<lds_ccplx *>(rb[k] + 16 * c);
-        const cplx m = mm[h + c];
-        cplx gf[2], gs[4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) gf[i] = cmul(v[2 * i], v[2 * i + 1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gs[j] = cmul(v[4 + 2 * j], v[5 + 2 * j]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[4 * i + j] = cmul(acc[4 * i + j], cfma(gf[i], gs[j], m));
+    for (uint32_t h0 = 0; h0 < (uint32_t)cl.Hloop; h0 += hw) {
+      if constexpr (WINDOWED) {
+        __syncthreads();  // everybody is done with the previous window
+        build_window(h0, false);
+        __syncthreads();
       }
+      if (active) {
+        uint32_t rb[12];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) rb[k] += 32;
+        for (int k = 0; k < 12; ++k) rb[k] = rb0[k];
+        const uint32_t wlen = min(hw, (uint32_t)cl.Hloop - h0);
+        for (uint32_t j = 0; j < wlen; j += 2) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            cplx v[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) v[k] = *reinterpret_cast<lds_ccplx *>(rb[k] + 16 * c);
+            const cplx m = mm[h0 + j + c];
+            cplx gf[2], gs[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gf[i] = cmul(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) gs[jj] = cmul(v[4 + 2 * jj], v[5 + 2 * jj]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) acc[4 * i + jj] = cmul(acc[4 * i + jj], cfma(gf[i], gs[jj], m));
+          }
+#pragma unroll
+          for (int k = 0; k < 12; ++k) rb[k] += 32;
+        }
+      }
     }
     if (cls < 4) {
       cplx cf[2], cs[4];
@@ -346,6 +389,24 @@ using namespace pynqs;
 
 static constexpr size_t kCrbmMaxLds = 158 * 1024;
 
+// hidden units of q' resident at a time: all of them (cl.Hloop) if they fit, else the largest even window that leaves room for two
+// workgroups per CU when it can (PYNQS_CRBM_WINDOW forces a window, for tests); 0: not even a window of two fits
+static uint32_t crbm_window(const SDParams &p, const CrbmLayout &cl) {
+  const int win_env = getenv("PYNQS_CRBM_WINDOW") ? atoi(getenv("PYNQS_CRBM_WINDOW")) : 0;  // (read per call: tests switch it)
+  if (win_env >= 2) {
+    const uint32_t hw = (uint32_t)win_env & ~1u;
+    return hw >= (uint32_t)cl.Hloop ? (uint32_t)cl.Hloop : (lds_bytes_crbm(p, cl, hw) <= kCrbmMaxLds ? hw : 0u);
+  }
+  if (lds_bytes_crbm(p, cl, (uint32_t)cl.Hloop) <= kCrbmMaxLds) return (uint32_t)cl.Hloop;
+  const size_t fixed = lds_bytes_crbm(p, cl, 0u), row = 16 * (size_t)(p.sorb + 1);
+  for (size_t budget : {(size_t)(79 * 1024), kCrbmMaxLds}) {
+    if (fixed + 3 * row > budget) continue;
+    uint32_t hw = (uint32_t)((budget - fixed) / row - 1) & ~1u;
+    if (hw >= 16u || budget == kCrbmMaxLds) return hw >= 2u ? hw : 0u;
+  }
+  return 0u;
+}
+
 extern "C" int64_t pynqs_crbm_table_bytes(int sorb, int nhidden) {
   CrbmLayout cl;
   if (!make_crbm_layout(sorb, nhidden, &cl)) return -1;
@@ -357,7 +418,7 @@ extern "C" int pynqs_eloc_crbm_supported(int sorb, int nele, int noA, int noB, i
   PlanLayout pl;
   CrbmLayout cl;
   if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl) || !make_crbm_layout(sorb, nhidden, &cl)) return 0;
-  return lds_bytes_crbm(p, cl) <= kCrbmMaxLds ? 1 : 0;
+  return crbm_window(p, cl) > 0 ? 1 : 0;
 }
 
 extern "C" int pynqs_crbm_table_build(const double *weights, const double *hidden_bias, const double *visible_bias, int sorb, int nhidden,
@@ -385,8 +446,10 @@ extern "C" int pynqs_eloc_crbm(const uint64_t *bra, int64_t nbatch, int sorb, in
   if (nbatch < 0 || nbatch > 0x3fffffffll) return set_error(PYNQS_EINVAL, "bad nbatch");
   if (nbatch == 0) return PYNQS_OK;
   if (!bra || !plan || !crbm_table || !eloc) return set_error(PYNQS_EINVAL, "null pointer");
-  const size_t lds = lds_bytes_crbm(p, cl);
-  if (lds > kCrbmMaxLds) return set_error(PYNQS_EINVAL, "sorb x num_hidden complex rows do not fit the LDS (pynqs_eloc_crbm_supported)");
+  const uint32_t hw = crbm_window(p, cl);
+  if (hw == 0) return set_error(PYNQS_EINVAL, "the per-hidden-unit arrays of this RBM do not fit the LDS (pynqs_eloc_crbm_supported)");
+  const bool windowed = hw < (uint32_t)cl.Hloop;
+  const size_t lds = lds_bytes_crbm(p, cl, hw);
   const CrbmBlocks B = make_crbm_blocks(p);
   uint32_t nchunks = 1;  // few walkers: a walker's tiles over several workgroups (each repeats the per-walker set-up)
   if (nbatch < 1024) {
@@ -412,10 +475,10 @@ extern "C" int pynqs_eloc_crbm(const uint64_t *bra, int64_t nbatch, int sorb, in
   if (blk_env == 128 || blk_env == 256 || blk_env == 512) threads = (uint32_t)blk_env;
   const int len = (sorb - 1) / 64 + 1;
   DISPATCH_LEN(len, {
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&eloc_crbm_kernel<LEN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds) != hipSuccess)
+    auto kfn = windowed ? eloc_crbm_kernel<LEN, true> : eloc_crbm_kernel<LEN, false>;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return check_launch("hipFuncSetAttribute");
-    hipLaunchKernelGGL((eloc_crbm_kernel<LEN>), dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, cl, B, nchunks, (const double *)plan,
+    hipLaunchKernelGGL(kfn, dim3((uint32_t)grid), dim3(threads), lds, st, bra, p, pl, cl, B, nchunks, hw, (const double *)plan,
                        (const cplx *)crbm_table, log_scale, eloc, psi);
   });
   return check_launch("eloc_crbm");

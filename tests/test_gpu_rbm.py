@@ -235,10 +235,12 @@ def test_complex_rbm_matches_reference_python(cx, fe2s2):
 
 
 @pytest.mark.parametrize("sorb,noA,noB,H,n", [(8, 2, 2, 5, 36), (12, 3, 2, 24, 40), (16, 5, 3, 33, 20), (4, 1, 0, 6, 2), (66, 3, 4, 40, 7),
-                                              (130, 3, 2, 30, 4), (40, 15, 15, 96, 2)])
+                                              (130, 3, 2, 30, 4), (40, 15, 15, 96, 2), (120, 4, 4, 240, 2), (184, 2, 2, 368, 2),
+                                              (66, 2, 2, 700, 3), (40, 6, 5, 1001, 2)])
 def test_complex_rbm_random_systems(cx, sorb, noA, noB, H, n):
     """pynqs_eloc_crbm on 1-3 ONV words, unequal alpha / beta, theta of both signs of the real part, against numpy on the oracle's
-    comb / Hmat (ratios of prod cosh, complex128)."""
+    comb / Hmat (ratios of prod cosh, complex128).  The last four do not fit the LDS: the WINDOWED kernel (round 3; sorb 120 x 240 is
+    VERDICT round 2's example), windows of 38, 24, 70 and 150 hidden units."""
     from oracle import oracle
 
     h1, h2 = synth_integrals(sorb)
@@ -255,7 +257,7 @@ def test_complex_rbm_random_systems(cx, sorb, noA, noB, H, n):
     ax = (xs @ vb).reshape(n, -1)
     ratio = np.exp(ax - ax[:, :1]) * np.prod(np.cosh(th) / np.cosh(th[:, :1]), axis=-1)
     e_ref = (hm * ratio).sum(1)
-    p_ref = np.exp(ax[:, 0]) * np.prod(2 * np.cosh(th[:, 0]), axis=-1)
+    p_ref = np.exp(ax[:, 0] + np.log(2 * np.cosh(th[:, 0])).sum(-1))
     tab = cx.CRBMTable(_dev(W), _dev(hb), _dev(vb))
     e, p = cx.eloc_crbm(_dev(bra_cpu), _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
     np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=0, atol=TOL, err_msg=f"sum |H| |ratio| max = {float((np.abs(hm) * np.abs(ratio)).sum(1).max()):.6g} Ha")
@@ -312,38 +314,66 @@ def test_end_to_end_vmc_lowers_the_energy():
     assert hist[-1] - e0 < 0.6 * (hist[0] - e0)
 
 
+def test_complex_rbm_windows_match_resident_rows(cx, fe2s2, monkeypatch):
+    """The windowed complex-parameter kernel against the resident one on the Fe2S2 fixture's parameters: the same factors multiplied in the
+    same order, so the same bits, for windows that divide the 40 hidden units and windows that do not."""
+    c = golden("eloc_complex_module.npz")
+    x = _dev(c["x"])
+    h1e, h2e = _dev(fe2s2["h1e"]), _dev(fe2s2["h2e"])
+    tab = cx.CRBMTable(_dev(c["Wc"]), _dev(c["hbc"]), _dev(c["vbc"]))
+    monkeypatch.delenv("PYNQS_CRBM_WINDOW", raising=False)
+    e0, p0 = cx.eloc_crbm(x, h1e, h2e, tab, 40, 30, 15, 15)
+    for w in ("2", "6", "8", "14", "38"):
+        monkeypatch.setenv("PYNQS_CRBM_WINDOW", w)
+        e, p = cx.eloc_crbm(x, h1e, h2e, tab, 40, 30, 15, 15)
+        assert torch.equal(p, p0)
+        np.testing.assert_allclose(e.cpu().numpy(), e0.cpu().numpy(), rtol=0, atol=1e-11)  # (which tile a wave gets differs: the order of the final sum)
+
+
 def test_complex_rbm_edge_cases(cx):
-    """Rows beyond the LDS: the C entry refuses (no silent wrong answer) and the energy layer takes the module path; empty batches;
+    """Per-hidden-unit arrays beyond the LDS: the C entry refuses (no silent wrong answer) and the energy layer takes the module path; empty batches;
     the Green's-function row refuses the complex-valued phase flavour."""
     from oracle import oracle
     from pynqs_amd import _native as N, energy, public_function as pf
     from pynqs_amd.rbm import ComplexRBM
 
-    sorb, noA, noB, H, n = 66, 2, 2, 700, 3
-    assert N.lib().pynqs_eloc_crbm_supported(sorb, noA + noB, noA, noB, H) == 0
+    sorb, noA, noB, n = 66, 2, 2, 3
+    assert N.lib().pynqs_eloc_crbm_supported(sorb, noA + noB, noA, noB, 700) == 1    # (windowed since round 3)
+    assert N.lib().pynqs_eloc_crbm_supported(sorb, noA + noB, noA, noB, 4000) == 0   # the per-hidden-unit arrays alone: 4000 x 56 bytes
     h1, h2 = synth_integrals(sorb)
     bra = oracle.pm01_to_onv(rand_occ(n, sorb, noA, noB, seed=5), sorb)
-    g = np.random.default_rng(5)
-    W = 0.02 * (g.random((H, sorb, 2)) - 0.5); hb = 0.5 * (g.random((H, 2)) - 0.5); vb = 0.1 * (g.random((sorb, 2)) - 0.5)
-    tab = cx.CRBMTable(_dev(W), _dev(hb), _dev(vb))
     x = _dev(bra.view(np.uint8).reshape(n, -1))
-    with pytest.raises(RuntimeError, match="LDS"):
-        cx.eloc_crbm(x, _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
+    comb, hm = oracle.comb_hij_fused(bra, h1, h2, sorb, noA + noB, noA, noB)
+    xs = oracle.onv_to_pm1(comb.reshape(-1, comb.shape[-1]), sorb)
     old = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
-        m = ComplexRBM(_dev(W), _dev(hb), _dev(vb)).cuda()
-        ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, sorb, x.device, torch.complex128)  # noqa: E731
-        el, _, ps, _ = energy.local_energy(x, _dev(h1), _dev(h2), m, ab, sorb, noA + noB, noA, noB, dtype=torch.complex128)
+        for H in (4000, 700):
+            g = np.random.default_rng(5)
+            W = 0.02 * (g.random((H, sorb, 2)) - 0.5); hb = 0.5 * (g.random((H, 2)) - 0.5); vb = 0.1 * (g.random((sorb, 2)) - 0.5)
+            tab = cx.CRBMTable(_dev(W), _dev(hb), _dev(vb))
+            m = ComplexRBM(_dev(W), _dev(hb), _dev(vb)).cuda()
+            ab = lambda xx, func: pf.ansatz_batch(func, xx, 100000, sorb, x.device, torch.complex128)  # noqa: E731
+            calls = []
+            orig = energy.CX.eloc_crbm
+            energy.CX.eloc_crbm = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            try:
+                if H == 4000:
+                    with pytest.raises(RuntimeError, match="LDS"):
+                        cx.eloc_crbm(x, _dev(h1), _dev(h2), tab, sorb, noA + noB, noA, noB)
+                    calls.clear()
+                el, _, ps, _ = energy.local_energy(x, _dev(h1), _dev(h2), m, ab, sorb, noA + noB, noA, noB, dtype=torch.complex128)
+            finally:
+                energy.CX.eloc_crbm = orig
+            assert len(calls) == (0 if H == 4000 else 1)  # module path (2^4000 overflows there, as in the reference) / windowed kernel
+            if H == 700:
+                Wc, hc, vc = W[..., 0] + 1j * W[..., 1], hb[:, 0] + 1j * hb[:, 1], vb[:, 0] + 1j * vb[:, 1]
+                th = (xs @ Wc.T + hc).reshape(n, -1, H)
+                ax = (xs @ vc).reshape(n, -1)
+                ratio = np.exp(ax - ax[:, :1]) * np.exp((np.log(2 * np.cosh(th)) - np.log(2 * np.cosh(th[:, :1]))).sum(-1))
+                np.testing.assert_allclose(el.cpu().numpy(), (hm * ratio).sum(1), rtol=0, atol=1e-8 * max(1.0, float(np.abs(hm).sum(1).max())))
     finally:
         torch.set_default_dtype(old)
-    comb, hm = oracle.comb_hij_fused(bra, h1, h2, sorb, noA + noB, noA, noB)
-    xs = oracle.onv_to_pm1(comb.reshape(-1, comb.shape[-1]), sorb)
-    Wc, hc, vc = W[..., 0] + 1j * W[..., 1], hb[:, 0] + 1j * hb[:, 1], vb[:, 0] + 1j * vb[:, 1]
-    th = (xs @ Wc.T + hc).reshape(n, -1, H)
-    ax = (xs @ vc).reshape(n, -1)
-    ratio = np.exp(ax - ax[:, :1]) * np.exp((np.log(2 * np.cosh(th)) - np.log(2 * np.cosh(th[:, :1]))).sum(-1))
-    np.testing.assert_allclose(el.cpu().numpy(), (hm * ratio).sum(1), rtol=0, atol=1e-8 * max(1.0, float(np.abs(hm).sum(1).max())))
     # empty batch
     small = cx.CRBMTable(_dev(W[:8, :8]), _dev(hb[:8]), None)
     e0, p0 = cx.eloc_crbm(torch.empty((0, 8), dtype=torch.uint8, device="cuda"), _dev(synth_integrals(8)[0]), _dev(synth_integrals(8)[1]), small, 8, 4, 2, 2)
