@@ -597,12 +597,13 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
       const uint32_t npair = nA * nB, first = item * kRanks;
       const uint32_t q64 = 64u / nA, r64 = 64u - q64 * nA;
       uint32_t i = (first + (uint32_t)lane) / nA, j = first + (uint32_t)lane - i * nA;
-      uint32_t rr[4];
+      uint32_t rr[4], ff[4], ss[4];
       bool pass[4];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const uint32_t m = first + 64u * g4 + (uint32_t)lane;
         const uint32_t slow = listB[min(i, nB - 1u)], f = listA[j];
+        ff[g4] = f; ss[g4] = slow;
         const uint32_t r = p.d3 + slow * (uint32_t)p.nSa + f;  // (no rotation in this class)
         rr[g4] = TWO ? cand.pack(2, slow, f) : r;
         const uint32_t z = zx ^ cand.flipped_at((uint32_t)p.offSa + f) ^ cand.flipped_at((uint32_t)p.offSb + slow);
@@ -613,6 +614,24 @@ __global__ __launch_bounds__(BLOCK) void eloc_sample_space_filtered_kernel(const
       }
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
+        // Most pairs of the two lists are in the table when it is a product of string sets (Fe2S2's CI space: all of them): a group
+        // with at least half of its lanes passing is evaluated where it stands -- table entries at hand, no queue, no rank decoding
+        // (0.145 -> 0.142 ms: the evaluation itself -- hash, probe, integral and psi gathers -- is what costs); sparser groups wait in the
+        // queue for company, as everywhere else.
+        const uint64_t pm = __ballot(pass[g4]);
+        if (!TWO && __popcll(pm) >= 32) {
+          double h = 0.0;
+          int64_t pos = -1;
+          if (pass[g4]) {
+            uint64_t ket[LEN];
+            h = cand.double_from_entries(L.tab[(uint32_t)p.offSa + ff[g4]], L.tab[(uint32_t)p.offSb + ss[g4]], true, plan + pl.offVab, 0x7fffu,
+                                         (uint32_t)(pl.K * pl.K), ket);
+            if (flip && spin_flip_ket<LEN>(ket)) h = -h;
+            pos = hash_find<LEN>(table, (uint64_t)cap, ket);
+          }
+          cand.add(h, pos);
+          continue;
+        }
         cand.template park<false, 1>(rr[g4], pass[g4]);
         if constexpr (!TWO) cand.template pump<false>();
       }
