@@ -404,14 +404,17 @@ int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const double *we
  *   pynqs_rbm_forward_children     : psi[r] for r < min(*count_dev, n) (count_dev may be NULL: all n rows; rows past the count are left alone)
  *   pynqs_rbm_forward_children_supported : 1 if the factor table ((2 sorb + 1) x (nhidden + 2) entries) fits 64 KB of LDS, else 0: the
  *                                    caller then uses pynqs_rbm_forward
- * Flavours and parameter layouts as pynqs_rbm_forward; |Re theta_h| must stay below ~350 (exp(-2 theta) is formed).  Values agree with
- * pynqs_rbm_forward to rounding (typically 1e-14 relative; a factor 2cosh(theta_h) near zero amplifies it).                           */
+ * Flavours and parameter layouts as pynqs_rbm_forward.  exp(-2 theta_h) is formed for the parents: if some Re theta_h < -340 the prepare
+ * step raises a flag in the table and pynqs_rbm_forward_children computes every row from scratch instead (the plain kernel, launched
+ * behind the children kernel; it returns at once when the flag is down).  Values agree with pynqs_rbm_forward to rounding (typically
+ * 1e-14 relative; a factor 2cosh(theta_h) near zero amplifies it).                                                                      */
 int64_t pynqs_rbm_children_table_bytes(int64_t nwalkers, int sorb, int nhidden, int flavour);
 int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalkers, int sorb, const double *weights, const double *hidden_bias,
                                const double *visible_bias, int nhidden, int flavour, void *table, void *stream);
 int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const int32_t *count_dev, const int32_t *parent,
-                               const uint64_t *walkers, int64_t nwalkers, const void *table, int sorb, int nhidden, int flavour,
-                               double *psi, void *stream);
+                               const uint64_t *walkers, int64_t nwalkers, const void *table, int sorb, const double *weights,
+                               const double *hidden_bias, const double *visible_bias, int nhidden, int flavour, double *psi,
+                               void *stream);
 int pynqs_rbm_forward_children_supported(int sorb, int nhidden, int flavour);
 
 int64_t pynqs_rbm_grad_workspace(int64_t n, int sorb, int nhidden, int flavour);

@@ -604,7 +604,8 @@ def rbm_forward_children(onv: Tensor, parent: Tensor, walkers: Tensor, weights: 
     out_c = rbm_type in ("pRBM", "complex")
     psi = out if out is not None else torch.empty(n, dtype=torch.complex128 if out_c else torch.float64, device=dev)
     N.check(N.lib().pynqs_rbm_forward_children(onv.contiguous().data_ptr(), n, count.data_ptr() if count is not None else None, parent.data_ptr(),
-                                               wk.data_ptr(), nw, table.data_ptr(), sorb, H, flav, psi.data_ptr(), st), "pynqs_rbm_forward_children")
+                                               wk.data_ptr(), nw, table.data_ptr(), sorb, W.data_ptr(), hb.data_ptr(),
+                                               vb.data_ptr() if vb is not None else None, H, flav, psi.data_ptr(), st), "pynqs_rbm_forward_children")
     return psi
 
 

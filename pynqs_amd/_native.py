@@ -89,7 +89,7 @@ SIGNATURES.update({
     "pynqs_rbm_forward": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_rbm_children_table_bytes": (_i64, [_i64, _int, _int, _int]),
     "pynqs_rbm_children_prepare": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _int, _int, _vp, _vp]),
-    "pynqs_rbm_forward_children": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp]),
+    "pynqs_rbm_forward_children": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_rbm_forward_children_supported": (_int, [_int, _int, _int]),
     "pynqs_rbm_grad_workspace": (_i64, [_i64, _int, _int, _int]),
     "pynqs_rbm_grad": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _int, _int, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

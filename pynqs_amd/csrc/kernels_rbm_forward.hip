@@ -80,8 +80,13 @@ __device__ __forceinline__ void write_psi(double *__restrict__ psi, int64_t i, c
 template <int LEN, int FLAVOUR>
 __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__restrict__ onv, int64_t n, int sorb, int H,
                                                              const double *__restrict__ W, const double *__restrict__ hb,
-                                                             const double *__restrict__ vb, double *__restrict__ psi) {
+                                                             const double *__restrict__ vb, double *__restrict__ psi,
+                                                             const int32_t *__restrict__ count_dev, const double *__restrict__ only_if) {
   constexpr bool CPLX = FLAVOUR == PYNQS_RBM_COMPLEX;
+  // (the children path's fall-back: this launch does something only if the table's flag says the parents were out of range)
+  if (only_if && *only_if == 0.0) return;
+  if (count_dev) n = min((int64_t)max(*count_dev, 0), n);
+  if ((int64_t)blockIdx.x * kBlock >= n) return;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t row = i < n ? i : n - 1;  // (idle lanes repeat the last determinant: the parameter loads below must stay wave-uniform)
   uint64_t ket[LEN];
@@ -134,7 +139,10 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__r
 //   parents [nwalkers][H + 2] : q_h(x) for h < H, then sum_h theta_h(x), then a.x
 //   factors [2 sorb + 1][HP]  : row 2 o (x'_o = +1) / 2 o + 1 (x'_o = -1): exp(-+4 W_ho) for h < H, +-2 sum_h W_ho, +-2 a_o;
 //                               the last row (1, ..., 1, 0, 0) stands for "no flip"; HP = H + 2 made odd (rows start in different banks)
-// all entries real or (re, im) by the flavour.  |Re theta| must stay below ~350 (exp(-2 theta) is formed, not exp(-2 |theta|)).
+//   flag    one double after the factors: non-zero if some parent has Re theta_h < -340, where q_h = exp(-2 theta_h) leaves the range of a
+//           double: the children kernel then does nothing and the plain forward kernel, launched behind it, computes every row from
+//           scratch (it returns at once otherwise)
+// all entries real or (re, im) by the flavour.
 __host__ __device__ inline int children_hp(int H) { return (H + 2) | 1; }
 
 template <bool CPLX>
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(kBlock) void rbm_children_factors_kernel(int sorb, 
   constexpr int C = CPLX ? 2 : 1;
   const int HP = children_hp(H);
   const int idx = blockIdx.x * kBlock + threadIdx.x;
+  if (idx == 0) factors[(size_t)(2 * sorb + 1) * HP * C] = 0.0;  // the flag (the parents kernel, launched next, may raise it)
   if (idx >= (2 * sorb + 1) * HP) return;
   const int row = idx / HP, h = idx - row * HP, o = row >> 1;
   const double sign = (row & 1) ? -1.0 : 1.0;  // x'_o
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void rbm_children_parents_kernel(const uint
 #pragma unroll
   for (int j = 0; j < kHChunk; ++j) {
     if (h0 + j < H && i < n) {
+      if (!(tr[j] > -340.0)) const_cast<double *>(factors)[(size_t)(2 * sorb + 1) * children_hp(H) * C] = 1.0;  // (also for nan)
       const double m = exp(-2.0 * tr[j]);
       if constexpr (CPLX) {
         double sn, cs;
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(kChildBlock) void rbm_forward_children_kernel(const
   constexpr int C = CPLX ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double wl[];
   const int HP = children_hp(H);
+  if (factors[(size_t)(2 * sorb + 1) * HP * C] != 0.0) return;  // (workgroup-uniform) parents out of range: the plain kernel takes over
   for (int idx = threadIdx.x; idx < (2 * sorb + 1) * HP * C; idx += kChildBlock) wl[idx] = factors[idx];
   __syncthreads();
   int64_t cnt = n;
@@ -348,7 +359,7 @@ extern "C" int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const
   const int len = (sorb - 1) / 64 + 1;
   const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
   hipStream_t st = (hipStream_t)stream;
-#define PYNQS_RF(F) hipLaunchKernelGGL((rbm_forward_kernel<LEN, F>), dim3(grid), dim3(kBlock), 0, st, onv, n, sorb, nhidden, weights, hidden_bias, visible_bias, psi)
+#define PYNQS_RF(F) hipLaunchKernelGGL((rbm_forward_kernel<LEN, F>), dim3(grid), dim3(kBlock), 0, st, onv, n, sorb, nhidden, weights, hidden_bias, visible_bias, psi, (const int32_t *)nullptr, (const double *)nullptr)
   DISPATCH_LEN(len, {
     switch (flavour) {
       case PYNQS_RBM_REAL: PYNQS_RF(PYNQS_RBM_REAL); break;
@@ -377,7 +388,7 @@ extern "C" int pynqs_rbm_forward_children_supported(int sorb, int nhidden, int f
 extern "C" int64_t pynqs_rbm_children_table_bytes(int64_t nwalkers, int sorb, int nhidden, int flavour) {
   if (nwalkers < 0 || sorb < 1 || sorb > kMaxSorb || nhidden < 1 || !children_flavour_ok(flavour)) return -1;
   const int64_t c = flavour == PYNQS_RBM_COMPLEX ? 16 : 8;
-  return nwalkers * (nhidden + 2) * c + (int64_t)children_lds_bytes(sorb, nhidden, flavour);
+  return nwalkers * (nhidden + 2) * c + (int64_t)children_lds_bytes(sorb, nhidden, flavour) + 8;
 }
 
 extern "C" int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalkers, int sorb, const double *weights, const double *hidden_bias,
@@ -410,14 +421,15 @@ extern "C" int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalk
 }
 
 extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const int32_t *count_dev, const int32_t *parent,
-                                          const uint64_t *walkers, int64_t nwalkers, const void *table, int sorb, int nhidden, int flavour,
-                                          double *psi, void *stream) {
+                                          const uint64_t *walkers, int64_t nwalkers, const void *table, int sorb, const double *weights,
+                                          const double *hidden_bias, const double *visible_bias, int nhidden, int flavour, double *psi,
+                                          void *stream) {
   pynqs::DeviceScope device_scope_(onv);
   if (n < 0 || n > 0x7fffffffll * kBlock || nwalkers < 0 || sorb < 1 || sorb > kMaxSorb || nhidden < 1) return set_error(PYNQS_EINVAL, "bad n/sorb/nhidden");
   if (!pynqs_rbm_forward_children_supported(sorb, nhidden, flavour))
     return set_error(PYNQS_EINVAL, "rbm_forward_children: unsupported (bad flavour, or the factor table exceeds the LDS: use pynqs_rbm_forward)");
   if (n == 0) return PYNQS_OK;
-  if (!onv || !parent || !walkers || !table || !psi || nwalkers == 0) return set_error(PYNQS_EINVAL, "null pointer");
+  if (!onv || !parent || !walkers || !table || !psi || !weights || !hidden_bias || nwalkers == 0) return set_error(PYNQS_EINVAL, "null pointer");
   const int len = (sorb - 1) / 64 + 1;
   int64_t blocks = (n + kChildBlock - 1) / kChildBlock;
   if (blocks > 1024) blocks = 1024;  // (a workgroup copies the factor table once and strides over the rows)
@@ -436,5 +448,18 @@ extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const 
     }
   });
 #undef PYNQS_RC
+  // the fall-back: every row from scratch if (and only if) the table's flag is up
+  const double *flag = factors + (size_t)(2 * sorb + 1) * (size_t)children_hp(nhidden) * (flavour == PYNQS_RBM_COMPLEX ? 2 : 1);
+  const uint32_t gridf = (uint32_t)((n + kBlock - 1) / kBlock);
+#define PYNQS_RF(F) hipLaunchKernelGGL((rbm_forward_kernel<LEN, F>), dim3(gridf), dim3(kBlock), 0, st, onv, n, sorb, nhidden, weights, hidden_bias, visible_bias, psi, count_dev, flag)
+  DISPATCH_LEN(len, {
+    switch (flavour) {
+      case PYNQS_RBM_REAL: PYNQS_RF(PYNQS_RBM_REAL); break;
+      case PYNQS_RBM_TANH: PYNQS_RF(PYNQS_RBM_TANH); break;
+      case PYNQS_RBM_PHASE: PYNQS_RF(PYNQS_RBM_PHASE); break;
+      default: PYNQS_RF(PYNQS_RBM_COMPLEX); break;
+    }
+  });
+#undef PYNQS_RF
   return check_launch("rbm_forward_children");
 }

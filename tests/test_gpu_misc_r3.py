@@ -139,3 +139,30 @@ def test_rbm_forward_children_matches_the_plain_forward(rbm_type, sorb, no, H):
     assert close(out[:nu], cx.rbm_forward(fe.uniq_onv[:nu].contiguous(), W, hb, vb, sorb, rbm_type))
     assert bool((out[nu:] == 7.0).all())
     assert not cx.rbm_forward_children_supported(184, 368, "complex")
+
+
+def test_rbm_forward_children_falls_back_when_the_parents_leave_the_range():
+    """A hidden bias of -400 puts Re theta below -340, where exp(-2 theta) overflows: the prepare step raises the table's flag, the
+    children kernel stands aside and the rows are computed from scratch -- the same values as pynqs_rbm_forward (bit for bit: it IS
+    that kernel), finite log-amplitudes included."""
+    import bench as B
+    from pynqs_amd import C_extension as cx, energy as E
+
+    dev = torch.device("cuda")
+    sorb, no, H, n = 40, 15, 12, 64
+    x = B.synth_walkers(n, sorb, no, no, 3).to(dev)
+    h1, h2 = B.synth_integrals(sorb)
+    fe, nu = E.reduce_front(x, h1.to(dev), h2.to(dev), sorb, 2 * no, no, no, 0.3, 20, None, seed=5, pm1_dtype=torch.float64)
+    g = torch.Generator().manual_seed(2)
+    r = lambda *s: (0.2 * (torch.rand(*s, generator=g, dtype=torch.float64) - 0.5)).to(dev)  # noqa: E731
+    W, hb, vb = r(H, sorb, 2), r(H, 2), r(sorb, 2)
+    hb[3, 0] = -400.0
+    uniq = fe.uniq_onv[:nu].contiguous()
+    want = cx.rbm_forward(uniq, W, hb, vb, sorb, "complex")
+    got = cx.rbm_forward_children(uniq, fe.uniq_parent, x, W, hb, vb, sorb, "complex")
+    assert bool(torch.isfinite(torch.view_as_real(want)).all())  # (2cosh(-400 + ...) ~ 1e173: finite)
+    assert torch.equal(got, want)
+    hb[3, 0] = 0.1  # back in range: the children kernel again
+    got2 = cx.rbm_forward_children(uniq, fe.uniq_parent, x, W, hb, vb, sorb, "complex")
+    want2 = cx.rbm_forward(uniq, W, hb, vb, sorb, "complex")
+    assert not torch.equal(got2, want2) and bool(((got2 - want2).abs() <= 1e-11 * want2.abs()).all())
