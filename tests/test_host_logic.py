@@ -47,6 +47,21 @@ def test_host_entry_points():
     assert (cx.MAX_SORB, cx.MAX_SORB_LEN, cx.MAX_NELE) == (192, 3, 120)
     assert N.lib().pynqs_plan_bytes(40, N.PYNQS_F64) == 8 * (20**4 + 2 * 190**2 + 2 * 400 * 40 + 800 + 1600 + 40)
     assert N.lib().pynqs_plan_bytes(41, N.PYNQS_F64) == -1
+    # round 3's host-only size functions (include/pynqs_amd.h)
+    lib = N.lib()
+    assert lib.pynqs_keys_index_bytes(65536, 120) == 65536 * 5 * 12 and lib.pynqs_keys_index_bytes(0, 40) == 0
+    assert lib.pynqs_keys_index_bytes(10, 41) == -1 and lib.pynqs_keys_index_bytes(1 << 27, 40) == -1
+    assert lib.pynqs_keys_index_workspace(0, 40) == 0 and lib.pynqs_keys_index_workspace(1000, 40) >= 1000 * 5 * 12
+    # factor table of the children forward: (2 sorb + 1) rows of (H + 2 made odd) entries, + the parents, + the flag
+    assert lib.pynqs_rbm_children_table_bytes(8192, 40, 40, N.RBM_COMPLEX) == 8192 * 42 * 16 + 81 * 43 * 16 + 8
+    assert lib.pynqs_rbm_children_table_bytes(10, 40, 80, N.RBM_REAL) == 10 * 82 * 8 + 81 * 83 * 8 + 8
+    assert lib.pynqs_rbm_forward_children_supported(40, 40, N.RBM_COMPLEX) == 1 and lib.pynqs_rbm_forward_children_supported(40, 80, N.RBM_REAL) == 1
+    assert lib.pynqs_rbm_forward_children_supported(120, 240, N.RBM_REAL) == 0 and lib.pynqs_rbm_forward_children_supported(40, 40, 7) == 0
+    assert lib.pynqs_rbm_grad_workspace(8192, 40, 40, N.RBM_COMPLEX) == 256 * (40 * 41 + 41) * 16
+    assert lib.pynqs_rbm_grad_workspace(33, 40, 80, N.RBM_REAL) == 2 * (80 * 41 + 41) * 8 and lib.pynqs_rbm_grad_workspace(8, 40, 40, N.RBM_TANH) == -1
+    # the complex-parameter RBM kernel: windowed beyond the LDS, refused only when the per-hidden-unit arrays alone do not fit
+    assert lib.pynqs_eloc_crbm_supported(40, 30, 15, 15, 80) == 1 and lib.pynqs_eloc_crbm_supported(120, 60, 30, 30, 240) == 1
+    assert lib.pynqs_eloc_crbm_supported(66, 4, 2, 2, 4000) == 0
 
 
 def test_integral_layout_matches_oracle():
