@@ -1098,12 +1098,12 @@ def main():
             # what the ranks agreed on in the last step: the all-reduced moments and the all-reduced gradient (for the N > 1 rehearsal test:
             # N ranks x W walkers must give what one rank gives on the N W walkers)
             mean = wl.stats[0]
-            flat = wl.graphed.flat if wl.graphed is not None else torch.cat([p.grad.reshape(-1) for p in wl.module.parameters()])
+            flat = torch.cat([p.grad.reshape(-1) for p in wl.module.parameters()])
             out["check"] = {"mean_eloc": [float(mean.real), float(mean.imag) if mean.is_complex() else 0.0], "var_eloc": float(wl.stats[1]),
                             "grad_l2": float(flat.double().norm()), "grad_first": [float(v) for v in flat[:4].double().cpu()]}
         if isinstance(wl, ReduceVmcStep):
             out["config"].update({"method": "REDUCE (vmc/energy/eloc.py:205-324), the Fe2S2 example's setting", "eps": wl.eps, "eps_sample": wl.eps_sample,
-                                  "amplitudes_on_distinct_rows": "pynqs_rbm_forward (one kernel, from the packed determinants)" if wl.fused_amplitudes
+                                  "amplitudes_on_distinct_rows": ("pynqs_rbm_forward_children (from the parent walkers' hidden-unit factors by table multiplications)" if getattr(wl, "from_parents", False) else "pynqs_rbm_forward (one kernel, from the packed determinants)") if wl.fused_amplitudes
                                   else "the PyTorch module on the +-1 rows"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()

@@ -176,12 +176,13 @@ class FusedRbmGrad:
             raise ValueError("FusedRbmGrad: float64 parameters on the GPU")
         dev = self.params[0].device
         self.H = self.params[0].size(0)
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float64, device=dev)
+        # one buffer for the gradients AND the loss (its last element): one all-reduce per step over the ranks, not two
+        self.flat = torch.zeros(sum(p.numel() for p in self.params) + 1, dtype=torch.float64, device=dev)
         self.views, o = [], 0
         for p in self.params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
-        self.loss = torch.zeros(1, dtype=torch.double, device=dev)
+        self.loss = self.flat[o:o + 1]
         self.work = None
         self.events = None
 
@@ -219,10 +220,10 @@ class FusedRbmGrad:
             import torch.distributed as dist
 
             dist.all_reduce(self.flat, dist.ReduceOp.SUM)
-            self.flat.div_(ws)
+            self.flat.div_(ws)  # gradients: mean over the ranks (DDP's convention); the loss is a sum: undone below
         if ev is not None:
             ev[1].record()
             self.events.append(ev)
         for p, v in zip(self.params, self.views):
             p.grad = v
-        return all_reduce_packed([self.loss], ws)[0]
+        return self.loss * ws if ws > 1 else self.loss.clone()
