@@ -183,8 +183,10 @@ __global__ __launch_bounds__(kBlock) void rbm_children_factors_kernel(int sorb, 
   if constexpr (CPLX) factors[(size_t)idx * C + 1] = im;
 }
 
-// one lane per (walker, chunk of kHChunk hidden units): blockIdx.y is the chunk, so that W_ho stays wave-uniform and 8192 walkers are
-// 5 x 128 waves, not 128 (80 -> 10 us for Fe2S2).  Chunk 0 also leaves sum_h theta_h = sum_h b_h + sum_o x_o sum_h W_ho (from the factor
+constexpr int kParentChunk = 4;
+
+// one lane per (walker, chunk of kParentChunk = 4 hidden units): blockIdx.y is the chunk, so that W_ho stays wave-uniform and 8192
+// walkers are 10 x 128 waves, not 128 (80 -> 28 us with chunks of 8 -> 17 us for Fe2S2).  Chunk 0 also leaves sum_h theta_h = sum_h b_h + sum_o x_o sum_h W_ho (from the factor
 // table's sum_h W_ho, built by the launch before this one) and a.x.
 template <int LEN, bool CPLX>
 __global__ __launch_bounds__(kBlock) void rbm_children_parents_kernel(const uint64_t *__restrict__ onv, int64_t n, int sorb, int H,
@@ -194,14 +196,14 @@ __global__ __launch_bounds__(kBlock) void rbm_children_parents_kernel(const uint
   constexpr int C = CPLX ? 2 : 1;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t row = i < n ? i : n - 1;
-  const int h0 = (int)blockIdx.y * kHChunk;
+  const int h0 = (int)blockIdx.y * kParentChunk;
   uint64_t ket[LEN];
 #pragma unroll
   for (int w = 0; w < LEN; ++w) ket[w] = onv[row * LEN + w];
   double *__restrict__ out = table + (size_t)row * (size_t)(H + 2) * C;
-  double tr[kHChunk], ti[kHChunk];
+  double tr[kParentChunk], ti[kParentChunk];
 #pragma unroll
-  for (int j = 0; j < kHChunk; ++j) {
+  for (int j = 0; j < kParentChunk; ++j) {
     const int h = min(h0 + j, H - 1);
     tr[j] = CPLX ? hb[2 * h] : hb[h];
     ti[j] = CPLX ? hb[2 * h + 1] : 0.0;
@@ -209,14 +211,14 @@ __global__ __launch_bounds__(kBlock) void rbm_children_parents_kernel(const uint
   for (int o = 0; o < sorb; ++o) {
     const double x = pm1_of<LEN>(ket, o);
 #pragma unroll
-    for (int j = 0; j < kHChunk; ++j) {
+    for (int j = 0; j < kParentChunk; ++j) {
       const int h = min(h0 + j, H - 1);  // (wave-uniform address: a scalar load)
       tr[j] = fma(x, W[((size_t)h * sorb + o) * C], tr[j]);
       if constexpr (CPLX) ti[j] = fma(x, W[((size_t)h * sorb + o) * C + 1], ti[j]);
     }
   }
 #pragma unroll
-  for (int j = 0; j < kHChunk; ++j) {
+  for (int j = 0; j < kParentChunk; ++j) {
     if (h0 + j < H && i < n) {
       if (!(tr[j] > -340.0)) const_cast<double *>(factors)[(size_t)(2 * sorb + 1) * children_hp(H) * C] = 1.0;  // (also for nan)
       const double m = exp(-2.0 * tr[j]);
@@ -406,7 +408,7 @@ extern "C" int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalk
   if (cplx) hipLaunchKernelGGL((rbm_children_factors_kernel<true>), dim3(gf), dim3(kBlock), 0, st, sorb, nhidden, weights, visible_bias, factors);
   else hipLaunchKernelGGL((rbm_children_factors_kernel<false>), dim3(gf), dim3(kBlock), 0, st, sorb, nhidden, weights, visible_bias, factors);
   if (nwalkers > 0) {
-    const dim3 grid((uint32_t)((nwalkers + kBlock - 1) / kBlock), (uint32_t)((nhidden + kHChunk - 1) / kHChunk));
+    const dim3 grid((uint32_t)((nwalkers + kBlock - 1) / kBlock), (uint32_t)((nhidden + kParentChunk - 1) / kParentChunk));
     if (grid.y > 65535u) return set_error(PYNQS_EINVAL, "too many hidden units");
     DISPATCH_LEN(len, {
       if (cplx)

@@ -178,30 +178,42 @@ __global__ __launch_bounds__(kBlock) void rbm_grad_partial_kernel(const uint64_t
   }
 }
 
-// grad[k] = 2 Re G_k (and -2 Im G_k), G_k = the workgroups' partial sums in order; parameter layout of the module:
+// grad[k] = 2 Re G_k (and -2 Im G_k), G_k = the workgroups' partial sums in a fixed order; parameter layout of the module:
 // weights [H][sorb](x2), hidden_bias [H](x2), visible_bias [sorb](x2)
 template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void rbm_grad_reduce_kernel(const double *__restrict__ partial, int64_t stride, int ngroups, int sorb, int H,
                                                                  double *__restrict__ gw, double *__restrict__ ghb, double *__restrict__ gvb,
                                                                  double *__restrict__ loss) {
   constexpr int C = CPLX ? 2 : 1;
+  constexpr int NS = kBlock / 64;  // a block owns 64 outputs; its NS waves take contiguous slices of the workgroups' partial sums
+  __shared__ double part[NS][64][2];
   const int SP = sorb + 1;
   const int64_t nout = (int64_t)H * SP + sorb + 1;
-  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= nout) return;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+  const int per = (ngroups + NS - 1) / NS, g_lo = min(slice * per, ngroups), g_hi = min(g_lo + per, ngroups);
   double re = 0.0, im = 0.0;
-  constexpr int RU = 16;  // loads in flight (the additions keep their order)
-  for (int g0 = 0; g0 < ngroups; g0 += RU) {
-    double vr[RU], vi[RU];
+  if (k < nout) {
+    constexpr int RU = 16;  // loads in flight (the additions keep their order)
+    for (int g0 = g_lo; g0 < g_hi; g0 += RU) {
+      double vr[RU], vi[RU];
 #pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      const bool in = g0 + u < ngroups;
-      vr[u] = in ? partial[(int64_t)(g0 + u) * stride + C * k] : 0.0;
-      vi[u] = CPLX && in ? partial[(int64_t)(g0 + u) * stride + C * k + 1] : 0.0;
+      for (int u = 0; u < RU; ++u) {
+        const bool in = g0 + u < g_hi;
+        vr[u] = in ? partial[(int64_t)(g0 + u) * stride + C * k] : 0.0;
+        vi[u] = CPLX && in ? partial[(int64_t)(g0 + u) * stride + C * k + 1] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) { re += vr[u]; im += vi[u]; }
     }
-#pragma unroll
-    for (int u = 0; u < RU; ++u) { re += vr[u]; im += vi[u]; }
   }
+  part[slice][lane][0] = re;
+  part[slice][lane][1] = im;
+  __syncthreads();
+  if (slice != 0 || k >= nout) return;
+  re = 0.0; im = 0.0;
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl) { re += part[sl][lane][0]; im += part[sl][lane][1]; }  // fixed order: reproducible
   if (k == nout - 1) {
     if (loss) loss[0] = re;
     return;
@@ -260,7 +272,7 @@ extern "C" int pynqs_rbm_grad(const uint64_t *onv, int64_t n, int sorb, const do
 #undef PYNQS_RG
   }
   const int64_t nout = (int64_t)nhidden * (sorb + 1) + sorb + 1;
-  const uint32_t g2 = (uint32_t)((nout + kBlock - 1) / kBlock);
+  const uint32_t g2 = (uint32_t)((nout + 63) / 64);
   if (cplx)
     hipLaunchKernelGGL((rbm_grad_reduce_kernel<true>), dim3(g2), dim3(kBlock), 0, st, partial, stride, (int)groups, sorb, nhidden, grad_weights,
                        grad_hidden_bias, grad_visible_bias, loss);
