@@ -1031,11 +1031,15 @@ struct ListDrawSink {
 
 // The LIST form keeps nothing in the staging scratch but the singles' and the diagonal's terms.  The sampled kernel, which is short
 // of LDS (draw areas), takes 256 elements per wave instead of 512: two rounds per singles tile, 3 -> 4 workgroups per CU
-// (1253 -> 1057 us per 8192 Fe2S2 walkers; 128 elements: 1148 us); the deterministic kernel keeps 512 (with 128 it loses 10 %).
+// (1253 -> 1057 us per 8192 Fe2S2 walkers; 128 elements: 1148 us); the deterministic kernel too (end of round 3: 260 -> 248 us with 256,
+// 252 with 384; with 128 it had lost 10 %).
 #ifndef PYNQS_LIST_Q_SAMPLED
 #define PYNQS_LIST_Q_SAMPLED 256
 #endif
-__host__ __device__ constexpr int list_quarter(bool sampled) { return sampled ? PYNQS_LIST_Q_SAMPLED : kDiagTile / 4; }
+#ifndef PYNQS_LIST_Q_DET
+#define PYNQS_LIST_Q_DET 256
+#endif
+__host__ __device__ constexpr int list_quarter(bool sampled) { return sampled ? PYNQS_LIST_Q_SAMPLED : PYNQS_LIST_Q_DET; }
 // `cached` (row-cache form): the draws read the row back and never enumerate again, so the waves' draw areas share the memory of the
 // staging scratch of phase A (barriers lie between the two uses): 8 KB less per workgroup, 5 instead of 4 workgroups per CU for Fe2S2
 __host__ __device__ inline size_t list_scratch_offset(const SDParams &p) { return (lds_fixed_bytes(p) + 15) & ~(size_t)15; }
