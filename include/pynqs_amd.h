@@ -405,8 +405,8 @@ int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const double *we
  *   pynqs_rbm_forward_children_supported : 1 if the factor table ((2 sorb + 1) x (nhidden + 2) entries) fits 64 KB of LDS, else 0: the
  *                                    caller then uses pynqs_rbm_forward
  * Flavours and parameter layouts as pynqs_rbm_forward.  exp(-2 theta_h) is formed for the parents: if some Re theta_h < -340 the prepare
- * step raises a flag in the table and pynqs_rbm_forward_children computes every row from scratch instead (the plain kernel, launched
- * behind the children kernel; it returns at once when the flag is down).  Values agree with pynqs_rbm_forward to rounding (typically
+ * step raises a flag in the table and pynqs_rbm_forward_children computes every row from scratch instead (pynqs_rbm_forward's
+ * algorithm inside the same kernel).  Values agree with pynqs_rbm_forward to rounding (typically
  * 1e-14 relative; a factor 2cosh(theta_h) near zero amplifies it).                                                                      */
 int64_t pynqs_rbm_children_table_bytes(int64_t nwalkers, int sorb, int nhidden, int flavour);
 int pynqs_rbm_children_prepare(const uint64_t *walkers, int64_t nwalkers, int sorb, const double *weights, const double *hidden_bias,

@@ -77,22 +77,11 @@ __device__ __forceinline__ void write_psi(double *__restrict__ psi, int64_t i, c
   }
 }
 
+// psi of one determinant from scratch (every lane of the wave takes part: the parameter loads are wave-uniform scalar loads)
 template <int LEN, int FLAVOUR>
-__global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__restrict__ onv, int64_t n, int sorb, int H,
-                                                             const double *__restrict__ W, const double *__restrict__ hb,
-                                                             const double *__restrict__ vb, double *__restrict__ psi,
-                                                             const int32_t *__restrict__ count_dev, const double *__restrict__ only_if) {
+__device__ __forceinline__ void rbm_forward_row(const uint64_t (&ket)[LEN], int sorb, int H, const double *__restrict__ W,
+                                                const double *__restrict__ hb, const double *__restrict__ vb, Prod &P, double &axr, double &axi) {
   constexpr bool CPLX = FLAVOUR == PYNQS_RBM_COMPLEX;
-  // (the children path's fall-back: this launch does something only if the table's flag says the parents were out of range)
-  if (only_if && *only_if == 0.0) return;
-  if (count_dev) n = min((int64_t)max(*count_dev, 0), n);
-  if ((int64_t)blockIdx.x * kBlock >= n) return;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t row = i < n ? i : n - 1;  // (idle lanes repeat the last determinant: the parameter loads below must stay wave-uniform)
-  uint64_t ket[LEN];
-#pragma unroll
-  for (int w = 0; w < LEN; ++w) ket[w] = onv[row * LEN + w];
-  Prod P;  // prod_h 2cosh(theta_h) = exp(P.lin + i P.ang) * (P.re + i P.im) * 2^P.e2
   for (int h0 = 0; h0 < H; h0 += kHChunk) {
     double tr[kHChunk], ti[kHChunk];
 #pragma unroll
@@ -119,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__r
       if (h0 + j < H) P.template times_2cosh<CPLX>(tr[j], ti[j]);
     P.renorm();
   }
-  double axr = 0.0, axi = 0.0;
+  axr = 0.0; axi = 0.0;
   if (vb) {
     for (int o = 0; o < sorb; ++o) {
       const double x = pm1_of<LEN>(ket, o);
@@ -127,6 +116,20 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__r
       else axr = fma(x, vb[o], axr);
     }
   }
+}
+
+template <int LEN, int FLAVOUR>
+__global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__restrict__ onv, int64_t n, int sorb, int H,
+                                                             const double *__restrict__ W, const double *__restrict__ hb,
+                                                             const double *__restrict__ vb, double *__restrict__ psi) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t row = i < n ? i : n - 1;  // (idle lanes repeat the last determinant: the parameter loads must stay wave-uniform)
+  uint64_t ket[LEN];
+#pragma unroll
+  for (int w = 0; w < LEN; ++w) ket[w] = onv[row * LEN + w];
+  Prod P;  // prod_h 2cosh(theta_h) = exp(P.lin + i P.ang) * (P.re + i P.im) * 2^P.e2
+  double axr, axi;
+  rbm_forward_row<LEN, FLAVOUR>(ket, sorb, H, W, hb, vb, P, axr, axi);
   if (i >= n) return;
   write_psi<FLAVOUR>(psi, i, P, axr, axi);
 }
@@ -140,8 +143,7 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_kernel(const uint64_t *__r
 //   factors [2 sorb + 1][HP]  : row 2 o (x'_o = +1) / 2 o + 1 (x'_o = -1): exp(-+4 W_ho) for h < H, +-2 sum_h W_ho, +-2 a_o;
 //                               the last row (1, ..., 1, 0, 0) stands for "no flip"; HP = H + 2 made odd (rows start in different banks)
 //   flag    one double after the factors: non-zero if some parent has Re theta_h < -340, where q_h = exp(-2 theta_h) leaves the range of a
-//           double: the children kernel then does nothing and the plain forward kernel, launched behind it, computes every row from
-//           scratch (it returns at once otherwise)
+//           double: the children kernel then computes every row from scratch (rbm_forward_row, the plain kernel's body)
 // all entries real or (re, im) by the flavour.
 __host__ __device__ inline int children_hp(int H) { return (H + 2) | 1; }
 
@@ -262,16 +264,32 @@ template <int LEN, int FLAVOUR>
 __global__ __launch_bounds__(kChildBlock) void rbm_forward_children_kernel(const uint64_t *__restrict__ onv, int64_t n, const int32_t *__restrict__ count_dev,
                                                                       const int32_t *__restrict__ parent, const uint64_t *__restrict__ walkers,
                                                                       int64_t nwalkers, const double *__restrict__ table,
-                                                                      const double *__restrict__ factors, int sorb, int H, double *__restrict__ psi) {
+                                                                      const double *__restrict__ factors, int sorb, int H,
+                                                                      const double *__restrict__ W, const double *__restrict__ hb,
+                                                                      const double *__restrict__ vb, double *__restrict__ psi) {
   constexpr bool CPLX = FLAVOUR == PYNQS_RBM_COMPLEX;
   constexpr int C = CPLX ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) double wl[];
   const int HP = children_hp(H);
-  if (factors[(size_t)(2 * sorb + 1) * HP * C] != 0.0) return;  // (workgroup-uniform) parents out of range: the plain kernel takes over
-  for (int idx = threadIdx.x; idx < (2 * sorb + 1) * HP * C; idx += kChildBlock) wl[idx] = factors[idx];
-  __syncthreads();
   int64_t cnt = n;
   if (count_dev) cnt = min((int64_t)max(*count_dev, 0), n);
+  if (factors[(size_t)(2 * sorb + 1) * HP * C] != 0.0) {  // (grid-uniform) parents out of range: every row from scratch
+    const int64_t rounds = (cnt + (int64_t)gridDim.x * kChildBlock - 1) / ((int64_t)gridDim.x * kChildBlock);
+    for (int64_t r = 0; r < rounds; ++r) {  // (whole waves iterate together: the parameter loads are wave-uniform)
+      const int64_t i = ((int64_t)r * gridDim.x + blockIdx.x) * kChildBlock + threadIdx.x;
+      const int64_t row = i < cnt ? i : cnt - 1;
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = onv[row * LEN + w];
+      Prod P;
+      double axr, axi;
+      rbm_forward_row<LEN, FLAVOUR>(ket, sorb, H, W, hb, vb, P, axr, axi);
+      if (i < cnt) write_psi<FLAVOUR>(psi, i, P, axr, axi);
+    }
+    return;
+  }
+  for (int idx = threadIdx.x; idx < (2 * sorb + 1) * HP * C; idx += kChildBlock) wl[idx] = factors[idx];
+  __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * kChildBlock + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * kChildBlock) {
     int64_t p = parent[i];
     p = p < 0 || p >= nwalkers ? 0 : p;
@@ -361,7 +379,7 @@ extern "C" int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const
   const int len = (sorb - 1) / 64 + 1;
   const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
   hipStream_t st = (hipStream_t)stream;
-#define PYNQS_RF(F) hipLaunchKernelGGL((rbm_forward_kernel<LEN, F>), dim3(grid), dim3(kBlock), 0, st, onv, n, sorb, nhidden, weights, hidden_bias, visible_bias, psi, (const int32_t *)nullptr, (const double *)nullptr)
+#define PYNQS_RF(F) hipLaunchKernelGGL((rbm_forward_kernel<LEN, F>), dim3(grid), dim3(kBlock), 0, st, onv, n, sorb, nhidden, weights, hidden_bias, visible_bias, psi)
   DISPATCH_LEN(len, {
     switch (flavour) {
       case PYNQS_RBM_REAL: PYNQS_RF(PYNQS_RBM_REAL); break;
@@ -440,7 +458,7 @@ extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const 
   const double *parents = (const double *)table;
   const double *factors = parents + (size_t)nwalkers * (size_t)(nhidden + 2) * (flavour == PYNQS_RBM_COMPLEX ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
-#define PYNQS_RC(F) hipLaunchKernelGGL((rbm_forward_children_kernel<LEN, F>), dim3(grid), dim3(kChildBlock), lds, st, onv, n, count_dev, parent, walkers, nwalkers, parents, factors, sorb, nhidden, psi)
+#define PYNQS_RC(F) hipLaunchKernelGGL((rbm_forward_children_kernel<LEN, F>), dim3(grid), dim3(kChildBlock), lds, st, onv, n, count_dev, parent, walkers, nwalkers, parents, factors, sorb, nhidden, weights, hidden_bias, visible_bias, psi)
   DISPATCH_LEN(len, {
     switch (flavour) {
       case PYNQS_RBM_REAL: PYNQS_RC(PYNQS_RBM_REAL); break;
@@ -450,18 +468,5 @@ extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const 
     }
   });
 #undef PYNQS_RC
-  // the fall-back: every row from scratch if (and only if) the table's flag is up
-  const double *flag = factors + (size_t)(2 * sorb + 1) * (size_t)children_hp(nhidden) * (flavour == PYNQS_RBM_COMPLEX ? 2 : 1);
-  const uint32_t gridf = (uint32_t)((n + kBlock - 1) / kBlock);
-#define PYNQS_RF(F) hipLaunchKernelGGL((rbm_forward_kernel<LEN, F>), dim3(gridf), dim3(kBlock), 0, st, onv, n, sorb, nhidden, weights, hidden_bias, visible_bias, psi, count_dev, flag)
-  DISPATCH_LEN(len, {
-    switch (flavour) {
-      case PYNQS_RBM_REAL: PYNQS_RF(PYNQS_RBM_REAL); break;
-      case PYNQS_RBM_TANH: PYNQS_RF(PYNQS_RBM_TANH); break;
-      case PYNQS_RBM_PHASE: PYNQS_RF(PYNQS_RBM_PHASE); break;
-      default: PYNQS_RF(PYNQS_RBM_COMPLEX); break;
-    }
-  });
-#undef PYNQS_RF
   return check_launch("rbm_forward_children");
 }
