@@ -1,0 +1,29 @@
+"""Per-workgroup phase timestamps of the semi-stochastic REDUCE front end (a build with -DSTAMP instrumentation: build_ab/libpynqs_stamps.so,
+see DESIGN.md 4.3): mean duration of every phase of a workgroup's life, 8192 Fe2S2 walkers."""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pynqs_amd import C_extension as cx, reduce_front as RF, _native as N
+d = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "fe2s2_inputs.npz"))
+dev = torch.device("cuda"); n = 8192
+ci = d["ci_space"]
+x = torch.from_numpy(np.ascontiguousarray(ci[np.arange(n) % ci.shape[0]])).to(dev)
+h1, h2 = torch.from_numpy(d["h1e"]).to(dev), torch.from_numpy(d["h2e"]).to(dev)
+plan = cx.plan_for(h1, h2, 40, dev).buf
+fe = RF.ReduceFrontEnd(n, 40, 30, 15, 15, 1000, torch.float64, dev, 246, 1900000, want_pm1=False)
+for _ in range(3):
+    fe.run(x, plan, 1e-2, 3, None)
+torch.cuda.synchronize()
+lib = ctypes.CDLL(N.LIB_PATH)
+out = np.zeros((8192, 10), dtype=np.uint64)
+assert lib.pynqs_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
+t = out.astype(np.float64)
+names = ["walker tables", "phase A (enumeration, row cache, kept list)", "record counts", "sort of the kept list (incl. barrier)", "kept records: kets, probes, rows, links",
+         "tile sums from the cached row", "tile-level draws, scans", "draws inside the tiles + emission", "drawn records: kets, probes, rows, links"]
+dt = np.diff(t, axis=1) / 100.0  # wall_clock64: 100 MHz
+print("mean per workgroup (us):")
+for k, nm in enumerate(names):
+    print(f"  {nm:55s} {dt[:, k].mean():8.2f}   (median {np.median(dt[:, k]):.2f})")
+life = (t[:, 9] - t[:, 0]) / 100.0
+span = (t[:, 9].max() - t[:, 0].min()) / 100.0
+print(f"  workgroup life {life.mean():.1f} us; kernel span {span:.1f} us; workgroups in flight on average {life.sum() / span:.0f}")
