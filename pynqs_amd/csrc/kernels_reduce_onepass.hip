@@ -24,6 +24,15 @@
 
 namespace pynqs {
 
+// -DPYNQS_OP_STAMPS: the LIST kernel notes wall_clock64() at its phase boundaries per workgroup (tools/onepass_stamps.py reads them through
+// pynqs_debug_stamps); nothing of this exists in the product build
+#ifdef PYNQS_OP_STAMPS
+__device__ unsigned long long g_stamps[8192][10];
+#define PYNQS_STAMP(k) do { if (threadIdx.x == 0 && walker < 8192) g_stamps[walker][k] = wall_clock64(); } while (0)
+#else
+#define PYNQS_STAMP(k) do { } while (0)
+#endif
+
 constexpr uint32_t kStatP = 0x80000000u;  // look-back status: inclusive prefix available
 constexpr uint32_t kStatA = 0x40000000u;  //                   this tile's count available
 constexpr uint32_t kStatMask = 0x3fffffffu;
@@ -1098,7 +1107,9 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   Walker<LEN> wk;
   load_walker<LEN>(bra + walker * LEN, wk);
   const LdsLayout L = carve_lds(smem, p);
+  PYNQS_STAMP(0);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
+  PYNQS_STAMP(1);
   {
     ListKeepSink<LEN, T, SAMPLED, CACHED> sink{eps, &list_n, list_col, list_h, cap, tsum, 0xffffffffu, 0.0,
                                                CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
@@ -1109,6 +1120,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   if (o.debug & 32u) return;  // (timing ablation: the enumeration alone)
   // ---- the kept columns: sort by column, write, resolve ----
   const uint32_t ntot = list_n;
+  PYNQS_STAMP(2);
   const uint32_t n = min(ntot, cap);
   if (tid == 0) {
     o.seg_count[slot] = (int32_t)(ntot > o.fixed ? ntot - o.fixed : 0u);
@@ -1120,6 +1132,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   for (uint32_t i = n + tid; i < P; i += kBlock) list_col[i] = 0xffffffffu;
   for (uint32_t i = n + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
   __syncthreads();
+  PYNQS_STAMP(3);
   uint32_t Ps = 64;  // sort only as many entries as there are
   while (Ps < n) Ps <<= 1;
   for (uint32_t k = 2; k <= Ps; k <<= 1) {
@@ -1137,6 +1150,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
       __syncthreads();
     }
   }
+  PYNQS_STAMP(4);
   for (uint32_t i0 = 0; i0 < n; i0 += kBlock) {
     const uint32_t i = i0 + tid;
     bool won = false;
@@ -1162,6 +1176,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     const int32_t mine = allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
     if (i < n) o.rec_link[seg_base + i] = final_link<LEN, T>(o, link, mine);
   }
+  PYNQS_STAMP(5);
   if constexpr (SAMPLED) {
     const uint32_t ncomb = p.nsd + 1;
     const T *__restrict__ hrow = CACHED ? o.row_cache + (size_t)walker * ncomb : nullptr;
@@ -1182,6 +1197,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
       }
       __syncthreads();
     }
+    PYNQS_STAMP(6);
     // ---- phase B (as in the look-back form) ----
     const uint32_t per = (max_tiles + kBlock - 1) / kBlock;
     const uint32_t b0 = min((uint32_t)tid * per, max_tiles), b1 = min(b0 + per, max_tiles);
@@ -1237,6 +1253,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     }
     if (tid == 0) next_tile = 0;
     __syncthreads();
+    PYNQS_STAMP(7);
     // ---- phase C: the draws inside the tiles ----
     unsigned char *mine = draw0 + (size_t)wave * (CACHED ? kCachedDrawLdsPerWave : kDrawLdsPerWave);
     DrawLds S;
@@ -1331,6 +1348,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
       sink.flush();
     }
     __syncthreads();
+    PYNQS_STAMP(8);
     // ---- the drawn records: kets, links, rows -- four draw slots per thread and round, one row allocation per round ----
     constexpr int K = 4;
     for (uint32_t i0 = 0; i0 < nsample; i0 += K * kBlock) {
@@ -1370,6 +1388,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
         if (lk[k] != kNoRecord) o.srec_link[(int64_t)walker * nsample + i] = final_link<LEN, T>(o, lk[k], mine[k]);
       }
     }
+    PYNQS_STAMP(9);
   }
 }
 
@@ -1600,3 +1619,9 @@ extern "C" int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA
 #undef PYNQS_CT_LAUNCH
   return check_launch("reduce_contract");
 }
+
+#ifdef PYNQS_OP_STAMPS
+extern "C" int pynqs_debug_stamps(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pynqs::g_stamps), sizeof(unsigned long long) * 8192 * 10);
+}
+#endif

@@ -1,5 +1,8 @@
-"""Per-workgroup phase timestamps of the semi-stochastic REDUCE front end (a build with -DSTAMP instrumentation: build_ab/libpynqs_stamps.so,
-see DESIGN.md 4.3): mean duration of every phase of a workgroup's life, 8192 Fe2S2 walkers."""
+"""Per-workgroup phase timestamps of the semi-stochastic REDUCE front end: mean duration of every phase of a workgroup's life, 8192 Fe2S2
+walkers.  Needs a library whose kernels_reduce_onepass.hip was compiled with -DPYNQS_OP_STAMPS, e.g.
+  cd pynqs_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DPYNQS_OP_STAMPS -c kernels_reduce_onepass.hip -o /tmp/s.o &&
+  hipcc --offload-arch=gfx950 -fPIC -shared -o ../../build_ab/libpynqs_stamps.so $(ls build/*.o | grep -v kernels_reduce_onepass.o) /tmp/s.o
+  PYNQS_AMD_LIB=$PWD/build_ab/libpynqs_stamps.so python tools/onepass_stamps.py"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
