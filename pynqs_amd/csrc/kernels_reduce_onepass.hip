@@ -890,8 +890,8 @@ template <int LEN, typename T, bool SAMPLED, bool CACHED = false>
 struct ListKeepSink {
   T eps;
   uint32_t *list_n;
-  uint32_t *list_col;
-  T *list_h;
+  unsigned long long *list_key;  // LDS: column << 32 | position of the value in rec_w (unsorted), sorted afterwards
+  T *__restrict__ rec_w;         // this segment's record weights (global): the kept values wait there in order of arrival
   uint32_t cap;
   double *tsum;
   uint32_t tile;
@@ -902,7 +902,7 @@ struct ListKeepSink {
     if constexpr (CACHED) hrow[col] = h;
     if (a >= eps) {
       const uint32_t k = atomicAdd(list_n, 1u);
-      if (k < cap) { list_col[k] = col; list_h[k] = h; }
+      if (k < cap) { list_key[k] = ((unsigned long long)col << 32) | k; rec_w[k] = h; }
     } else if constexpr (SAMPLED && !CACHED) {
       sub += (double)a;
     }
@@ -1059,7 +1059,7 @@ __host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, b
 }
 
 // LDS of the LIST form after the walker tables and the staging scratch:
-//   (SAMPLED) tsum[max_tiles] f64 | dinfo[max_tiles] u32 | draw areas ;  then the list: col[P] u32, h[P] T  (P = power of two >= capacity),
+//   (SAMPLED) tsum[max_tiles] f64 | dinfo[max_tiles] u32 | draw areas ;  then the list: key[P] u64  (P = power of two >= capacity),
 //   which the draw slots' columns (pend[N] u32) re-use in phase C
 __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample,
                                                    bool cached) {
@@ -1069,14 +1069,14 @@ __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz
     b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
     if (!cached) b += (kBlock / 64) * kDrawLdsPerWave;
   }
-  const size_t list = (size_t)P * (4 + esz), pend = (size_t)nsample * 4;
+  const size_t list = (size_t)P * 8, pend = (size_t)nsample * 4;
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
 }
 
-template <int LEN, typename T, bool SAMPLED, bool CACHED = false>
-__global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
-                                                                     uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
-                                                                     uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
+template <int LEN, typename T, bool SAMPLED, bool CACHED>
+__device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restrict__ bra, const SDParams &p, const PlanLayout &pl, uint32_t nchunks,
+                                                         uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
+                                                         uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t next_tile, list_n, bw_cnt;
   __shared__ int32_t bw_base;
@@ -1097,8 +1097,10 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   unsigned char *after = SAMPLED ? reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) : extra;
   unsigned char *draw0 = CACHED ? smem + list_scratch_offset(p) : after;  // (CACHED: over the staging scratch, see list_base_lds)
   if (SAMPLED && !CACHED) after += (kBlock / 64) * kDrawLdsPerWave;
-  T *list_h = reinterpret_cast<T *>(after);                       // h first: 8-byte aligned
-  uint32_t *list_col = reinterpret_cast<uint32_t *>(list_h + P);
+  // the kept list: ONE 64-bit key per entry (column << 32 | order of arrival); the values wait in the segment's rec_w, in order of arrival,
+  // and are permuted after the sort (12 -> 8 bytes of LDS per entry: with the draw slots' 4000 bytes sharing the memory that is what
+  // decides between 7 and 8 workgroups per CU)
+  unsigned long long *list_key = reinterpret_cast<unsigned long long *>(after);
   uint32_t *pend = reinterpret_cast<uint32_t *>(after);           // phase C re-uses the list's memory
   if constexpr (SAMPLED) {
     for (uint32_t i = tid; i < max_tiles; i += kBlock) { tsum[i] = 0.0; dinfo[i] = 0u; }
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   const int nocc = build_walker_tables<LEN>(wk, p, L);
   PYNQS_STAMP(1);
   {
-    ListKeepSink<LEN, T, SAMPLED, CACHED> sink{eps, &list_n, list_col, list_h, cap, tsum, 0xffffffffu, 0.0,
+    ListKeepSink<LEN, T, SAMPLED, CACHED> sink{eps, &list_n, list_key, o.rec_w + seg_base, cap, tsum, 0xffffffffu, 0.0,
                                                CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
     visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
     sink.flush();
@@ -1129,7 +1131,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
       atomicMax(o.counters + 2, (int32_t)(ntot - o.fixed));
     }
   }
-  for (uint32_t i = n + tid; i < P; i += kBlock) list_col[i] = 0xffffffffu;
+  for (uint32_t i = n + tid; i < P; i += kBlock) list_key[i] = ~0ull;
   for (uint32_t i = n + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
   __syncthreads();
   PYNQS_STAMP(3);
@@ -1140,10 +1142,9 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
       for (uint32_t i = tid; i < Ps; i += kBlock) {
         const uint32_t ixj = i ^ j;
         if (ixj > i) {
-          const uint32_t a = list_col[i], b = list_col[ixj];
+          const unsigned long long a = list_key[i], b = list_key[ixj];
           if ((a > b) == ((i & k) == 0)) {
-            list_col[i] = b; list_col[ixj] = a;
-            const T ha = list_h[i]; list_h[i] = list_h[ixj]; list_h[ixj] = ha;
+            list_key[i] = b; list_key[ixj] = a;
           }
         }
       }
@@ -1151,6 +1152,22 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
     }
   }
   PYNQS_STAMP(4);
+  // the values, from their order of arrival into the sorted order: every thread fetches its entries' values, then (barrier) stores them
+  {
+    constexpr int kMaxPer = 8;  // n <= 2048 = 8 x 256
+    T mine_w[kMaxPer];
+#pragma unroll
+    for (int r = 0; r < kMaxPer; ++r) {
+      const uint32_t i = (uint32_t)r * kBlock + tid;
+      mine_w[r] = i < n ? o.rec_w[seg_base + (uint32_t)(list_key[i] & 0xffffffffull)] : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kMaxPer; ++r) {
+      const uint32_t i = (uint32_t)r * kBlock + tid;
+      if (i < n) o.rec_w[seg_base + i] = mine_w[r];
+    }
+  }
   for (uint32_t i0 = 0; i0 < n; i0 += kBlock) {
     const uint32_t i = i0 + tid;
     bool won = false;
@@ -1159,14 +1176,13 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
 #pragma unroll
     for (int w = 0; w < LEN; ++w) ket[w] = wk.w[w];
     if (i < n) {
-      const uint32_t col = list_col[i];
+      const uint32_t col = (uint32_t)(list_key[i] >> 32);
       if (col) {
         const Excitation x = decode(col - 1, p, L);
         make_ket<LEN>(wk, x, ket);
       }
       const int64_t g = seg_base + i;
       o.rec_col[g] = (int32_t)col;
-      o.rec_w[g] = list_h[i];
       if (o.rec_onv) {
 #pragma unroll
         for (int w = 0; w < LEN; ++w) o.rec_onv[g * LEN + w] = ket[w];
@@ -1392,6 +1408,25 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_kernel(const uint6
   }
 }
 
+// The kernels.  Eight waves per SIMD (64 VGPRs, 96 SGPRs; the 106 scalar registers the compiler would otherwise take cap the CU at SIX
+// workgroups -- measured, tools/onepass_stamps.py -- whatever the LDS allows) for the forms whose LDS fits eight workgroups per CU: 8192
+// walkers are 32 workgroups per CU, i.e. exactly four generations of eight.  The form that enumerates the drawn tiles a second time
+// (no row cache: ~38 KB of LDS, four workgroups per CU) keeps its registers.
+template <int LEN, typename T, bool SAMPLED, bool CACHED = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void reduce_onepass_list_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks, uint32_t chunk_len, uint32_t max_tiles,
+                                const T *__restrict__ plan, T eps, uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
+  static_assert(CACHED || !SAMPLED, "the re-enumerating form has its own kernel");
+  reduce_onepass_list_body<LEN, T, SAMPLED, CACHED>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
+}
+
+template <int LEN, typename T>
+__global__ __launch_bounds__(kBlock) void reduce_onepass_list_redraw_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
+                                                                            uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
+                                                                            uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
+  reduce_onepass_list_body<LEN, T, true, false>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
+}
+
 // ---- contraction: E_loc(x) = sum_records w psi(x') / psi(x) ------------------------------------------------------------
 // One wave per walker.  Slots are visited in their fixed order (fixed slots, compacted doubles, drawn records; chunk by chunk),
 // lane l takes slots l, l + 64, ...; the 64 partial sums meet in a butterfly: the result does not depend on anything but the
@@ -1576,7 +1611,8 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
   do {                                                                                                                               \
-    auto kfn = use_list ? (use_cache ? reduce_onepass_list_kernel<LEN, TT, SM, SM> : reduce_onepass_list_kernel<LEN, TT, SM, false>) \
+    auto kfn = use_list ? (use_cache ? reduce_onepass_list_kernel<LEN, TT, SM, SM>                                                   \
+                                     : (SM ? reduce_onepass_list_redraw_kernel<LEN, TT> : reduce_onepass_list_kernel<LEN, TT, false, false>)) \
                         : reduce_onepass_kernel<LEN, TT, SM>;                                                                        \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                                (int)lds) != hipSuccess)                                                              \

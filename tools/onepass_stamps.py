@@ -30,3 +30,11 @@ for k, nm in enumerate(names):
 life = (t[:, 9] - t[:, 0]) / 100.0
 span = (t[:, 9].max() - t[:, 0].min()) / 100.0
 print(f"  workgroup life {life.mean():.1f} us; kernel span {span:.1f} us; workgroups in flight on average {life.sum() / span:.0f}")
+ev = np.concatenate([np.stack([t[:, 0], np.ones(len(t))], 1), np.stack([t[:, 9], -np.ones(len(t))], 1)])
+ev = ev[np.argsort(ev[:, 0], kind="stable")]
+alive = np.cumsum(ev[:, 1])
+dur = np.diff(ev[:, 0], append=ev[-1, 0])
+order = np.argsort(alive)
+cum = np.cumsum(dur[order]) / dur.sum()
+med = alive[order][np.searchsorted(cum, 0.5)]
+print(f"  workgroups alive at once: peak {int(alive.max())} ({alive.max() / 256:.2f} per CU), time-weighted median {int(med)} ({med / 256:.2f} per CU)")
