@@ -909,7 +909,28 @@ struct ListKeepSink {
   }
   __device__ __forceinline__ void one(uint32_t col, T h, const uint64_t (&)[LEN]) { add(col, h); }
   __device__ __forceinline__ void two(uint32_t c0, T h0, const uint64_t (&)[LEN], uint32_t c1, T h1, const uint64_t (&)[LEN]) { add(c0, h0); add(c1, h1); }
-  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&)[LEN], const uint64_t (&)[LEN]) { add(col, h0); add(col + 1, h1); }
+  __device__ __forceinline__ void pair(uint32_t col, T h0, T h1, const uint64_t (&)[LEN], const uint64_t (&)[LEN]) {
+    if constexpr (CACHED && sizeof(T) == 8) {
+      // the two neighbouring elements of the cached row in ONE 16-byte store when they are aligned (two 8-byte stores of a wave each
+      // touch every other 8 bytes of the same lines: twice the write requests at the L2)
+      if ((reinterpret_cast<uintptr_t>(hrow + col) & 15u) == 0) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<d2 *>(hrow + col) = d2{(double)h0, (double)h1};
+        add_nocache(col, h0); add_nocache(col + 1, h1);
+        return;
+      }
+    }
+    add(col, h0); add(col + 1, h1);
+  }
+  __device__ __forceinline__ void add_nocache(uint32_t col, T h) {
+    const T a = fabs(h);
+    if (a >= eps) {
+      const uint32_t k = atomicAdd(list_n, 1u);
+      if (k < cap) { list_key[k] = ((unsigned long long)col << 32) | k; rec_w[k] = h; }
+    } else if constexpr (SAMPLED && !CACHED) {
+      sub += (double)a;
+    }
+  }
   __device__ __forceinline__ void flush() {
     if constexpr (SAMPLED && !CACHED) {
       if (tile == 0xffffffffu) return;
