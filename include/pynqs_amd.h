@@ -325,6 +325,10 @@ int pynqs_reduce_sample(const uint64_t *bra, int64_t nbatch, int sorb, int nele,
  *                                   out[2] = bytes of the de-duplication table for `dedup_slots` slots of this sorb
  *                                   (dedup_slots passed in out[2] on entry), out[3] = 1 if the fused form exists for
  *                                   this system (LDS budget), else 0
+ *   pynqs_reduce_onepass_list_capacity : [host] the largest io->cap_doubles with which pynqs_reduce_onepass keeps a segment's
+ *                                   records in an LDS list (its fast form on rows of more than 65536 columns: beyond it such a
+ *                                   row is served faster by the multi-pass entry points, pynqs_reduce_count / _emit), or -1;
+ *                                   with_row_cache: whether io->row_cache will be given
  *   pynqs_reduce_onepass          : the launch (memsets of the de-duplication table and counters included)
  *   pynqs_reduce_contract         : eloc[x] = sum_records w A(x') / A(x) (divide = 1) or sum_records w A(x') (divide = 0) and
  *                                   psi_x[x] = A(x), from the records (io->rec_w / srec_w: any weights in the records' slot
@@ -367,6 +371,8 @@ typedef struct pynqs_reduce_io {
                            intermediate values (pynqs_rbm_forward_children) */
 } pynqs_reduce_io;
 int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
+int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
+                                       int with_row_cache, int64_t *cap_doubles);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                          int dtype, double eps, int eps_sample, uint64_t seed, const pynqs_reduce_io *io, void *stream);
 int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,

@@ -1560,6 +1560,57 @@ extern "C" int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele,
   return PYNQS_OK;
 }
 
+// Which of the two forms a call takes.  LIST form when a segment's records fit an LDS list (PYNQS_OP_LIST=0 / 1 overrides; 1 only where it
+// fits): up to 1024 slots per segment, up to 2048 on rows of more than kLongRow columns -- there the look-back form is the slow one (sorb 80
+// / 120: 2 to 4 times slower than the multi-pass entry points, tools/reduce_big_paths.py; energy.py routes such calls away from it), on short
+// rows a list of 2048 costs more than it saves.  With a row cache (io->row_cache: [nbatch][ncomb] elements of the integral dtype) the draws
+// read the row back instead of visiting the drawn tiles a second time (PYNQS_OP_CACHE=0 ignores the buffer); LIST form only.
+constexpr uint32_t kLongRow = 65536;
+struct OnepassForm {
+  uint32_t P;
+  bool use_list, use_cache;
+  size_t lds;
+};
+static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tiles, uint32_t fixed, uint64_t cap_doubles, int eps_sample,
+                                bool have_cache) {
+  static const int list_env = getenv("PYNQS_OP_LIST") ? atoi(getenv("PYNQS_OP_LIST")) : -1;
+  static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
+  const bool sampled = eps_sample > 0;
+  const uint64_t seg_cap = (uint64_t)fixed + cap_doubles;
+  OnepassForm f;
+  f.P = 64;
+  while (f.P < seg_cap && f.P < (1u << 20)) f.P <<= 1;
+  const bool want_cache = sampled && have_cache && cache_env != 0;
+  const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, f.P, (uint32_t)eps_sample, want_cache);
+  const bool list_fits = seg_cap <= 2048 && lds_list + 256 <= 160 * 1024;
+  f.use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024 || p.nsd + 1 > kLongRow));
+  f.use_cache = want_cache && f.use_list;
+  f.lds = f.use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, winner_list_cap(eps_sample));
+  return f;
+}
+
+extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
+                                                  int with_row_cache, int64_t *cap_doubles) {
+  SDParams p;
+  PlanLayout pl;
+  if (!cap_doubles) return set_error(PYNQS_EINVAL, "null pointer");
+  if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl)) return set_error(PYNQS_EINVAL, "bad sorb/noA/noB (even sorb in [2, 192])");
+  if (nbatch < 0 || nbatch > 0x7fffffffll || eps_sample < 0 || eps_sample > 65535 || (dtype != PYNQS_F32 && dtype != PYNQS_F64))
+    return set_error(PYNQS_EINVAL, "bad nbatch / eps_sample / dtype");
+  uint32_t nchunks, chunk_len, max_tiles, fixed;
+  onepass_geometry(nbatch, p, eps_sample > 0, &nchunks, &chunk_len, &max_tiles, &fixed);
+  *cap_doubles = -1;
+  for (uint32_t seg = 2048; seg >= 128; seg >>= 1) {
+    if (seg < fixed) break;
+    const OnepassForm f = onepass_form(p, dtype == PYNQS_F64 ? 8 : 4, max_tiles, fixed, seg - fixed, eps_sample, with_row_cache != 0);
+    if (f.use_list && f.lds + onepass_static_lds(0) <= 160 * 1024) {
+      *cap_doubles = (int64_t)(seg - fixed);
+      break;
+    }
+  }
+  return PYNQS_OK;
+}
+
 template <typename T>
 static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed) {
   OnepassOut<T> o;
@@ -1608,21 +1659,10 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   if (grid * ((uint64_t)fixed + (uint64_t)io->cap_doubles) > 0x7fffffffull * 16ull) return set_error(PYNQS_EINVAL, "record arrays too large");
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
-  const uint32_t wl_cap = winner_list_cap(eps_sample);
-  // LIST form when a segment's records fit an LDS list (PYNQS_OP_LIST=0 / 1 overrides; 1 only where it fits)
-  static const int list_env = getenv("PYNQS_OP_LIST") ? atoi(getenv("PYNQS_OP_LIST")) : -1;
-  const uint64_t seg_cap = (uint64_t)fixed + (uint64_t)io->cap_doubles;
-  uint32_t P = 64;
-  while (P < seg_cap && P < (1u << 20)) P <<= 1;
-  static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
-  const bool want_cache = sampled && io->row_cache != nullptr && cache_env != 0;
-  const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, P, (uint32_t)eps_sample, want_cache);
-  const bool list_fits = seg_cap <= 2048 && lds_list + 256 <= 160 * 1024;
-  const bool use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024));
-  // with a row cache (io->row_cache: [nbatch][ncomb] elements of the integral dtype) the draws read the row back instead of visiting the
-  // drawn tiles a second time (PYNQS_OP_CACHE=0 ignores the buffer)
-  const bool use_cache = want_cache && use_list;
-  const size_t lds = use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, wl_cap);
+  const OnepassForm form = onepass_form(p, esz, max_tiles, fixed, (uint64_t)io->cap_doubles, eps_sample, io->row_cache != nullptr);
+  const uint32_t P = form.P;
+  const bool use_list = form.use_list, use_cache = form.use_cache;
+  const size_t lds = form.lds;
   if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
   static const bool verbose = getenv("PYNQS_OP_VERBOSE") != nullptr;
   if (verbose)
@@ -1639,7 +1679,7 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
                                                (int)lds) != hipSuccess)                                                              \
       return check_launch("hipFuncSetAttribute");                                                                                   \
     hipLaunchKernelGGL(kfn, dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, chunk_len, max_tiles, (const TT *)plan, \
-                       (TT)eps_eff, (uint32_t)eps_sample, seed, use_list ? P : wl_cap, make_out<TT>(io, len, fixed));                \
+                       (TT)eps_eff, (uint32_t)eps_sample, seed, use_list ? P : winner_list_cap(eps_sample), make_out<TT>(io, len, fixed));                \
   } while (0)
   DISPATCH_LEN(len, {
     if (dtype == PYNQS_F64) { if (sampled) PYNQS_OP_LAUNCH(double, true); else PYNQS_OP_LAUNCH(double, false); }

@@ -53,6 +53,15 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+# REDUCE on rows of more than FRONT_LONG_ROW columns: the one-launch front end only while a segment's kept records fit its LDS list, else
+# the multi-pass path (reduce_compact / reduce_compact_sampled).  Measured (tools/reduce_big_paths.py, one MI355X, local_energy with a real
+# RBM, ms one-launch / multi-pass): rows of 7.9e3 and 3.1e4 columns (sorb 40, 56) the one-launch form wins in either of its forms (4.2 / 13.2,
+# 0.56 / 1.14, 8.4 / 43.6, 5.7 / 6.4, sampled 0.9 / 2.6 and 6.2 / 9.0); rows of 2.3e5 and 1.2e6 columns (sorb 80, 120): LIST form 5.3 / 6.4,
+# 10.6 / 10.4, sampled 13.0 / 14.6, 2.7 / 3.0 -- its other (look-back) form 22 / 6.1, 94 / 30, 96 / 38, sampled 68 / 14 and 54 / 16.
+FRONT_ROUTE = True
+FRONT_LONG_ROW = 65536   # (= kLongRow of kernels_reduce_onepass.hip)
+FRONT_MAX_CHUNKS = 32    # rows cut into more chunks than this per walker (few walkers, sorb 184): multi-pass (30.8 / 25.9, 4.1 / 3.8 at 64 chunks)
+_FRONT_DENSE: "set[tuple]" = set()   # long-row systems whose kept records outgrew the LDS list (this process)
 FUSED_ONEPASS = True  # REDUCE: the one-launch front end (reduce_front.ReduceFrontEnd); False: the multi-pass compaction of round 2
 
 
@@ -494,21 +503,46 @@ def _draw_seed() -> int:
     return (s ^ ((r + 1) * 0x9E3779B97F4A7C15)) & (2**63 - 1) if r else s
 
 
+class _FrontDense(RuntimeError):
+    """a long row kept more records than the one-launch front end's LDS list holds: the caller takes the multi-pass path"""
+
+    def __init__(self) -> None:
+        super().__init__("rows of this system keep more records per segment than the one-launch REDUCE front end's LDS list holds: "
+                         "reduce_compact / reduce_compact_sampled serve them faster (energy.FRONT_ROUTE = False forces the one-launch form)")
+
+
+def _dense_key(device, sorb, nele, noa, nob, eps_sample) -> tuple:
+    return (str(device), sorb, nele, noa, nob, int(eps_sample) > 0)
+
+
+def _long_row_cap(n, h1e, sorb, nele, noa, nob, eps_sample) -> Optional[int]:
+    """None on rows the one-launch front end serves in either form; else the cap_doubles up to which it is used (-1: never)"""
+    if not FRONT_ROUTE or get_Num_SinglesDoubles(sorb, noa, nob) + 1 <= FRONT_LONG_ROW:
+        return None
+    return RF.list_capacity(n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype)
+
+
 def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d=None, cap_u=None):
     if cap_d is None:
         nseg, fixed, _, _ = RF.geometry(n, sorb, nele, noa, nob, eps_sample)
         ncomb = get_Num_SinglesDoubles(sorb, noa, nob) + 1
         per_seg = (ncomb * max(n, 1) + max(nseg, 1) - 1) // max(nseg, 1)
         cap_d, cap_u = min(per_seg, max(64, per_seg // 32)), max(4096, 32 * n)
+        limit = _long_row_cap(n, h1e, sorb, nele, noa, nob, eps_sample)
+        if limit is not None and limit >= 0:
+            cap_d = min(cap_d, limit)   # (long rows: start in the LIST form; reduce_front_finish leaves the path if that overflows)
     return RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype, want_pm1=want_pm1)
 
 
 def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
-                        lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True, slot: int = 0):
+                        lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True, slot: int = 0,
+                        route: bool = False):
     """Enqueue the fused REDUCE front end for the walkers x on the CURRENT stream (buffers cached per (device, batch size, system,
     eps_sample, slot)) together with an asynchronous copy of its counters to pinned host memory; returns a ticket for reduce_front_finish.
     Nothing is waited for: a caller can enqueue the front end of the NEXT chunk of walkers on a second stream while the ansatz works on
-    the current one (total_energy does: SURVEY 7.6)."""
+    the current one (total_energy does: SURVEY 7.6).
+    route (local_energy's calls): on rows of more than FRONT_LONG_ROW columns reduce_front_finish raises _FrontDense instead of growing the
+    buffers past the front end's LDS list (the multi-pass path is the faster one there); a direct caller gets the front end regardless."""
     plan = CX.plan_for(h1e, h2e, sorb, x.device)
     n = x.size(0)
     pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
@@ -523,7 +557,7 @@ def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: in
     host.copy_(fe.counters, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(x.device))
-    return dict(fe=fe, key=key, host=host, ev=ev, x=x, plan=plan, eps=eps, seed=seed, lut=lut, args=(h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1))
+    return dict(fe=fe, key=key, host=host, ev=ev, x=x, plan=plan, eps=eps, seed=seed, lut=lut, route=route, args=(h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1))
 
 
 def reduce_front_finish(t):
@@ -537,6 +571,10 @@ def reduce_front_finish(t):
         nu, flags, mx = cnt
         cap_d = max(fe.cap_doubles, int(mx * 1.25) + 16) if mx > fe.cap_doubles else fe.cap_doubles
         cap_u = fe.cap_unique
+        limit = _long_row_cap(x.size(0), h1e, sorb, nele, noa, nob, eps_sample) if t["route"] else None
+        if limit is not None and cap_d > limit:
+            _FRONT_DENSE.add(_dense_key(x.device, sorb, nele, noa, nob, eps_sample))
+            raise _FrontDense()
         if flags & RF.OVERFLOW_TABLE:
             cap_u = max(2 * cap_u, int(nu * 1.5))
         elif nu > cap_u:
@@ -551,11 +589,11 @@ def reduce_front_finish(t):
 
 
 def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
-                 lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True):
+                 lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True, route: bool = False):
     """Run the fused REDUCE front end on the walkers x (vmc/energy/eloc.py:243-298 + flip.py:29-63 in one launch) and return
     (front end, number of distinct x').  Buffers are cached per (device, batch size, system, eps_sample) and grown when a call
     reports that it needed more (the call is then repeated); ONE device-to-host read per call, after the kernel has been enqueued."""
-    return reduce_front_finish(reduce_front_launch(x, h1e, h2e, sorb, nele, noa, nob, eps, eps_sample, lut, seed, pm1_dtype, want_pm1))
+    return reduce_front_finish(reduce_front_launch(x, h1e, h2e, sorb, nele, noa, nob, eps, eps_sample, lut, seed, pm1_dtype, want_pm1, route=route))
 
 
 def _reduce_front_options(ansatz, WF_LUT, dtype, use_multi_psi, use_spin_flip):
@@ -575,8 +613,15 @@ def _reduce_front_options(ansatz, WF_LUT, dtype, use_multi_psi, use_spin_flip):
 
 
 def _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample) -> bool:
-    return (FUSED and FUSED_ONEPASS and x.is_cuda and sorb % 2 == 0 and h1e.dtype in (torch.float64, torch.float32)
-            and (eps_sample == 0 or FUSED_SAMPLED) and RF.supported(x.size(0), sorb, nele, noa, nob, int(eps_sample)))
+    if not (FUSED and FUSED_ONEPASS and x.is_cuda and sorb % 2 == 0 and h1e.dtype in (torch.float64, torch.float32)
+            and (eps_sample == 0 or FUSED_SAMPLED) and RF.supported(x.size(0), sorb, nele, noa, nob, int(eps_sample))):
+        return False
+    limit = _long_row_cap(x.size(0), h1e, sorb, nele, noa, nob, eps_sample)
+    if limit is None:
+        return True
+    n = x.size(0)
+    chunks = RF.geometry(n, sorb, nele, noa, nob, int(eps_sample))[0] // max(n, 1)
+    return limit >= 0 and chunks <= FRONT_MAX_CHUNKS and _dense_key(x.device, sorb, nele, noa, nob, eps_sample) not in _FRONT_DENSE
 
 
 def local_energy(
@@ -686,13 +731,19 @@ def local_energy(
             ansatz_f = partial(ansatz_batch, func=ansatz)
 
         # ---- fast path: REDUCE through the one-launch front end (deterministic and semi-stochastic, every form) ---------------
+        front = None
         if reduce_psi and not use_sample_space and batch > 0 and _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample):
-            plain = not (use_multi_psi or use_spin_flip)
             ht, rbm_fwd = _reduce_front_options(ansatz, WF_LUT, dtype, use_multi_psi, use_spin_flip)
-            if _front_ticket is not None:
-                fe, nu = reduce_front_finish(_front_ticket)
-            else:
-                fe, nu = reduce_front(x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht, want_pm1=not rbm_fwd)
+            try:
+                if _front_ticket is not None:
+                    front = reduce_front_finish(_front_ticket)
+                else:
+                    front = reduce_front(x, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht, want_pm1=not rbm_fwd, route=True)
+            except _FrontDense:
+                front = None   # (long rows, more kept records than the LDS list holds: the multi-pass path below, from now on)
+        if front is not None:
+            fe, nu = front
+            plain = not (use_multi_psi or use_spin_flip)
             t2 = time.time_ns()
             uniq = fe.uniq_onv[:nu]
             takes_rows = fe.uniq_pm1 is not None and getattr(ansatz_batch, "accepts_pm1_rows", False) and fe.pm1_dtype == torch.get_default_dtype()
@@ -952,17 +1003,19 @@ def total_energy(
             if k >= 2:
                 side.wait_event(done[k - 2])  # the workspace of slot k % 2 is free once chunk k - 2 has been contracted
             with torch.cuda.stream(side):
-                tickets[k] = reduce_front_launch(xs, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht_, want_pm1=not rbm_fwd_, slot=k % 2)
+                tickets[k] = reduce_front_launch(xs, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht_, want_pm1=not rbm_fwd_, slot=k % 2, route=True)
 
         launch(0)
     begin = 0
     for k, end in enumerate(ends):
         ticket = None
         if look_ahead:
-            ticket = tickets.pop(k)
-            ticket["ev"].synchronize()           # (host: the counters of chunk k are there)
-            main.wait_event(ticket["ev"])         # (device: chunk k's records are there before the ansatz / contraction read them)
-            if k + 1 < len(ends):
+            ticket = tickets.pop(k, None)
+            if ticket is not None:
+                ticket["ev"].synchronize()       # (host: the counters of chunk k are there)
+                main.wait_event(ticket["ev"])     # (device: chunk k's records are there before the ansatz / contraction read them)
+            # (a chunk whose rows outgrew the front end's LDS list sends the rest of the call to the multi-pass path: no more tickets)
+            if k + 1 < len(ends) and _front_ok(x[starts[k + 1]:ends[k + 1]], h1e, sorb, nele, noa, nob, eps_sample):
                 launch(k + 1)                     # runs while the ansatz works on chunk k
         _eloc, _sloc, _psi, _ = local_energy(
             ticket["x"] if ticket is not None else x[begin:end], h1e, h2e, ansatz, _ansatz_batch, sorb, nele, noa, nob, dtype=dtype, WF_LUT=WF_LUT,

@@ -49,6 +49,24 @@ def supported(n: int, sorb: int, nele: int, noa: int, nob: int, eps_sample: int)
         return False
 
 
+def wants_row_cache(n: int, ncomb: int, eps_sample: int, nchunks: int, esz: int) -> bool:
+    """the semi-stochastic kernel's row cache: worth it when the draws are dense in the row (>= one draw per 64 columns) and the
+    [n, ncomb] scratch is affordable (<= ROW_CACHE_MAX_BYTES)"""
+    return bool(eps_sample > 0 and nchunks == 1 and ROW_CACHE and eps_sample * 64 >= ncomb and n * ncomb * esz <= ROW_CACHE_MAX_BYTES)
+
+
+def list_capacity(n: int, sorb: int, nele: int, noa: int, nob: int, eps_sample: int, h_dtype: torch.dtype = torch.float64) -> int:
+    """Largest cap_doubles with which the kernel keeps a segment's records in an LDS list (pynqs_reduce_onepass_list_capacity), or -1."""
+    ncomb = int(N.lib().pynqs_num_sd(sorb, noa, nob)) + 1
+    esz = 8 if h_dtype == torch.float64 else 4
+    nseg = geometry(n, sorb, nele, noa, nob, eps_sample)[0]
+    cache = wants_row_cache(n, ncomb, int(eps_sample), nseg // max(n, 1) if n else 1, esz)
+    out = C.c_int64(-1)
+    N.check(N.lib().pynqs_reduce_onepass_list_capacity(n, sorb, nele, noa, nob, N.PYNQS_F64 if esz == 8 else N.PYNQS_F32, int(eps_sample),
+                                                       int(cache), C.byref(out)), "pynqs_reduce_onepass_list_capacity")
+    return int(out.value)
+
+
 class ReduceFrontEnd:
     """Buffers of the fused REDUCE front end for `n` walkers of one system.  Capacities: `cap_doubles` compacted slots per
     (walker, chunk) segment for the kept doubles (column 0, the singles and the unpaired doubles have fixed slots), `cap_unique`
@@ -94,12 +112,11 @@ class ReduceFrontEnd:
         self.uniq_parent = torch.zeros(self.cap_unique, dtype=torch.int32, device=dev)  # the walker each distinct row descends from
         self.counters = torch.zeros(4, dtype=torch.int32, device=dev)
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # added to run()'s seed: bump it between the replays of a captured step
-        # row cache of the semi-stochastic kernel: the draws read the row back instead of enumerating the drawn tiles again.  Worth it when
-        # the draws are dense in the row (>= one draw per 64 columns) and the [n, ncomb] scratch is affordable (<= ROW_CACHE_MAX_BYTES)
+        # row cache of the semi-stochastic kernel: the draws read the row back instead of enumerating the drawn tiles again
         ncomb = int(N.lib().pynqs_num_sd(sorb, noa, nob)) + 1
         esz = 8 if h_dtype == torch.float64 else 4
         self.row_cache = None
-        if self.eps_sample > 0 and self.nchunks == 1 and ROW_CACHE and self.eps_sample * 64 >= ncomb and self.n * ncomb * esz <= ROW_CACHE_MAX_BYTES:
+        if wants_row_cache(self.n, ncomb, self.eps_sample, self.nchunks, esz):
             self.row_cache = torch.empty(max(self.n * ncomb, 1), dtype=h_dtype, device=dev)
         self._lut = None
         self._io = self._make_io()
