@@ -352,7 +352,11 @@ typedef struct pynqs_reduce_io {
   uint64_t *srec_onv;   /* may be NULL */
   int32_t *srec_link;
   double *row_sum;      /* [nbatch] S (may be NULL) */
-  void *dedup_table;    /* out[2] bytes from the geometry call */
+  void *dedup_table;    /* out[2] bytes from the geometry call; NULL = no de-duplication: every record that the wave-function table
+                           does not answer gets a row of its own in uniq_onv (cap_unique >= the number of records; the distinct-list
+                           counter counts records).  E_loc is the same; worth it when nearly all x' are distinct anyway and the table
+                           would be gigabytes (random probes there cost 10x the enumeration).  LIST forms only: cap_doubles <=
+                           pynqs_reduce_onepass_list_capacity */
   uint64_t *uniq_onv;   /* [cap_unique][len] distinct determinants, order of first insertion */
   void *uniq_pm1;       /* [cap_unique][sorb] +1/-1 rows, element type pm1_dtype (may be NULL) */
   int32_t pm1_dtype;    /* PYNQS_F32 / PYNQS_F64 */

@@ -29,8 +29,15 @@ namespace pynqs {
 #ifdef PYNQS_OP_STAMPS
 __device__ unsigned long long g_stamps[8192][10];
 #define PYNQS_STAMP(k) do { if (threadIdx.x == 0 && walker < 8192) g_stamps[walker][k] = wall_clock64(); } while (0)
+// (the flushing form: time spent between two marks, summed over the rounds, into stamp slot k)
+#define PYNQS_STAMP_MARK() unsigned long long stamp_mark_ = wall_clock64()
+#define PYNQS_STAMP_ADD(k) do { const unsigned long long now_ = wall_clock64(); if (threadIdx.x == 0 && walker < 8192) g_stamps[walker][k] += now_ - stamp_mark_; stamp_mark_ = now_; } while (0)
+#define PYNQS_STAMP_ZERO(k) do { if (threadIdx.x == 0 && walker < 8192) g_stamps[walker][k] = 0; } while (0)
 #else
 #define PYNQS_STAMP(k) do { } while (0)
+#define PYNQS_STAMP_MARK() do { } while (0)
+#define PYNQS_STAMP_ADD(k) do { } while (0)
+#define PYNQS_STAMP_ZERO(k) do { } while (0)
 #endif
 
 constexpr uint32_t kStatP = 0x80000000u;  // look-back status: inclusive prefix available
@@ -38,6 +45,7 @@ constexpr uint32_t kStatA = 0x40000000u;  //                   this tile's count
 constexpr uint32_t kStatMask = 0x3fffffffu;
 constexpr int kFixedHead = 8;             // slot 0: column 0; slots 1..6: unpaired doubles; 7: unused
 constexpr int kOneTileCols = 128 * PYNQS_U;
+constexpr uint32_t kMaxKeptPerTile = kOneTileCols;  // columns of the largest tile (a tile of doubles; singles come 16 per tile, tile 0 has <= 7)
 constexpr uint32_t kProbeLimit = 512;     // a de-duplication table at most half full never needs that many
 constexpr int32_t kDirectLink = 1 << 30;  // link >= kDirectLink: row of the distinct list = link - kDirectLink (no look at the de-duplication slot)
 
@@ -213,8 +221,9 @@ __device__ __forceinline__ bool assign_row(const OnepassOut<T> &o, uint32_t s, i
   }
   // (agent scope: other workgroups, on other XCDs, read the row of a determinant they find already inserted -- slot_row() -- to point their
   // records at it directly; one that still reads -1 keeps the slot as its link and the contraction looks the row up)
-  __hip_atomic_store(reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN)) + dedup_row_offset(LEN), r, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+  if (o.dedup)
+    __hip_atomic_store(reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN)) + dedup_row_offset(LEN), r, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
   for (int i = 0; i < LEN; ++i) o.uniq_onv[(size_t)r * LEN + i] = ket[i];
   if (o.uniq_parent) o.uniq_parent[r] = o.parent;
@@ -234,6 +243,7 @@ __device__ __forceinline__ int32_t slot_row(const OnepassOut<T> &o, uint32_t s) 
 template <int LEN, typename T>
 __device__ __forceinline__ int32_t final_link(const OnepassOut<T> &o, int32_t link, int32_t mine) {
   if (link < 0) return link;
+  if (!o.dedup) return mine >= 0 && (uint32_t)mine < o.ucap ? (mine | kDirectLink) : -1;  // (no de-duplication: own row, or none: overflow)
   const int32_t r = mine >= 0 ? mine : slot_row<LEN, T>(o, (uint32_t)link);
   return r >= 0 && (uint32_t)r < o.ucap ? (r | kDirectLink) : link;
 }
@@ -809,6 +819,13 @@ __device__ __forceinline__ int32_t probe_amplitude(const OnepassOut<T> &o, const
     const int64_t pos = hash_find<LEN>(o.lut, o.lut_cap, ket);
     if (pos >= 0) return (int32_t)(-2 - pos);
   }
+  if (!o.dedup) {  // no de-duplication (io->dedup_table == NULL): every record gets a row of its own
+    won = true;
+    return 0;
+  }
+  // a call whose table has overflowed is going to be repeated with a larger one: do not walk the full table for every further record
+  // (each probe then runs to its limit: 0.3 - 0.7 s per launch at sorb 80 with 4096 walkers before this check)
+  if (__hip_atomic_load(o.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) return -1;
   const uint32_t s = dedup_insert<LEN>(o.dedup, o.dedup_mask, ket, won);
   if (s == 0xffffffffu) {
     won = false;
@@ -886,7 +903,11 @@ __device__ __forceinline__ void allocate_batch_k(const OnepassOut<T> &o, int sor
   __syncthreads();
 }
 
-template <int LEN, typename T, bool SAMPLED, bool CACHED = false>
+// FLUSH (the flushing LIST form, rows whose kept columns exceed the list): the workgroup empties the list whenever it is nearly full
+// (pause(): asked by visit_tiles before a wave takes a tile); entries of tile 0 (column 0 and the few unpaired doubles, whose columns lie
+// anywhere in the row) keep bit 63 of the key clear and so sort in front of everything else of the first flush, the others carry it:
+// the records of a segment are then the same whatever the timing of the flushes.
+template <int LEN, typename T, bool SAMPLED, bool CACHED = false, bool FLUSH = false>
 struct ListKeepSink {
   T eps;
   uint32_t *list_n;
@@ -897,12 +918,21 @@ struct ListKeepSink {
   uint32_t tile;
   double sub;
   T *__restrict__ hrow;  // CACHED: this walker's row of matrix elements in global memory (the draws read it back instead of a second enumeration)
+  uint32_t pause_at = 0;          // FLUSH: the list is emptied once it holds more than this
+  unsigned long long tag = 0ull;  // FLUSH: bit 63 for the entries of every tile but tile 0
+  template <bool F = FLUSH, typename = std::enable_if_t<F>>
+  __device__ __forceinline__ bool pause() const {
+    return __builtin_amdgcn_readfirstlane(__atomic_load_n(list_n, __ATOMIC_RELAXED)) > pause_at;
+  }
   __device__ __forceinline__ void add(uint32_t col, T h) {
     const T a = fabs(h);
     if constexpr (CACHED) hrow[col] = h;
     if (a >= eps) {
       const uint32_t k = atomicAdd(list_n, 1u);
-      if (k < cap) { list_key[k] = ((unsigned long long)col << 32) | k; rec_w[k] = h; }
+      if (k < cap) {
+        list_key[k] = FLUSH ? (((unsigned long long)col << 32) | k | tag) : (((unsigned long long)col << 32) | k);
+        rec_w[k] = h;
+      }
     } else if constexpr (SAMPLED && !CACHED) {
       sub += (double)a;
     }
@@ -938,7 +968,10 @@ struct ListKeepSink {
       if ((threadIdx.x & 63) == 0) tsum[tile] = s;
     }
   }
-  __device__ __forceinline__ void tile_begin(uint32_t t) { flush(); tile = t; sub = 0.0; }
+  __device__ __forceinline__ void tile_begin(uint32_t t) {
+    flush(); tile = t; sub = 0.0;
+    if constexpr (FLUSH) tag = t ? (1ull << 63) : 0ull;
+  }
 };
 
 // phase C of the LIST form: as DrawSink, but a drawn record only notes its column in the LDS array `pend` (one entry per draw
@@ -1094,12 +1127,13 @@ __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
 }
 
-template <int LEN, typename T, bool SAMPLED, bool CACHED>
+template <int LEN, typename T, bool SAMPLED, bool CACHED, bool FLUSH = false>
 __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restrict__ bra, const SDParams &p, const PlanLayout &pl, uint32_t nchunks,
                                                          uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
                                                          uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t next_tile, list_n, bw_cnt;
+  static_assert(!FLUSH || (!SAMPLED && !CACHED), "the flushing form has no draws");
+  __shared__ uint32_t next_tile, list_n, bw_cnt, s_done;
   __shared__ int32_t bw_base;
   __shared__ double s_part[kBlock / 64 + 1];
   __shared__ uint32_t s_parti[kBlock / 64 + 1];
@@ -1109,9 +1143,9 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   o.parent = (int32_t)walker;
   const uint64_t slot = walker * nchunks + chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P)
+  const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P unless FLUSH)
   const int64_t seg_base = (int64_t)slot * cap;
-  if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; }
+  if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; s_done = 0; }
   unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED, CACHED);
   double *tsum = reinterpret_cast<double *>(extra);
   uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
@@ -1133,27 +1167,43 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   PYNQS_STAMP(0);
   const int nocc = build_walker_tables<LEN>(wk, p, L);
   PYNQS_STAMP(1);
+  // FLUSH: rounds of (enumerate until the list is nearly full, sort, write, resolve) until the tiles are exhausted; the tiles are taken in
+  // order and every taken tile is finished before a flush, so the flushes cover consecutive ranges of tiles = ascending columns
+  uint32_t flushed = 0;  // records of this segment written by earlier rounds
+  uint32_t needed = 0;   // kept columns so far, whether they had room or not
+  PYNQS_STAMP_ZERO(6); PYNQS_STAMP_ZERO(7); PYNQS_STAMP_ZERO(8); PYNQS_STAMP_ZERO(9);
+  PYNQS_STAMP_MARK();
+  for (;;) {
+  const uint32_t room = FLUSH ? (cap > flushed ? min(cap - flushed, P) : 0u) : cap;
   {
-    ListKeepSink<LEN, T, SAMPLED, CACHED> sink{eps, &list_n, list_key, o.rec_w + seg_base, cap, tsum, 0xffffffffu, 0.0,
-                                               CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
-    visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+    ListKeepSink<LEN, T, SAMPLED, CACHED, FLUSH> sink{eps, &list_n, list_key, o.rec_w + seg_base + flushed, room, tsum, 0xffffffffu, 0.0,
+                                                      CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
+    if constexpr (FLUSH) sink.pause_at = P - (kBlock / 64) * kMaxKeptPerTile - 64;  // (every wave may be in the middle of a tile)
+    const bool exhausted =
+        visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
     sink.flush();
+    if (FLUSH && exhausted && lane == 0) s_done = 1u;  // (a wave that found no tile left: every tile has been taken, and finished by the barrier)
   }
   __syncthreads();
   if (o.debug & 32u) return;  // (timing ablation: the enumeration alone)
   // ---- the kept columns: sort by column, write, resolve ----
+  const bool last = !FLUSH || s_done != 0u;
   const uint32_t ntot = list_n;
   PYNQS_STAMP(2);
-  const uint32_t n = min(ntot, cap);
-  if (tid == 0) {
-    o.seg_count[slot] = (int32_t)(ntot > o.fixed ? ntot - o.fixed : 0u);
-    if (ntot > cap) {
-      atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 1u);
-      atomicMax(o.counters + 2, (int32_t)(ntot - o.fixed));
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(6);  // enumeration (with the wait for the slowest wave)
+  const uint32_t n = min(ntot, room);
+  needed += ntot;
+  if constexpr (!FLUSH) {
+    if (tid == 0) {
+      o.seg_count[slot] = (int32_t)(ntot > o.fixed ? ntot - o.fixed : 0u);
+      if (ntot > cap) {
+        atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 1u);
+        atomicMax(o.counters + 2, (int32_t)(ntot - o.fixed));
+      }
     }
+    for (uint32_t i = n + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
   }
   for (uint32_t i = n + tid; i < P; i += kBlock) list_key[i] = ~0ull;
-  for (uint32_t i = n + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
   __syncthreads();
   PYNQS_STAMP(3);
   uint32_t Ps = 64;  // sort only as many entries as there are
@@ -1173,22 +1223,25 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
     }
   }
   PYNQS_STAMP(4);
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(7);  // sort
   // the values, from their order of arrival into the sorted order: every thread fetches its entries' values, then (barrier) stores them
+  const int64_t out_base = seg_base + flushed;
   {
     constexpr int kMaxPer = 8;  // n <= 2048 = 8 x 256
     T mine_w[kMaxPer];
 #pragma unroll
     for (int r = 0; r < kMaxPer; ++r) {
       const uint32_t i = (uint32_t)r * kBlock + tid;
-      mine_w[r] = i < n ? o.rec_w[seg_base + (uint32_t)(list_key[i] & 0xffffffffull)] : T(0);
+      mine_w[r] = i < n ? o.rec_w[out_base + (uint32_t)(list_key[i] & 0xffffffffull)] : T(0);
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kMaxPer; ++r) {
       const uint32_t i = (uint32_t)r * kBlock + tid;
-      if (i < n) o.rec_w[seg_base + i] = mine_w[r];
+      if (i < n) o.rec_w[out_base + i] = mine_w[r];
     }
   }
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(8);  // values into sorted order
   for (uint32_t i0 = 0; i0 < n; i0 += kBlock) {
     const uint32_t i = i0 + tid;
     bool won = false;
@@ -1197,12 +1250,12 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
 #pragma unroll
     for (int w = 0; w < LEN; ++w) ket[w] = wk.w[w];
     if (i < n) {
-      const uint32_t col = (uint32_t)(list_key[i] >> 32);
+      const uint32_t col = (uint32_t)(list_key[i] >> 32) & (FLUSH ? 0x7fffffffu : 0xffffffffu);
       if (col) {
         const Excitation x = decode(col - 1, p, L);
         make_ket<LEN>(wk, x, ket);
       }
-      const int64_t g = seg_base + i;
+      const int64_t g = out_base + i;
       o.rec_col[g] = (int32_t)col;
       if (o.rec_onv) {
 #pragma unroll
@@ -1211,7 +1264,24 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
       link = probe_amplitude<LEN, T>(o, ket, won);
     }
     const int32_t mine = allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
-    if (i < n) o.rec_link[seg_base + i] = final_link<LEN, T>(o, link, mine);
+    if (i < n) o.rec_link[out_base + i] = final_link<LEN, T>(o, link, mine);
+  }
+  flushed += n;
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(9);  // kets, probes, rows, links
+  if (last) break;
+  __syncthreads();  // (everybody is done with the list)
+  if (tid == 0) list_n = 0;
+  __syncthreads();
+  }
+  if constexpr (FLUSH) {
+    if (tid == 0) {
+      o.seg_count[slot] = (int32_t)(needed > o.fixed ? needed - o.fixed : 0u);
+      if (needed > cap) {
+        atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 1u);
+        atomicMax(o.counters + 2, (int32_t)(needed - o.fixed));
+      }
+    }
+    for (uint32_t i = flushed + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
   }
   PYNQS_STAMP(5);
   if constexpr (SAMPLED) {
@@ -1441,6 +1511,15 @@ void reduce_onepass_list_kernel(const uint64_t *__restrict__ bra, SDParams p, Pl
   reduce_onepass_list_body<LEN, T, SAMPLED, CACHED>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
 }
 
+// rows whose kept columns do not fit the list (deterministic): the list is emptied as it fills (FLUSH); ~40 KB of LDS at sorb 120, four
+// workgroups per CU: no register squeeze
+template <int LEN, typename T>
+__global__ __launch_bounds__(kBlock) void reduce_onepass_list_flush_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
+                                                                           uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
+                                                                           uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
+  reduce_onepass_list_body<LEN, T, false, false, true>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
+}
+
 template <int LEN, typename T>
 __global__ __launch_bounds__(kBlock) void reduce_onepass_list_redraw_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
                                                                             uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
@@ -1474,6 +1553,7 @@ __global__ __launch_bounds__(kBlock) void reduce_contract_kernel(int64_t nbatch,
       src = psi_u; at = link - kDirectLink;
       if ((uint32_t)at >= ucap) { bad = true; re = im = 0.0; return; }
     } else if (link >= 0) {
+      if (!dedup_i32) { bad = true; re = im = 0.0; return; }  // (no de-duplication table: every link is direct)
       const int32_t row = dedup_i32[(int64_t)link * slot_i32 + row_off];
       if (row < 0 || (uint32_t)row >= ucap) { bad = true; re = im = 0.0; return; }
       src = psi_u; at = row;
@@ -1568,13 +1648,15 @@ extern "C" int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele,
 constexpr uint32_t kLongRow = 65536;
 struct OnepassForm {
   uint32_t P;
-  bool use_list, use_cache;
+  bool use_list, use_cache, use_flush;
   size_t lds;
 };
+constexpr uint32_t kFlushList = 2048;  // list slots of the flushing form
 static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tiles, uint32_t fixed, uint64_t cap_doubles, int eps_sample,
                                 bool have_cache) {
   static const int list_env = getenv("PYNQS_OP_LIST") ? atoi(getenv("PYNQS_OP_LIST")) : -1;
   static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
+  static const int flush_env = getenv("PYNQS_OP_FLUSH") ? atoi(getenv("PYNQS_OP_FLUSH")) : -1;
   const bool sampled = eps_sample > 0;
   const uint64_t seg_cap = (uint64_t)fixed + cap_doubles;
   OnepassForm f;
@@ -1586,6 +1668,11 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   f.use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024 || p.nsd + 1 > kLongRow));
   f.use_cache = want_cache && f.use_list;
   f.lds = f.use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, winner_list_cap(eps_sample));
+  // the flushing LIST form: deterministic calls on long rows whose kept columns do not fit the list (PYNQS_OP_FLUSH=0 / 1: never / also
+  // on short rows) -- instead of the look-back form
+  const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, false, kFlushList, 0u, false);
+  f.use_flush = !sampled && !f.use_list && flush_env != 0 && (p.nsd + 1 > kLongRow || flush_env == 1) && lds_flush + 256 <= 160 * 1024;
+  if (f.use_flush) { f.P = kFlushList; f.lds = lds_flush; }
   return f;
 }
 
@@ -1600,6 +1687,13 @@ extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int 
   uint32_t nchunks, chunk_len, max_tiles, fixed;
   onepass_geometry(nbatch, p, eps_sample > 0, &nchunks, &chunk_len, &max_tiles, &fixed);
   *cap_doubles = -1;
+  {  // (deterministic calls on long rows: the flushing form takes over where the list ends -- any capacity)
+    const OnepassForm f = onepass_form(p, dtype == PYNQS_F64 ? 8 : 4, max_tiles, fixed, (uint64_t)1 << 29, eps_sample, false);
+    if (f.use_flush && f.lds + onepass_static_lds(0) <= 160 * 1024) {
+      *cap_doubles = ((int64_t)1 << 30) - 1;
+      return PYNQS_OK;
+    }
+  }
   for (uint32_t seg = 2048; seg >= 128; seg >>= 1) {
     if (seg < fixed) break;
     const OnepassForm f = onepass_form(p, dtype == PYNQS_F64 ? 8 : 4, max_tiles, fixed, seg - fixed, eps_sample, with_row_cache != 0);
@@ -1616,7 +1710,7 @@ static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed
   OnepassOut<T> o;
   o.rec_col = io->rec_col; o.rec_w = (T *)io->rec_w; o.rec_onv = io->rec_onv; o.rec_link = io->rec_link; o.seg_count = io->seg_count;
   o.srec_col = io->srec_col; o.srec_w = (T *)io->srec_w; o.srec_onv = io->srec_onv; o.srec_link = io->srec_link; o.row_sum = io->row_sum;
-  o.dedup = (uint64_t *)io->dedup_table; o.dedup_mask = (uint32_t)(io->dedup_slots - 1);
+  o.dedup = (uint64_t *)io->dedup_table; o.dedup_mask = io->dedup_table ? (uint32_t)(io->dedup_slots - 1) : 0u;
   o.lut = (const uint64_t *)io->lut_table; o.lut_cap = io->lut_table ? hash_capacity(io->lut_nkeys) : 0;
   o.uniq_parent = io->uniq_parent; o.parent = 0;
   o.uniq_onv = io->uniq_onv; o.uniq_pm1 = io->uniq_pm1; o.pm1_f32 = io->pm1_dtype == PYNQS_F32; o.ucap = (uint32_t)io->cap_unique;
@@ -1639,18 +1733,20 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   if (eps_sample < 0 || eps_sample > 65535) return set_error(PYNQS_EINVAL, "eps_sample must be in [0, 65535]");
   if (!io) return set_error(PYNQS_EINVAL, "null pointer");
   const bool sampled = eps_sample > 0;
-  if (!io->counters || !io->dedup_table || !io->uniq_onv || !io->rec_col || !io->rec_w || !io->rec_link || !io->seg_count ||
+  if (!io->counters || !io->uniq_onv || !io->rec_col || !io->rec_w || !io->rec_link || !io->seg_count ||
       (sampled && (!io->srec_col || !io->srec_w || !io->srec_link)))
     return set_error(PYNQS_EINVAL, "null pointer");
-  if (io->dedup_slots < 64 || (io->dedup_slots & (io->dedup_slots - 1)) || io->dedup_slots > (1ll << 30) || io->cap_unique < 1 ||
-      2 * io->cap_unique > io->dedup_slots || io->cap_doubles < 0 || io->cap_doubles >= (1ll << 30))
+  if (io->cap_unique < 1 || io->cap_unique >= (1ll << 30) || io->cap_doubles < 0 || io->cap_doubles >= (1ll << 30) ||
+      (io->dedup_table && (io->dedup_slots < 64 || (io->dedup_slots & (io->dedup_slots - 1)) || io->dedup_slots > (1ll << 30) ||
+                           2 * io->cap_unique > io->dedup_slots)))
     return set_error(PYNQS_EINVAL, "bad capacities (dedup_slots: power of two >= 2 * cap_unique)");
   if (io->pm1_dtype != PYNQS_F32 && io->pm1_dtype != PYNQS_F64) return set_error(PYNQS_EINVAL, "bad pm1_dtype");
   if (io->lut_table && io->lut_nkeys < 0) return set_error(PYNQS_EINVAL, "bad lut_nkeys");
   hipStream_t st = (hipStream_t)stream;
   const int len = (sorb - 1) / 64 + 1;
   if (hipMemsetAsync(io->counters, 0, 16, st) != hipSuccess) return check_launch("memset");
-  if (hipMemsetAsync(io->dedup_table, 0xFF, (size_t)io->dedup_slots * dedup_slot_words(len) * 8, st) != hipSuccess) return check_launch("memset");
+  if (io->dedup_table &&
+      hipMemsetAsync(io->dedup_table, 0xFF, (size_t)io->dedup_slots * dedup_slot_words(len) * 8, st) != hipSuccess) return check_launch("memset");
   if (nbatch == 0) return PYNQS_OK;
   if (!bra || !plan) return set_error(PYNQS_EINVAL, "null pointer");
   uint32_t nchunks, chunk_len, max_tiles, fixed;
@@ -1661,18 +1757,21 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
   const OnepassForm form = onepass_form(p, esz, max_tiles, fixed, (uint64_t)io->cap_doubles, eps_sample, io->row_cache != nullptr);
   const uint32_t P = form.P;
-  const bool use_list = form.use_list, use_cache = form.use_cache;
+  const bool use_list = form.use_list || form.use_flush, use_cache = form.use_cache, use_flush = form.use_flush;
   const size_t lds = form.lds;
   if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
+  if (!io->dedup_table && !use_list)
+    return set_error(PYNQS_EINVAL, "no de-duplication table: only the LIST forms run without one (cap_doubles <= pynqs_reduce_onepass_list_capacity)");
   static const bool verbose = getenv("PYNQS_OP_VERBOSE") != nullptr;
   if (verbose)
     fprintf(stderr, "pynqs_reduce_onepass: %s form%s, LDS %zu bytes per workgroup (walker tables %zu, max_tiles %u, list P %u), %u chunk(s) per walker\n",
-            use_list ? "LIST" : "look-back", use_cache ? " with row cache" : "", lds, (size_t)lds_fixed_bytes(p), max_tiles, P, nchunks);
+            use_flush ? "flushing LIST" : use_list ? "LIST" : "look-back", use_cache ? " with row cache" : "", lds, (size_t)lds_fixed_bytes(p), max_tiles, P, nchunks);
   // eloc.py:257-264: with draws and eps <= 0 nothing is kept (every column can be drawn); without draws |H| >= eps as it stands
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
   do {                                                                                                                               \
-    auto kfn = use_list ? (use_cache ? reduce_onepass_list_kernel<LEN, TT, SM, SM>                                                   \
+    auto kfn = use_flush ? reduce_onepass_list_flush_kernel<LEN, TT>                                                                 \
+             : use_list ? (use_cache ? reduce_onepass_list_kernel<LEN, TT, SM, SM>                                                   \
                                      : (SM ? reduce_onepass_list_redraw_kernel<LEN, TT> : reduce_onepass_list_kernel<LEN, TT, false, false>)) \
                         : reduce_onepass_kernel<LEN, TT, SM>;                                                                        \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,      \
@@ -1698,7 +1797,7 @@ extern "C" int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA
   if (nbatch < 0 || nbatch > 0x7fffffffll || (dtype != PYNQS_F32 && dtype != PYNQS_F64) || eps_sample < 0 || eps_sample > 65535)
     return set_error(PYNQS_EINVAL, "bad nbatch/dtype/eps_sample");
   if (nbatch == 0) return PYNQS_OK;
-  if (!io || !io->rec_col || !io->rec_w || !io->rec_link || !io->seg_count || !io->dedup_table || !psi_unique || !eloc || !psi_x ||
+  if (!io || !io->rec_col || !io->rec_w || !io->rec_link || !io->seg_count || !psi_unique || !eloc || !psi_x ||
       (eps_sample > 0 && (!io->srec_col || !io->srec_w || !io->srec_link)) || (io->lut_table && !psi_table))
     return set_error(PYNQS_EINVAL, "null pointer");
   uint32_t nchunks, chunk_len, max_tiles, fixed;

@@ -101,8 +101,16 @@ struct sink_can_skip : std::false_type {};
 template <typename S>
 struct sink_can_skip<S, std::void_t<decltype(std::declval<S &>().skip_tile(0u))>> : std::true_type {};
 
+// optional member of a sink: bool pause() (wave-uniform), asked before a wave takes its next tile -- true: visit_tiles returns (false)
+// with the tile counter untouched, and may be called again later to go on (the flushing LIST form of the REDUCE front end: the
+// workgroup's list is nearly full).  visit_tiles returns true when this wave found the tiles exhausted.
+template <typename S, typename = void>
+struct sink_can_pause : std::false_type {};
+template <typename S>
+struct sink_can_pause<S, std::void_t<decltype(std::declval<S &>().pause())>> : std::true_type {};
+
 template <int LEN, typename T, typename Sink, bool EXACT = true, int QUARTER = kDiagTile / 4>
-__device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
+__device__ __forceinline__ bool visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
                                             uint32_t chunk_len, uint32_t odd_base, uint32_t *next_tile, Sink &sink) {
   constexpr int U = PYNQS_U;           // pair slots per lane and tile (2*U gathers in flight)
@@ -136,6 +144,9 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
   };
 
   for (;;) {
+    if constexpr (sink_can_pause<Sink>::value) {
+      if (sink.pause()) return false;
+    }
     uint32_t tile = 0;
     if (lane == 0) tile = atomicAdd(next_tile, 1u);
     tile = __builtin_amdgcn_readfirstlane(tile);
@@ -253,6 +264,7 @@ __device__ __forceinline__ void visit_tiles(const SDParams &p, const PlanLayout 
       }
     }
   }
+  return true;
 }
 
 }  // namespace pynqs

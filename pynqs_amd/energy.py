@@ -60,8 +60,15 @@ def _side_stream(device):
 # 10.6 / 10.4, sampled 13.0 / 14.6, 2.7 / 3.0 -- its other (look-back) form 22 / 6.1, 94 / 30, 96 / 38, sampled 68 / 14 and 54 / 16.
 FRONT_ROUTE = True
 FRONT_LONG_ROW = 65536   # (= kLongRow of kernels_reduce_onepass.hip)
-FRONT_MAX_CHUNKS = 32    # rows cut into more chunks than this per walker (few walkers, sorb 184): multi-pass (30.8 / 25.9, 4.1 / 3.8 at 64 chunks)
 _FRONT_DENSE: "set[tuple]" = set()   # long-row systems whose kept records outgrew the LDS list (this process)
+# De-duplication of the x' costs random probes into a table of 2-4 slots per distinct determinant: 64 MB for Fe2S2 (8192 walkers, 1.5 M distinct
+# of 10 M records: it stays in the 256 MB cache and saves 85 % of the amplitude evaluations), 1.6 GB at sorb 80 with 4096 walkers, where
+# 21.5 M of 21.5 M records are distinct and the probes cost 16x the enumeration (46.6 against 2.8 ms per launch, tools/onepass_flush_stamps.py).
+# local_energy therefore looks at the first call of a (system, batch size): when more than FRONT_NODEDUP_RATIO of the records were distinct
+# the following calls run without the table (every record its own row; E_loc is the same, the ansatz sees <= 1 / ratio as many rows).
+FRONT_NODEDUP = True
+FRONT_NODEDUP_RATIO = 0.9
+_FRONT_NODEDUP: "dict[tuple, Optional[tuple]]" = {}   # key -> (cap_doubles, cap_unique) of the table-less front end, or None: keep the table
 FUSED_ONEPASS = True  # REDUCE: the one-launch front end (reduce_front.ReduceFrontEnd); False: the multi-pass compaction of round 2
 
 
@@ -522,7 +529,13 @@ def _long_row_cap(n, h1e, sorb, nele, noa, nob, eps_sample) -> Optional[int]:
     return RF.list_capacity(n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype)
 
 
-def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d=None, cap_u=None):
+def _nodedup_key(device, n, sorb, nele, noa, nob, eps_sample) -> tuple:
+    return (str(device), int(n), sorb, nele, noa, nob, int(eps_sample))
+
+
+def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d=None, cap_u=None, dedup=True):
+    if not dedup and cap_d is not None and cap_d > RF.list_capacity(n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype):
+        dedup = True   # (only the LIST forms of the kernel run without the table)
     if cap_d is None:
         nseg, fixed, _, _ = RF.geometry(n, sorb, nele, noa, nob, eps_sample)
         ncomb = get_Num_SinglesDoubles(sorb, noa, nob) + 1
@@ -531,7 +544,7 @@ def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1,
         limit = _long_row_cap(n, h1e, sorb, nele, noa, nob, eps_sample)
         if limit is not None and limit >= 0:
             cap_d = min(cap_d, limit)   # (long rows: start in the LIST form; reduce_front_finish leaves the path if that overflows)
-    return RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype, want_pm1=want_pm1)
+    return RF.ReduceFrontEnd(n, sorb, nele, noa, nob, eps_sample, h1e.dtype, x.device, cap_d, cap_u, pm1_dtype, want_pm1=want_pm1, dedup=dedup)
 
 
 def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
@@ -546,10 +559,12 @@ def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: in
     plan = CX.plan_for(h1e, h2e, sorb, x.device)
     n = x.size(0)
     pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
-    key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype, bool(want_pm1), int(slot))
+    key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype, bool(want_pm1), int(slot), bool(route))
     fe = _FRONTS.pop(key, None)
     if fe is None:
-        fe = _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1)
+        caps = _FRONT_NODEDUP.get(_nodedup_key(x.device, n, sorb, nele, noa, nob, eps_sample)) if (route and FRONT_NODEDUP) else None
+        fe = _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1) if caps is None else \
+            _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, caps[0], caps[1], dedup=False)
     if seed is None:
         seed = _draw_seed() if eps_sample > 0 else 0
     fe.run(x, plan.buf, eps, seed, lut)
@@ -576,12 +591,21 @@ def reduce_front_finish(t):
             _FRONT_DENSE.add(_dense_key(x.device, sorb, nele, noa, nob, eps_sample))
             raise _FrontDense()
         if flags & RF.OVERFLOW_TABLE:
-            cap_u = max(2 * cap_u, int(nu * 1.5))
+            cap_u = max(4 * cap_u, int(nu * 1.5))   # (the kernel stops inserting once the table is full: nu is a lower bound then)
         elif nu > cap_u:
             cap_u = int(nu * 1.25) + 1024
-        fe = _new_front(x.size(0), x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d, cap_u)
+        fe = _new_front(x.size(0), x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d, cap_u, dedup=fe.dedup)
         fe.run(x, t["plan"].buf, t["eps"], t["seed"], t["lut"])
         cnt = fe.counters_host()
+    nk = _nodedup_key(x.device, x.size(0), sorb, nele, noa, nob, eps_sample)
+    if t["route"] and FRONT_NODEDUP and fe.dedup and nk not in _FRONT_NODEDUP:
+        # the first call for this system and batch size: how many of the records were distinct?  (one more read-back, once)
+        records = fe.count_records()
+        list_ok = fe.cap_doubles <= RF.list_capacity(x.size(0), sorb, nele, noa, nob, int(eps_sample), h1e.dtype)
+        if list_ok and t["lut"] is None and cnt[0] > FRONT_NODEDUP_RATIO * records:
+            _FRONT_NODEDUP[nk] = (fe.cap_doubles, int(records * 1.05) + 4096)
+            return fe, cnt[0]   # (not kept: the next call builds the table-less front end)
+        _FRONT_NODEDUP[nk] = None
     _FRONTS[t["key"]] = fe  # (most recently used last)
     while len(_FRONTS) > _MAX_FRONTS:
         _FRONTS.pop(next(iter(_FRONTS)))
@@ -619,9 +643,7 @@ def _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample) -> bool:
     limit = _long_row_cap(x.size(0), h1e, sorb, nele, noa, nob, eps_sample)
     if limit is None:
         return True
-    n = x.size(0)
-    chunks = RF.geometry(n, sorb, nele, noa, nob, int(eps_sample))[0] // max(n, 1)
-    return limit >= 0 and chunks <= FRONT_MAX_CHUNKS and _dense_key(x.device, sorb, nele, noa, nob, eps_sample) not in _FRONT_DENSE
+    return limit >= 0 and _dense_key(x.device, sorb, nele, noa, nob, eps_sample) not in _FRONT_DENSE
 
 
 def local_energy(

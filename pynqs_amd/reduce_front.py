@@ -73,7 +73,8 @@ class ReduceFrontEnd:
     rows for the distinct x'."""
 
     def __init__(self, n: int, sorb: int, nele: int, noa: int, nob: int, eps_sample: int, h_dtype: torch.dtype, device,
-                 cap_doubles: int, cap_unique: int, pm1_dtype: torch.dtype = torch.float64, keep_onv: bool = True, want_pm1: bool = True) -> None:
+                 cap_doubles: int, cap_unique: int, pm1_dtype: torch.dtype = torch.float64, keep_onv: bool = True, want_pm1: bool = True,
+                 dedup: bool = True) -> None:
         if h_dtype not in (torch.float64, torch.float32) or pm1_dtype not in (torch.float64, torch.float32):
             raise TypeError("float32 / float64 only")
         self.n, self.sorb, self.nele, self.noa, self.nob = int(n), sorb, nele, noa, nob
@@ -100,7 +101,10 @@ class ReduceFrontEnd:
         self.srec_onv = torch.zeros((ns, 8 * L), dtype=torch.uint8, device=dev) if keep_onv else None
         self.srec_link = torch.empty(ns, dtype=torch.int32, device=dev)
         self.row_sum = torch.zeros(max(self.n, 1), dtype=torch.float64, device=dev)
-        self.table = torch.empty(table_bytes // 4, dtype=torch.int32, device=dev)
+        # dedup = False: no de-duplication table -- every record gets its own row of the distinct list (uniq_onv then holds duplicates and
+        # `counters[0]` counts records); for systems whose x' are nearly all distinct, where the table would be gigabytes of random probes
+        self.dedup = bool(dedup)
+        self.table = torch.empty(table_bytes // 4, dtype=torch.int32, device=dev) if self.dedup else None
         self.slot_i32 = table_bytes // 4 // self.dedup_slots
         self.row_off = 2 if L == 1 else 1
         self.uniq_onv = torch.zeros((self.cap_unique, 8 * L), dtype=torch.uint8, device=dev)
@@ -130,7 +134,7 @@ class ReduceFrontEnd:
         io.srec_col, io.srec_w = self.srec_col.data_ptr(), (self.srec_w if srec_w is None else srec_w).data_ptr()
         io.srec_onv = self.srec_onv.data_ptr() if self.srec_onv is not None else None
         io.srec_link, io.row_sum = self.srec_link.data_ptr(), self.row_sum.data_ptr()
-        io.dedup_table, io.uniq_onv = self.table.data_ptr(), self.uniq_onv.data_ptr()
+        io.dedup_table, io.uniq_onv = (self.table.data_ptr() if self.table is not None else None), self.uniq_onv.data_ptr()
         io.uniq_pm1 = self.uniq_pm1.data_ptr() if self.uniq_pm1 is not None else None
         io.pm1_dtype = N.PYNQS_F64 if self.pm1_dtype == torch.float64 else N.PYNQS_F32
         io.lut_is_hash = 1
@@ -199,6 +203,16 @@ class ReduceFrontEnd:
         if not bool(direct.all()):
             rows = torch.where(direct, rows, self.table_rows().long()[torch.where(direct, torch.zeros_like(link), link)])
         return rows
+
+    def count_records(self) -> int:
+        """number of valid kept + drawn records of the last call (synchronises)"""
+        col = self.rec_col.view(self.nseg, self.stride)
+        slot = torch.arange(self.stride, device=self.device).unsqueeze(0)
+        kept = self.seg_count[: self.nseg].clamp(max=self.cap_doubles).unsqueeze(1)
+        m = int(torch.where(slot < self.fixed, col >= 0, slot < self.fixed + kept).sum())
+        if self.eps_sample > 0:
+            m += int((self.srec_col[: self.n * self.eps_sample] >= 0).sum())
+        return m
 
     def records(self):
         """Flat view of the valid records, for the host-side algebra of the projected / multi-psi forms and for tests (synchronises):

@@ -1,6 +1,7 @@
-"""REDUCE on long rows (more than energy.FRONT_LONG_ROW columns): local_energy uses the one-launch front end while a segment's kept records
-fit its LDS list and the multi-pass path once they do not (energy._FRONT_DENSE) -- the same local energies either way (the reference's
-_reduce_psi, vmc/energy/eloc.py:205-324, through the generic tensor path as the check)."""
+"""REDUCE on long rows (more than energy.FRONT_LONG_ROW columns; the reference's _reduce_psi, vmc/energy/eloc.py:205-324):
+* the flushing LIST form of the one-launch front end (the list is emptied as it fills) against the multi-pass kernels, record by record;
+* the table-less mode (no de-duplication when nearly all x' are distinct) against the generic tensor path;
+* the routing of the semi-stochastic form: the front end while a segment's records fit its list, the multi-pass path afterwards."""
 import pytest
 import torch
 
@@ -19,22 +20,41 @@ def _case(sorb, no, n):
     return x, h1, h2, RealRBM(r(sorb // 2, sorb), r(sorb // 2), r(sorb)).to(dev)
 
 
-def test_long_rows_leave_the_front_end_when_the_list_overflows(monkeypatch):
-    from pynqs_amd import energy as E, public_function as pf, reduce_front as RF
+@pytest.mark.parametrize("sorb,no,n,eps", [(80, 20, 300, 0.3), (80, 20, 5000, 0.49), (136, 4, 4100, 0.47)])
+def test_flushing_list_form_writes_the_records_of_the_multi_pass_kernels(sorb, no, n, eps):
+    """(col, <x|H|x'>, x') of every kept column, walker by walker in ascending columns (column 0 and the unpaired doubles of tile 0 first),
+    bit for bit; the distinct list holds every x' once; rows cut into chunks (300 walkers) and whole rows (5000)."""
+    from pynqs_amd import energy as E, reduce_front as RF
+
+    x, h1, h2, _ = _case(sorb, no, n)
+    assert E.get_Num_SinglesDoubles(sorb, no, no) + 1 > E.FRONT_LONG_ROW
+    assert RF.list_capacity(n, sorb, 2 * no, no, no, 0) == (1 << 30) - 1
+    fe, nu = E.reduce_front(x, h1, h2, sorb, 2 * no, no, no, eps, want_pm1=False)
+    assert fe.cap_doubles + fe.fixed > 2048   # (more than a list holds: several flushes per segment)
+    w, col, h, link, onv, _ = fe.records()
+    row, col2, onv2, h2_, counts = E.reduce_compact(x, h1, h2, sorb, 2 * no, no, no, eps, sort=True)
+    assert w.numel() == row.numel() and int(counts.sum()) == w.numel()
+    k1 = torch.argsort((w << 32) | col.long(), stable=True)
+    assert torch.equal(w[k1], row) and torch.equal(col[k1], col2) and torch.equal(h[k1], h2_) and torch.equal(onv[k1], onv2)
+    # inside a segment: ascending columns after the entries of tile 0
+    c = fe.rec_col.view(fe.nseg, fe.stride)[0, : fe.fixed + int(fe.seg_count[0])].long()
+    c = c[c >= 0]
+    assert int((c[1:] < c[:-1]).sum()) <= 6   # (at most the few unpaired doubles in front are out of order)
+    # links: every record points at a row holding its determinant; rows are distinct
+    rows = fe.rows_of(link)
+    assert torch.equal(fe.uniq_onv[rows], onv)
+    assert torch.unique(fe.uniq_onv[:nu], dim=0).size(0) == nu
+
+
+def test_long_rows_drop_the_table_when_everything_is_distinct(monkeypatch):
+    from pynqs_amd import energy as E, public_function as pf
 
     sorb, no, n = 80, 20, 320
     x, h1, h2, m = _case(sorb, no, n)
     dev = x.device
     ab = lambda xx, func: pf.ansatz_batch(func, xx, 1 << 20, sorb, dev, torch.float64)  # noqa: E731
-    monkeypatch.setattr(E, "_FRONT_DENSE", set())
-    monkeypatch.setattr(E, "_FRONTS", {})
-    assert E.get_Num_SinglesDoubles(sorb, no, no) + 1 > E.FRONT_LONG_ROW
-    limit = RF.list_capacity(n, sorb, 2 * no, no, no, 0)
-    assert limit > 0 and E._front_ok(x, h1, sorb, 2 * no, no, no, 0)
-    calls = {"front": 0, "multi": 0}
-    run, compact = RF.ReduceFrontEnd.run, E.reduce_compact
-    monkeypatch.setattr(RF.ReduceFrontEnd, "run", lambda self, *a, **k: (calls.__setitem__("front", calls["front"] + 1), run(self, *a, **k))[1])
-    monkeypatch.setattr(E, "reduce_compact", lambda *a, **k: (calls.__setitem__("multi", calls["multi"] + 1), compact(*a, **k))[1])
+    for name, val in (("_FRONT_DENSE", set()), ("_FRONTS", {}), ("_FRONT_NODEDUP", {})):
+        monkeypatch.setattr(E, name, val)
 
     def energies(eps, xs=x):
         return E.local_energy(xs, h1, h2, m, ab, sorb, 2 * no, no, no, reduce_psi=True, eps=eps)[0]
@@ -47,35 +67,66 @@ def test_long_rows_leave_the_front_end_when_the_list_overflows(monkeypatch):
         assert bool((torch.isfinite(e[:6]) == ok).all()) and bool(ok.any())
         assert float((e[:6] - want)[ok].abs().max()) < 1e-8  # Ha
 
-    # sparse: the LIST form of the front end
-    e1 = energies(0.4997)
-    assert calls["front"] >= 1 and calls["multi"] == 0   # (the first call may repeat itself to grow its buffers)
-    nf = calls["front"]
+    e1 = energies(0.3)             # first call: with the table; nearly every x' turns out distinct
+    check(e1, 0.3)
+    (key, caps), = E._FRONT_NODEDUP.items()
+    assert caps is not None and not E._FRONTS
+    e2 = energies(0.3)             # table-less from now on
     fe = next(iter(E._FRONTS.values()))
-    assert fe.cap_doubles <= limit and not E._FRONT_DENSE
-    check(e1, 0.4997)
-    # dense: the list overflows, the call is served by the multi-pass path and so are the following ones
-    e2 = energies(0.3)
-    assert calls["multi"] == 1 and calls["front"] == nf + 1 and len(E._FRONT_DENSE) == 1
-    assert not E._front_ok(x, h1, sorb, 2 * no, no, no, 0)
-    check(e2, 0.3)
+    assert fe.table is None and not fe.dedup
+    both = torch.isfinite(e1)
+    assert bool((torch.isfinite(e2) == both).all()) and float((e2 - e1)[both].abs().max()) < 1e-10
     e3 = energies(0.3)
-    assert calls["multi"] == 2 and calls["front"] == nf + 1 and torch.equal(torch.nan_to_num(e3), torch.nan_to_num(e2))
-    # total_energy with look-ahead tickets takes the same turn (on walkers whose diagonal survives eps: it refuses NaN)
-    fin = torch.isfinite(e2).nonzero().flatten()[:256]
-    assert fin.numel() == 256
-    monkeypatch.setattr(E, "_FRONT_DENSE", set())
-    monkeypatch.setattr(E, "_FRONTS", {})
-    nf, nm = calls["front"], calls["multi"]
+    assert torch.equal(torch.nan_to_num(e3), torch.nan_to_num(e2))
+    # total_energy (look-ahead tickets, two workspaces) on the walkers whose diagonal survives eps
+    fin = both.nonzero().flatten()[:256]
     et = E.total_energy(x[fin].contiguous(), 128, -1, h1, h2, m, sorb, 2 * no, no, no, reduce_psi=True, eps=0.3)[0]
-    assert float((et - e2[fin]).abs().max()) < 1e-9 and len(E._FRONT_DENSE) == 1
-    assert calls["multi"] == nm + 2 and calls["front"] > nf   # chunk 0 overflowed its list; chunk 1's ticket was in flight and is dropped
-    # forced (FRONT_ROUTE = False): the front end's other form, same numbers
-    monkeypatch.setattr(E, "FRONT_ROUTE", False)
+    assert float((et - e1[fin]).abs().max()) < 1e-9
+    # Fe2S2-like duplication keeps the table: walkers repeated four times
+    monkeypatch.setattr(E, "_FRONT_NODEDUP", {})
     monkeypatch.setattr(E, "_FRONTS", {})
-    e4 = energies(0.3)
-    both = torch.isfinite(e2) & torch.isfinite(e4)
-    assert bool((torch.isfinite(e2) == torch.isfinite(e4)).all()) and float((e4 - e2)[both].abs().max()) < 1e-9
+    xr = x[:64].repeat(4, 1).contiguous()
+    er = energies(0.3, xr)
+    (key, caps), = E._FRONT_NODEDUP.items()
+    assert caps is None and next(iter(E._FRONTS.values())).dedup
+    ok = torch.isfinite(er[:64])
+    assert float((er[:64] - e1[:64])[ok].abs().max()) < 1e-10
+
+
+def test_semi_stochastic_long_rows_leave_the_front_end_when_the_list_overflows(monkeypatch):
+    from pynqs_amd import energy as E, public_function as pf, reduce_front as RF
+
+    sorb, no, n, ns = 80, 20, 128, 200
+    x, h1, h2, m = _case(sorb, no, n)
+    dev = x.device
+    ab = lambda xx, func: pf.ansatz_batch(func, xx, 1 << 20, sorb, dev, torch.float64)  # noqa: E731
+    for name, val in (("_FRONT_DENSE", set()), ("_FRONTS", {}), ("_FRONT_NODEDUP", {})):
+        monkeypatch.setattr(E, name, val)
+    limit = RF.list_capacity(n, sorb, 2 * no, no, no, ns)
+    assert 0 < limit < 2048 and E._front_ok(x, h1, sorb, 2 * no, no, no, ns)
+    calls = {"front": 0, "multi": 0}
+    run, compact = RF.ReduceFrontEnd.run, E.reduce_compact_sampled
+    monkeypatch.setattr(RF.ReduceFrontEnd, "run", lambda self, *a, **k: (calls.__setitem__("front", calls["front"] + 1), run(self, *a, **k))[1])
+    monkeypatch.setattr(E, "reduce_compact_sampled", lambda *a, **k: (calls.__setitem__("multi", calls["multi"] + 1), compact(*a, **k))[1])
+
+    def energies(eps):
+        torch.manual_seed(5)
+        return E.local_energy(x, h1, h2, m, ab, sorb, 2 * no, no, no, reduce_psi=True, eps=eps, eps_sample=ns)[0]
+
+    e1 = energies(0.4999)          # a few dozen kept columns per row: the LIST form
+    assert calls["front"] >= 1 and calls["multi"] == 0 and not E._FRONT_DENSE
+    nf = calls["front"]
+    e2 = energies(0.47)            # thousands: the list overflows, the call and the following ones take the multi-pass path
+    assert calls["multi"] == 1 and calls["front"] == nf + 1 and len(E._FRONT_DENSE) == 1
+    assert not E._front_ok(x, h1, sorb, 2 * no, no, no, ns)
+    e3 = energies(0.47)
+    assert calls["multi"] == 2 and calls["front"] == nf + 1
+    # the deterministic form of the same system is not affected (the flushing form has no limit)
+    assert E._front_ok(x, h1, sorb, 2 * no, no, no, 0)
+    # same walkers without a diagonal above eps (NaN there, as in the reference), finite elsewhere
+    ed = E.local_energy(x, h1, h2, m, ab, sorb, 2 * no, no, no, reduce_psi=True, eps=0.47)[0]
+    assert bool((torch.isfinite(e2) == torch.isfinite(ed)).all()) and bool((torch.isfinite(e3) == torch.isfinite(ed)).all())
+    assert int(torch.isfinite(e1).sum()) > n // 2
 
 
 def test_short_rows_stay_on_the_front_end(fe2s2):

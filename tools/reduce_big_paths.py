@@ -15,7 +15,7 @@ torch.set_default_dtype(torch.float64)
 
 
 def timeit(fn, reps=3):
-    fn(); torch.cuda.synchronize()
+    fn(); fn(); fn(); torch.cuda.synchronize()   # (the first call sizes the buffers, the second may switch the de-duplication off)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
@@ -46,10 +46,13 @@ for case in sys.argv[1:]:
         E.FRONT_ROUTE = route   # (False: the one-launch front end whatever the row length)
         E._FRONTS.clear()
         E._FRONT_DENSE.clear()
+        E._FRONT_NODEDUP.clear()
         fn = lambda: E.local_energy(x, h1, h2, m, ab, sorb, 2 * no, no, no, reduce_psi=True, eps=eps, eps_sample=ns)[0]
         t, e = timeit(fn)
         res[name] = e
         where = " (took the multi-pass path)" if route and not E._front_ok(x, h1, sorb, 2 * no, no, no, ns) else ""
+        if route and any(v is not None for v in E._FRONT_NODEDUP.values()):
+            where += " (without the de-duplication table)"
         print(f"sorb {sorb}, {n} walkers, eps {eps}, eps_sample {ns}: {name:22s} {t:9.3f} ms per call{where}", flush=True)
     a, b = res[modes[0][0]], res[modes[1][0]]
     both = torch.isfinite(a) & torch.isfinite(b)
