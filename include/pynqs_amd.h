@@ -326,9 +326,12 @@ int pynqs_reduce_sample(const uint64_t *bra, int64_t nbatch, int sorb, int nele,
  *                                   (dedup_slots passed in out[2] on entry), out[3] = 1 if the fused form exists for
  *                                   this system (LDS budget), else 0
  *   pynqs_reduce_onepass_list_capacity : [host] the largest io->cap_doubles with which pynqs_reduce_onepass keeps a segment's
- *                                   records in an LDS list (its fast form on rows of more than 65536 columns: beyond it such a
- *                                   row is served faster by the multi-pass entry points, pynqs_reduce_count / _emit), or -1;
- *                                   with_row_cache: whether io->row_cache will be given
+ *                                   records in an LDS list -- its LIST form (one list per segment) or, without draws, the flushing
+ *                                   form (the list is emptied as it fills: 2^30 - 1 = any capacity on rows of more than 65536
+ *                                   columns and whenever there is no de-duplication table, else a tenth of a segment's columns);
+ *                                   -1: never.  Beyond it the look-back form runs, which long rows should avoid (the multi-pass entry
+ *                                   points pynqs_reduce_count / _emit are 2-4 x faster there).  with_row_cache / without_table: whether
+ *                                   io->row_cache will be given / io->dedup_table will be NULL
  *   pynqs_reduce_onepass          : the launch (memsets of the de-duplication table and counters included)
  *   pynqs_reduce_contract         : eloc[x] = sum_records w A(x') / A(x) (divide = 1) or sum_records w A(x') (divide = 0) and
  *                                   psi_x[x] = A(x), from the records (io->rec_w / srec_w: any weights in the records' slot
@@ -376,7 +379,7 @@ typedef struct pynqs_reduce_io {
 } pynqs_reduce_io;
 int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
 int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
-                                       int with_row_cache, int64_t *cap_doubles);
+                                       int with_row_cache, int without_table, int64_t *cap_doubles);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                          int dtype, double eps, int eps_sample, uint64_t seed, const pynqs_reduce_io *io, void *stream);
 int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,

@@ -812,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_kernel(const uint64_t *
 // resolution), which four 256-thread workgroups per CU hide behind each other's enumeration.)
 
 template <int LEN, typename T>
-__device__ __forceinline__ int32_t probe_amplitude(const OnepassOut<T> &o, const uint64_t (&ket)[LEN], bool &won) {
+__device__ __forceinline__ int32_t probe_amplitude(const OnepassOut<T> &o, const uint64_t (&ket)[LEN], bool &won, uint32_t *full_flag = nullptr) {
   won = false;
   if (o.debug & 1u) return -1;
   if (o.lut) {
@@ -823,13 +823,16 @@ __device__ __forceinline__ int32_t probe_amplitude(const OnepassOut<T> &o, const
     won = true;
     return 0;
   }
-  // a call whose table has overflowed is going to be repeated with a larger one: do not walk the full table for every further record
-  // (each probe then runs to its limit: 0.3 - 0.7 s per launch at sorb 80 with 4096 walkers before this check)
-  if (__hip_atomic_load(o.counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) return -1;
+  // a call whose table has overflowed is going to be repeated with a larger one: once a probe of this WORKGROUP has run to its limit
+  // (full_flag, in LDS) its further records skip the table (every probe of a full table walks kProbeLimit slots: 0.3 - 0.7 s per launch
+  // at sorb 80 with 4096 walkers).  Not the global overflow word: even ONE load of it per workgroup waits behind the row counter's
+  // atomics on the same line (Fe2S2 step 0.94 -> 1.18 ms), one per record is 10^7 requests to one L2 channel (2.3 ms).
+  if (full_flag && *full_flag) return -1;
   const uint32_t s = dedup_insert<LEN>(o.dedup, o.dedup_mask, ket, won);
   if (s == 0xffffffffu) {
     won = false;
     atomicOr(reinterpret_cast<unsigned int *>(o.counters + 1), 2u);
+    if (full_flag) *full_flag = 1u;
     return -1;
   }
   return (int32_t)s;
@@ -1133,7 +1136,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
                                                          uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(!FLUSH || (!SAMPLED && !CACHED), "the flushing form has no draws");
-  __shared__ uint32_t next_tile, list_n, bw_cnt, s_done;
+  __shared__ uint32_t next_tile, list_n, bw_cnt, s_done, s_full;
   __shared__ int32_t bw_base;
   __shared__ double s_part[kBlock / 64 + 1];
   __shared__ uint32_t s_parti[kBlock / 64 + 1];
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P unless FLUSH)
   const int64_t seg_base = (int64_t)slot * cap;
-  if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; s_done = 0; }
+  if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; s_done = 0; s_full = 0; }
   unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED, CACHED);
   double *tsum = reinterpret_cast<double *>(extra);
   uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
@@ -1261,7 +1264,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
 #pragma unroll
         for (int w = 0; w < LEN; ++w) o.rec_onv[g * LEN + w] = ket[w];
       }
-      link = probe_amplitude<LEN, T>(o, ket, won);
+      link = probe_amplitude<LEN, T>(o, ket, won, &s_full);
     }
     const int32_t mine = allocate_batch<LEN, T>(o, p.sorb, won, (uint32_t)link, ket, &bw_cnt, &bw_base);
     if (i < n) o.rec_link[out_base + i] = final_link<LEN, T>(o, link, mine);
@@ -1653,7 +1656,7 @@ struct OnepassForm {
 };
 constexpr uint32_t kFlushList = 2048;  // list slots of the flushing form
 static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tiles, uint32_t fixed, uint64_t cap_doubles, int eps_sample,
-                                bool have_cache) {
+                                bool have_cache, uint32_t chunk_len, bool no_table) {
   static const int list_env = getenv("PYNQS_OP_LIST") ? atoi(getenv("PYNQS_OP_LIST")) : -1;
   static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
   static const int flush_env = getenv("PYNQS_OP_FLUSH") ? atoi(getenv("PYNQS_OP_FLUSH")) : -1;
@@ -1668,16 +1671,19 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   f.use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024 || p.nsd + 1 > kLongRow));
   f.use_cache = want_cache && f.use_list;
   f.lds = f.use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, winner_list_cap(eps_sample));
-  // the flushing LIST form: deterministic calls on long rows whose kept columns do not fit the list (PYNQS_OP_FLUSH=0 / 1: never / also
-  // on short rows) -- instead of the look-back form
+  // the flushing LIST form: deterministic calls whose kept columns do not fit the list -- on long rows, on any row when at most a tenth
+  // of a segment's columns can be kept (a flush costs a sort of 2048 entries; the look-back form pays per tile instead: Fe2S2 with 9 % kept
+  // 0.81 look-back against 2.45 ms, sorb 56 with 6 % 6.5 against 3.7, sorb 80 with 10 % / 40 % 103 / 292 against 71 / 269), and whenever
+  // there is no de-duplication table (the look-back form needs one).  PYNQS_OP_FLUSH=0 / 1: never / wherever possible.
   const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, false, kFlushList, 0u, false);
-  f.use_flush = !sampled && !f.use_list && flush_env != 0 && (p.nsd + 1 > kLongRow || flush_env == 1) && lds_flush + 256 <= 160 * 1024;
+  f.use_flush = !sampled && !f.use_list && flush_env != 0 && lds_flush + 256 <= 160 * 1024 &&
+                (p.nsd + 1 > kLongRow || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len);
   if (f.use_flush) { f.P = kFlushList; f.lds = lds_flush; }
   return f;
 }
 
 extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
-                                                  int with_row_cache, int64_t *cap_doubles) {
+                                                  int with_row_cache, int without_table, int64_t *cap_doubles) {
   SDParams p;
   PlanLayout pl;
   if (!cap_doubles) return set_error(PYNQS_EINVAL, "null pointer");
@@ -1686,22 +1692,19 @@ extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int 
     return set_error(PYNQS_EINVAL, "bad nbatch / eps_sample / dtype");
   uint32_t nchunks, chunk_len, max_tiles, fixed;
   onepass_geometry(nbatch, p, eps_sample > 0, &nchunks, &chunk_len, &max_tiles, &fixed);
+  const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
+  auto listed = [&](uint64_t cap) {
+    const OnepassForm f = onepass_form(p, esz, max_tiles, fixed, cap, eps_sample, with_row_cache != 0, chunk_len, without_table != 0);
+    return (f.use_list || f.use_flush) && f.lds + onepass_static_lds(0) <= 160 * 1024;
+  };
   *cap_doubles = -1;
-  {  // (deterministic calls on long rows: the flushing form takes over where the list ends -- any capacity)
-    const OnepassForm f = onepass_form(p, dtype == PYNQS_F64 ? 8 : 4, max_tiles, fixed, (uint64_t)1 << 29, eps_sample, false);
-    if (f.use_flush && f.lds + onepass_static_lds(0) <= 160 * 1024) {
-      *cap_doubles = ((int64_t)1 << 30) - 1;
-      return PYNQS_OK;
-    }
-  }
+  // (the forms are monotonic in the capacity: LIST up to a limit, then possibly the flushing form up to another, or without one)
+  if (listed((uint64_t)1 << 29)) { *cap_doubles = ((int64_t)1 << 30) - 1; return PYNQS_OK; }
   for (uint32_t seg = 2048; seg >= 128; seg >>= 1) {
     if (seg < fixed) break;
-    const OnepassForm f = onepass_form(p, dtype == PYNQS_F64 ? 8 : 4, max_tiles, fixed, seg - fixed, eps_sample, with_row_cache != 0);
-    if (f.use_list && f.lds + onepass_static_lds(0) <= 160 * 1024) {
-      *cap_doubles = (int64_t)(seg - fixed);
-      break;
-    }
+    if (listed(seg - fixed)) { *cap_doubles = (int64_t)(seg - fixed); break; }
   }
+  if ((int64_t)(chunk_len / 10) > *cap_doubles && listed(chunk_len / 10)) *cap_doubles = chunk_len / 10;
   return PYNQS_OK;
 }
 
@@ -1755,7 +1758,8 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   if (grid * ((uint64_t)fixed + (uint64_t)io->cap_doubles) > 0x7fffffffull * 16ull) return set_error(PYNQS_EINVAL, "record arrays too large");
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
-  const OnepassForm form = onepass_form(p, esz, max_tiles, fixed, (uint64_t)io->cap_doubles, eps_sample, io->row_cache != nullptr);
+  const OnepassForm form = onepass_form(p, esz, max_tiles, fixed, (uint64_t)io->cap_doubles, eps_sample, io->row_cache != nullptr, chunk_len,
+                                        io->dedup_table == nullptr);
   const uint32_t P = form.P;
   const bool use_list = form.use_list || form.use_flush, use_cache = form.use_cache, use_flush = form.use_flush;
   const size_t lds = form.lds;

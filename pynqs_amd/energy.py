@@ -66,7 +66,7 @@ _FRONT_DENSE: "set[tuple]" = set()   # long-row systems whose kept records outgr
 # 21.5 M of 21.5 M records are distinct and the probes cost 16x the enumeration (46.6 against 2.8 ms per launch, tools/onepass_flush_stamps.py).
 # local_energy therefore looks at the first call of a (system, batch size): when more than FRONT_NODEDUP_RATIO of the records were distinct
 # the following calls run without the table (every record its own row; E_loc is the same, the ansatz sees <= 1 / ratio as many rows).
-FRONT_NODEDUP = True
+FRONT_NODEDUP = __import__("os").environ.get("PYNQS_FRONT_NODEDUP", "1") != "0"
 FRONT_NODEDUP_RATIO = 0.9
 _FRONT_NODEDUP: "dict[tuple, Optional[tuple]]" = {}   # key -> (cap_doubles, cap_unique) of the table-less front end, or None: keep the table
 FUSED_ONEPASS = True  # REDUCE: the one-launch front end (reduce_front.ReduceFrontEnd); False: the multi-pass compaction of round 2
@@ -534,7 +534,7 @@ def _nodedup_key(device, n, sorb, nele, noa, nob, eps_sample) -> tuple:
 
 
 def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d=None, cap_u=None, dedup=True):
-    if not dedup and cap_d is not None and cap_d > RF.list_capacity(n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype):
+    if not dedup and cap_d is not None and cap_d > RF.list_capacity(n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, without_table=True):
         dedup = True   # (only the LIST forms of the kernel run without the table)
     if cap_d is None:
         nseg, fixed, _, _ = RF.geometry(n, sorb, nele, noa, nob, eps_sample)
@@ -601,7 +601,7 @@ def reduce_front_finish(t):
     if t["route"] and FRONT_NODEDUP and fe.dedup and nk not in _FRONT_NODEDUP:
         # the first call for this system and batch size: how many of the records were distinct?  (one more read-back, once)
         records = fe.count_records()
-        list_ok = fe.cap_doubles <= RF.list_capacity(x.size(0), sorb, nele, noa, nob, int(eps_sample), h1e.dtype)
+        list_ok = fe.cap_doubles <= RF.list_capacity(x.size(0), sorb, nele, noa, nob, int(eps_sample), h1e.dtype, without_table=True)
         if list_ok and t["lut"] is None and cnt[0] > FRONT_NODEDUP_RATIO * records:
             _FRONT_NODEDUP[nk] = (fe.cap_doubles, int(records * 1.05) + 4096)
             return fe, cnt[0]   # (not kept: the next call builds the table-less front end)

@@ -55,15 +55,17 @@ def wants_row_cache(n: int, ncomb: int, eps_sample: int, nchunks: int, esz: int)
     return bool(eps_sample > 0 and nchunks == 1 and ROW_CACHE and eps_sample * 64 >= ncomb and n * ncomb * esz <= ROW_CACHE_MAX_BYTES)
 
 
-def list_capacity(n: int, sorb: int, nele: int, noa: int, nob: int, eps_sample: int, h_dtype: torch.dtype = torch.float64) -> int:
-    """Largest cap_doubles with which the kernel keeps a segment's records in an LDS list (pynqs_reduce_onepass_list_capacity), or -1."""
+def list_capacity(n: int, sorb: int, nele: int, noa: int, nob: int, eps_sample: int, h_dtype: torch.dtype = torch.float64,
+                  without_table: bool = False) -> int:
+    """Largest cap_doubles with which the kernel keeps a segment's records in an LDS list (its LIST form or the flushing form;
+    pynqs_reduce_onepass_list_capacity), or -1.  without_table: for a front end built with dedup=False."""
     ncomb = int(N.lib().pynqs_num_sd(sorb, noa, nob)) + 1
     esz = 8 if h_dtype == torch.float64 else 4
     nseg = geometry(n, sorb, nele, noa, nob, eps_sample)[0]
     cache = wants_row_cache(n, ncomb, int(eps_sample), nseg // max(n, 1) if n else 1, esz)
     out = C.c_int64(-1)
     N.check(N.lib().pynqs_reduce_onepass_list_capacity(n, sorb, nele, noa, nob, N.PYNQS_F64 if esz == 8 else N.PYNQS_F32, int(eps_sample),
-                                                       int(cache), C.byref(out)), "pynqs_reduce_onepass_list_capacity")
+                                                       int(cache), int(without_table), C.byref(out)), "pynqs_reduce_onepass_list_capacity")
     return int(out.value)
 
 

@@ -46,6 +46,51 @@ def test_flushing_list_form_writes_the_records_of_the_multi_pass_kernels(sorb, n
     assert torch.unique(fe.uniq_onv[:nu], dim=0).size(0) == nu
 
 
+@pytest.mark.parametrize("system,eps,dedup", [("fe2s2", 1e-12, False), ("fe2s2", 1e-3, False), ("sorb56", 0.47, True), ("sorb56", 0.47, False), ("sorb56", 0.2, False)])
+def test_short_rows_in_the_flushing_form_and_without_the_table(system, eps, dedup, fe2s2):
+    """Short rows take the flushing form when at most a tenth of the columns is kept (sorb 56, eps 0.47: 6 %) and whenever there is no
+    de-duplication table (ReduceFrontEnd(dedup=False): every record its own row): records as the multi-pass kernels write them."""
+    import numpy as np
+    from pynqs_amd import C_extension as cx, energy as E, reduce_front as RF
+
+    dev = torch.device("cuda")
+    if system == "fe2s2":
+        sorb, no, n = 40, 15, 4096
+        x = torch.from_numpy(np.ascontiguousarray(fe2s2["ci_space"][:n])).to(dev)
+        h1, h2 = torch.from_numpy(fe2s2["h1e"]).to(dev), torch.from_numpy(fe2s2["h2e"]).to(dev)
+    else:
+        sorb, no, n = 56, 7, 4100
+        x, h1, h2, _ = _case(sorb, no, n)
+    row, col2, onv2, h2_, counts = E.reduce_compact(x, h1, h2, sorb, 2 * no, no, no, eps, sort=True)
+    cap_d = int(counts.max()) + 8
+    assert cap_d <= RF.list_capacity(n, sorb, 2 * no, no, no, 0, without_table=not dedup)
+    assert cap_d + RF.geometry(n, sorb, 2 * no, no, no, 0)[1] > 1024      # (not the plain LIST form)
+    fe = RF.ReduceFrontEnd(n, sorb, 2 * no, no, no, 0, torch.float64, dev, cap_d, int(counts.sum()) + 64, want_pm1=False, dedup=dedup)
+    fe.run(x, cx.plan_for(h1, h2, sorb, dev).buf, eps)
+    nu, flags, _ = fe.counters_host()
+    assert flags == 0
+    w, col, h, link, onv, _ = fe.records()
+    assert w.numel() == row.numel() == fe.count_records()
+    k1 = torch.argsort((w << 32) | col.long(), stable=True)
+    assert torch.equal(w[k1], row) and torch.equal(col[k1], col2) and torch.equal(h[k1], h2_) and torch.equal(onv[k1], onv2)
+    rows = fe.rows_of(link)
+    assert torch.equal(fe.uniq_onv[rows], onv)
+    if dedup:
+        assert torch.unique(fe.uniq_onv[:nu], dim=0).size(0) == nu   # (a row's parent: whichever walker's record inserted it first)
+    else:
+        assert nu == w.numel() and torch.unique(rows).numel() == nu and bool((link >= (1 << 30)).all())
+        assert torch.equal(fe.uniq_parent[rows].long(), w)
+    # the contraction on these records: sum_k h_k A(x'_k) / A(x) with A = a function of the determinant's bytes
+    a = (fe.uniq_onv[:nu].double() * torch.arange(1, fe.uniq_onv.size(1) + 1, device=dev).double()).sum(1).cos() + 2.0
+    eloc, ax = fe.contract(a)
+    a_rec = (onv2.double() * torch.arange(1, onv2.size(1) + 1, device=dev).double()).sum(1).cos() + 2.0
+    first = torch.zeros(n, dtype=torch.float64, device=dev)
+    first[row[col2 == 0]] = a_rec[col2 == 0]
+    want = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, row, h2_ * a_rec) / first
+    ok = first != 0
+    assert bool(ok.any()) and float((eloc - want)[ok].abs().max()) < 1e-9 * float(want[ok].abs().max())
+
+
 def test_long_rows_drop_the_table_when_everything_is_distinct(monkeypatch):
     from pynqs_amd import energy as E, public_function as pf
 

@@ -18,7 +18,11 @@ h1, h2 = (t.to(dev) for t in B.synth_integrals(sorb))
 g = torch.Generator().manual_seed(1)
 m = RealRBM(0.02 * (torch.rand(sorb, sorb, generator=g) - 0.5), 0.02 * (torch.rand(sorb, generator=g) - 0.5), 0.05 * (torch.rand(sorb, generator=g) - 0.5)).to(dev)
 ab = lambda xx, func: pf.ansatz_batch(func, xx, 1 << 22, sorb, dev, torch.float64)
-for _ in range(reps):
+import time
+for r in range(reps):
+    torch.cuda.synchronize(); t0 = time.time()
     e = E.local_energy(x, h1, h2, m, ab, sorb, 2 * no, no, no, reduce_psi=True, eps=eps, eps_sample=ns)[0]
+    torch.cuda.synchronize()
+    print(f"call {r}: {(time.time() - t0) * 1e3:.1f} ms (wall, with buffer allocation and growth)", flush=True)
 torch.cuda.synchronize()
 print("mean", float(e[torch.isfinite(e)].mean()))
