@@ -1161,6 +1161,49 @@ def main():
                 torch.cuda.empty_cache()
         except Exception as e:  # pragma: no cover
             extra["reduce_compact"] = {"error": repr(e)}
+        # deterministic REDUCE local energies beyond Fe2S2 (N2-, C3- and C5-sized rows, synthetic integrals) through energy.local_energy with
+        # the RBM forward kernel on the x': the one-launch front end as local_energy routes it (flushing LIST form, table-less once the
+        # x' prove distinct) beside round 2's multi-pass path
+        try:
+            from pynqs_amd import energy as E6, public_function as pf6
+            from pynqs_amd.rbm import RealRBM as RealRBM6
+
+            old_default6 = torch.get_default_dtype()
+            torch.set_default_dtype(torch.float64)
+            for tag, sorb6, no6, nw6, eps6 in (("syn56_reduce_local_energy", 56, 7, 4096, 0.47), ("syn120_reduce_local_energy", 120, 30, 4096, 0.49995),
+                                               ("syn184_reduce_local_energy", 184, 46, 1024, 0.49999)):
+                h1c, h2c = (t.to(dev) for t in synth_integrals(sorb6))
+                xc = synth_walkers(nw6, sorb6, no6, no6, 4321).to(dev)
+                g6 = torch.Generator().manual_seed(1)
+                m6 = RealRBM6(0.02 * (torch.rand(sorb6, sorb6, generator=g6) - 0.5), 0.02 * (torch.rand(sorb6, generator=g6) - 0.5),
+                              0.05 * (torch.rand(sorb6, generator=g6) - 0.5)).to(dev)
+                ab6 = lambda xx, func: pf6.ansatz_batch(func, xx, 1 << 22, sorb6, dev, torch.float64)  # noqa: E731
+                res6 = {}
+                for mode, onepass in (("one_launch_front_end", True), ("multi_pass_round2", False)):
+                    old_op, E6.FUSED_ONEPASS = E6.FUSED_ONEPASS, onepass
+                    try:
+                        fn = lambda: E6.local_energy(xc, h1c, h2c, m6, ab6, sorb6, 2 * no6, no6, no6, reduce_psi=True, eps=eps6)[0]
+                        fn(); fn(); fn(); torch.cuda.synchronize(dev)   # (sizing call, the call that may drop the table, one more)
+                        t0 = time.perf_counter(); reps = 3
+                        for _ in range(reps):
+                            e6 = fn()
+                        torch.cuda.synchronize(dev)
+                        res6[mode] = ((time.perf_counter() - t0) / reps, e6)
+                    finally:
+                        E6.FUSED_ONEPASS = old_op
+                el6, e6 = res6["one_launch_front_end"]
+                fin6 = torch.isfinite(e6) & torch.isfinite(res6["multi_pass_round2"][1])
+                ncomb6 = algorithmic_bytes_dropin(sorb6, 2 * no6, no6, no6)[1]
+                extra[tag] = {"value": nw6 / el6, "unit": "local energies/s", "walkers": nw6, "ncomb": int(ncomb6), "eps": eps6, "ms_per_step": el6 * 1e3,
+                              "columns_per_s": nw6 * ncomb6 / el6, "multi_pass_round2_ms": res6["multi_pass_round2"][0] * 1e3,
+                              "table_less": any(v is not None for k, v in E6._FRONT_NODEDUP.items() if k[2] == sorb6),
+                              "max_abs_diff_between_the_paths": float((e6 - res6["multi_pass_round2"][1])[fin6].abs().max())}
+                del h1c, h2c, xc, res6, e6
+                E6._FRONTS.clear()
+                torch.cuda.empty_cache()
+            torch.set_default_dtype(old_default6)
+        except Exception as e:  # pragma: no cover
+            extra["reduce_local_energy_large"] = {"error": repr(e)}
         # fused-aware chunking (public_function.get_nbatch(fused=...), total_energy(nbatch=0)): the example's batch of 2048 walkers per
         # local_energy call against chunks sized for what the fused path allocates, on 65 536 walkers (C4's global batch)
         try:
