@@ -376,8 +376,13 @@ typedef struct pynqs_reduce_io {
   int32_t *uniq_parent; /* optional, [cap_unique]: the walker whose record put the row on the distinct list -- the row is that walker or a
                            single / double excitation of it, which lets an amplitude with cheap updates start from the walker's
                            intermediate values (pynqs_rbm_forward_children) */
+  void *tile_scratch;   /* optional, eps_sample > 0 without row_cache: pynqs_reduce_onepass_tile_scratch_bytes bytes.  The per-tile sums of
+                           the sub-eps |H| and the tiles' draw counts then live there instead of the LDS (12 bytes per tile: 57 KB per
+                           workgroup at sorb 120, which leaves one workgroup per CU); for rows of more than ~65536 columns */
+  int64_t tile_scratch_bytes;
 } pynqs_reduce_io;
 int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
+int64_t pynqs_reduce_onepass_tile_scratch_bytes(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample);
 int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
                                        int with_row_cache, int without_table, int64_t *cap_doubles);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,

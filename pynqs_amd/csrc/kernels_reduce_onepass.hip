@@ -109,6 +109,8 @@ struct OnepassOut {
                    // Fe2S2, 8192 walkers, 1000 draws (round 3, row-cache form, no +-1 rows): 794 us = enumeration 184 + row cache
                    // written 80 + kept list sorted and resolved 66 + tile sums, tile-level draws, scans 117 + draws inside the tiles
                    // 209 (search 10, emission and resolution of the drawn records 75) + de-duplication 146
+  unsigned char *tile_scratch = nullptr;  // GTILE: per walker [max_tiles] f64 tile sums + [max_tiles] u32 draw counts in global memory
+  uint32_t tile_stride = 0;               // bytes per walker of tile_scratch
 };
 
 // ---- de-duplication table ----------------------------------------------------------------------------------------
@@ -1118,19 +1120,25 @@ __host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, b
 // LDS of the LIST form after the walker tables and the staging scratch:
 //   (SAMPLED) tsum[max_tiles] f64 | dinfo[max_tiles] u32 | draw areas ;  then the list: key[P] u64  (P = power of two >= capacity),
 //   which the draw slots' columns (pend[N] u32) re-use in phase C
+__host__ __device__ inline size_t tile_scratch_stride(uint32_t max_tiles) { return ((size_t)max_tiles * 12 + 15) & ~(size_t)15; }
+
+// gtile: the tile sums and the tiles' draw counts live in global memory (io->tile_scratch) instead of the LDS -- long rows: 4768 tiles at
+// sorb 120 are 57 KB, which with the draw areas and the list leaves ONE workgroup per CU
 __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample,
-                                                   bool cached) {
+                                                   bool cached, bool gtile = false) {
   size_t b = list_base_lds(p, esz, sampled, cached);
   if (sampled) {
-    b += (size_t)max_tiles * 8;
-    b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
+    if (!gtile) {
+      b += (size_t)max_tiles * 8;
+      b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
+    }
     if (!cached) b += (kBlock / 64) * kDrawLdsPerWave;
   }
   const size_t list = (size_t)P * 8, pend = (size_t)nsample * 4;
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
 }
 
-template <int LEN, typename T, bool SAMPLED, bool CACHED, bool FLUSH = false>
+template <int LEN, typename T, bool SAMPLED, bool CACHED, bool FLUSH = false, bool GTILE = false>
 __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restrict__ bra, const SDParams &p, const PlanLayout &pl, uint32_t nchunks,
                                                          uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
                                                          uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
@@ -1149,10 +1157,12 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   const uint32_t cap = o.fixed + o.cap_d;  // records of a segment (<= P unless FLUSH)
   const int64_t seg_base = (int64_t)slot * cap;
   if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; s_done = 0; s_full = 0; }
+  static_assert(!GTILE || (SAMPLED && !CACHED), "tile sums in global memory: the re-enumerating semi-stochastic form only");
   unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED, CACHED);
-  double *tsum = reinterpret_cast<double *>(extra);
-  uint32_t *dinfo = reinterpret_cast<uint32_t *>(extra + (SAMPLED ? (size_t)max_tiles * 8 : 0));
-  unsigned char *after = SAMPLED ? reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) : extra;
+  unsigned char *tile_mem = GTILE ? o.tile_scratch + (size_t)walker * o.tile_stride : extra;
+  double *tsum = reinterpret_cast<double *>(tile_mem);
+  uint32_t *dinfo = reinterpret_cast<uint32_t *>(tile_mem + (SAMPLED ? (size_t)max_tiles * 8 : 0));
+  unsigned char *after = (SAMPLED && !GTILE) ? reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) : extra;
   unsigned char *draw0 = CACHED ? smem + list_scratch_offset(p) : after;  // (CACHED: over the staging scratch, see list_base_lds)
   if (SAMPLED && !CACHED) after += (kBlock / 64) * kDrawLdsPerWave;
   // the kept list: ONE 64-bit key per entry (column << 32 | order of arrival); the values wait in the segment's rec_w, in order of arrival,
@@ -1523,11 +1533,11 @@ __global__ __launch_bounds__(kBlock) void reduce_onepass_list_flush_kernel(const
   reduce_onepass_list_body<LEN, T, false, false, true>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
 }
 
-template <int LEN, typename T>
+template <int LEN, typename T, bool GTILE = false>
 __global__ __launch_bounds__(kBlock) void reduce_onepass_list_redraw_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
                                                                             uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
                                                                             uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
-  reduce_onepass_list_body<LEN, T, true, false>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
+  reduce_onepass_list_body<LEN, T, true, false, false, GTILE>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
 }
 
 // ---- contraction: E_loc(x) = sum_records w psi(x') / psi(x) ------------------------------------------------------------
@@ -1651,12 +1661,12 @@ extern "C" int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele,
 constexpr uint32_t kLongRow = 65536;
 struct OnepassForm {
   uint32_t P;
-  bool use_list, use_cache, use_flush;
+  bool use_list, use_cache, use_flush, use_gtile;
   size_t lds;
 };
 constexpr uint32_t kFlushList = 2048;  // list slots of the flushing form
 static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tiles, uint32_t fixed, uint64_t cap_doubles, int eps_sample,
-                                bool have_cache, uint32_t chunk_len, bool no_table) {
+                                bool have_cache, uint32_t chunk_len, bool no_table, bool have_tile_scratch = false) {
   static const int list_env = getenv("PYNQS_OP_LIST") ? atoi(getenv("PYNQS_OP_LIST")) : -1;
   static const int cache_env = getenv("PYNQS_OP_CACHE") ? atoi(getenv("PYNQS_OP_CACHE")) : -1;
   static const int flush_env = getenv("PYNQS_OP_FLUSH") ? atoi(getenv("PYNQS_OP_FLUSH")) : -1;
@@ -1666,10 +1676,12 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   f.P = 64;
   while (f.P < seg_cap && f.P < (1u << 20)) f.P <<= 1;
   const bool want_cache = sampled && have_cache && cache_env != 0;
-  const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, f.P, (uint32_t)eps_sample, want_cache);
+  const bool gtile = sampled && !want_cache && have_tile_scratch;  // tile sums / draw counts in global memory (long rows)
+  const size_t lds_list = onepass_list_lds(p, esz, max_tiles, sampled, f.P, (uint32_t)eps_sample, want_cache, gtile);
   const bool list_fits = seg_cap <= 2048 && lds_list + 256 <= 160 * 1024;
   f.use_list = list_env == 0 ? false : (list_fits && (list_env == 1 || seg_cap <= 1024 || p.nsd + 1 > kLongRow));
   f.use_cache = want_cache && f.use_list;
+  f.use_gtile = gtile && f.use_list;
   f.lds = f.use_list ? lds_list : onepass_lds(p, esz, max_tiles, sampled, winner_list_cap(eps_sample));
   // the flushing LIST form: deterministic calls whose kept columns do not fit the list -- on long rows, on any row when at most a tenth
   // of a segment's columns can be kept (a flush costs a sort of 2048 entries; the look-back form pays per tile instead: Fe2S2 with 9 % kept
@@ -1680,6 +1692,19 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
                 (p.nsd + 1 > kLongRow || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len);
   if (f.use_flush) { f.P = kFlushList; f.lds = lds_flush; }
   return f;
+}
+
+extern "C" int64_t pynqs_reduce_onepass_tile_scratch_bytes(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample) {
+  SDParams p;
+  PlanLayout pl;
+  if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl) || nbatch < 0 || nbatch > 0x7fffffffll || eps_sample < 0 || eps_sample > 65535) {
+    set_error(PYNQS_EINVAL, "bad arguments");
+    return -1;
+  }
+  if (eps_sample == 0) return 0;
+  uint32_t nchunks, chunk_len, max_tiles, fixed;
+  onepass_geometry(nbatch, p, true, &nchunks, &chunk_len, &max_tiles, &fixed);
+  return (int64_t)((size_t)nbatch * tile_scratch_stride(max_tiles));
 }
 
 extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
@@ -1709,7 +1734,7 @@ extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int 
 }
 
 template <typename T>
-static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed) {
+static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed, uint32_t gtile_max_tiles = 0) {
   OnepassOut<T> o;
   o.rec_col = io->rec_col; o.rec_w = (T *)io->rec_w; o.rec_onv = io->rec_onv; o.rec_link = io->rec_link; o.seg_count = io->seg_count;
   o.srec_col = io->srec_col; o.srec_w = (T *)io->srec_w; o.srec_onv = io->srec_onv; o.srec_link = io->srec_link; o.row_sum = io->row_sum;
@@ -1722,6 +1747,7 @@ static OnepassOut<T> make_out(const pynqs_reduce_io *io, int len, uint32_t fixed
   o.debug = dbg;
   o.seed_dev = io->seed_dev;
   o.row_cache = (T *)io->row_cache;
+  if (gtile_max_tiles) { o.tile_scratch = (unsigned char *)io->tile_scratch; o.tile_stride = (uint32_t)tile_scratch_stride(gtile_max_tiles); }
   (void)len;
   return o;
 }
@@ -1758,10 +1784,11 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   if (grid > 0x7fffffffull) return set_error(PYNQS_EINVAL, "grid too large");
   if (grid * ((uint64_t)fixed + (uint64_t)io->cap_doubles) > 0x7fffffffull * 16ull) return set_error(PYNQS_EINVAL, "record arrays too large");
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
+  const bool have_tiles = io->tile_scratch != nullptr && io->tile_scratch_bytes >= (int64_t)((size_t)nbatch * tile_scratch_stride(max_tiles));
   const OnepassForm form = onepass_form(p, esz, max_tiles, fixed, (uint64_t)io->cap_doubles, eps_sample, io->row_cache != nullptr, chunk_len,
-                                        io->dedup_table == nullptr);
+                                        io->dedup_table == nullptr, have_tiles);
   const uint32_t P = form.P;
-  const bool use_list = form.use_list || form.use_flush, use_cache = form.use_cache, use_flush = form.use_flush;
+  const bool use_list = form.use_list || form.use_flush, use_cache = form.use_cache, use_flush = form.use_flush, use_gtile = form.use_gtile;
   const size_t lds = form.lds;
   if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
   if (!io->dedup_table && !use_list)
@@ -1769,20 +1796,21 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   static const bool verbose = getenv("PYNQS_OP_VERBOSE") != nullptr;
   if (verbose)
     fprintf(stderr, "pynqs_reduce_onepass: %s form%s, LDS %zu bytes per workgroup (walker tables %zu, max_tiles %u, list P %u), %u chunk(s) per walker\n",
-            use_flush ? "flushing LIST" : use_list ? "LIST" : "look-back", use_cache ? " with row cache" : "", lds, (size_t)lds_fixed_bytes(p), max_tiles, P, nchunks);
+            use_flush ? "flushing LIST" : use_list ? (use_gtile ? "LIST (tile sums in global memory)" : "LIST") : "look-back", use_cache ? " with row cache" : "", lds, (size_t)lds_fixed_bytes(p), max_tiles, P, nchunks);
   // eloc.py:257-264: with draws and eps <= 0 nothing is kept (every column can be drawn); without draws |H| >= eps as it stands
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
   do {                                                                                                                               \
     auto kfn = use_flush ? reduce_onepass_list_flush_kernel<LEN, TT>                                                                 \
              : use_list ? (use_cache ? reduce_onepass_list_kernel<LEN, TT, SM, SM>                                                   \
-                                     : (SM ? reduce_onepass_list_redraw_kernel<LEN, TT> : reduce_onepass_list_kernel<LEN, TT, false, false>)) \
+                                     : (SM ? (use_gtile ? reduce_onepass_list_redraw_kernel<LEN, TT, true> : reduce_onepass_list_redraw_kernel<LEN, TT, false>) \
+                                           : reduce_onepass_list_kernel<LEN, TT, false, false>)) \
                         : reduce_onepass_kernel<LEN, TT, SM>;                                                                        \
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                                (int)lds) != hipSuccess)                                                              \
       return check_launch("hipFuncSetAttribute");                                                                                   \
     hipLaunchKernelGGL(kfn, dim3((uint32_t)grid), dim3(kBlock), lds, st, bra, p, pl, nchunks, chunk_len, max_tiles, (const TT *)plan, \
-                       (TT)eps_eff, (uint32_t)eps_sample, seed, use_list ? P : winner_list_cap(eps_sample), make_out<TT>(io, len, fixed));                \
+                       (TT)eps_eff, (uint32_t)eps_sample, seed, use_list ? P : winner_list_cap(eps_sample), make_out<TT>(io, len, fixed, use_gtile ? max_tiles : 0u));                \
   } while (0)
   DISPATCH_LEN(len, {
     if (dtype == PYNQS_F64) { if (sampled) PYNQS_OP_LAUNCH(double, true); else PYNQS_OP_LAUNCH(double, false); }

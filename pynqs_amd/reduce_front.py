@@ -24,6 +24,7 @@ from . import _native as N
 OVERFLOW_DOUBLES, OVERFLOW_TABLE, OVERFLOW_UNIQUE = 1, 2, 4
 ROW_CACHE = True                  # semi-stochastic kernel: cache the row in global memory for the draws (see ReduceFrontEnd)
 ROW_CACHE_MAX_BYTES = 8 << 30
+TILE_SCRATCH_MIN_ROW = int(__import__("os").environ.get("PYNQS_TILE_SCRATCH_MIN_ROW", "65536"))  # columns per row from which the tile sums leave the LDS
 
 
 def _pow2_at_least(v: int) -> int:
@@ -124,6 +125,12 @@ class ReduceFrontEnd:
         self.row_cache = None
         if wants_row_cache(self.n, ncomb, self.eps_sample, self.nchunks, esz):
             self.row_cache = torch.empty(max(self.n * ncomb, 1), dtype=h_dtype, device=dev)
+        # long rows with draws and no row cache: the tile sums / draw counts of the kernel in global memory instead of the LDS
+        self.tile_scratch = None
+        if self.eps_sample > 0 and self.row_cache is None and ncomb > TILE_SCRATCH_MIN_ROW:
+            nb = int(N.lib().pynqs_reduce_onepass_tile_scratch_bytes(self.n, sorb, nele, noa, nob, self.eps_sample))
+            if nb > 0:
+                self.tile_scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         self._lut = None
         self._io = self._make_io()
 
@@ -146,6 +153,8 @@ class ReduceFrontEnd:
         io.seed_dev = self.seed_dev.data_ptr()
         io.row_cache = self.row_cache.data_ptr() if self.row_cache is not None else None
         io.uniq_parent = self.uniq_parent.data_ptr()
+        io.tile_scratch = self.tile_scratch.data_ptr() if self.tile_scratch is not None else None
+        io.tile_scratch_bytes = self.tile_scratch.numel() if self.tile_scratch is not None else 0
         return io
 
     # ---- launches -------------------------------------------------------------------------------------------------------

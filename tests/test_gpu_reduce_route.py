@@ -174,6 +174,29 @@ def test_semi_stochastic_long_rows_leave_the_front_end_when_the_list_overflows(m
     assert int(torch.isfinite(e1).sum()) > n // 2
 
 
+def test_tile_sums_in_global_memory_draw_the_same_records(monkeypatch):
+    """Semi-stochastic LIST form on long rows: with io->tile_scratch the per-tile sums and draw counts live in global memory (two workgroups
+    per CU at sorb 120 instead of one); same kept records, same draws, same weights, bit for bit."""
+    from pynqs_amd import C_extension as cx, reduce_front as RF
+
+    for sorb, no, n, eps, ns in ((80, 20, 200, 0.4995, 300), (136, 4, 100, 0.499, 64)):
+        x, h1, h2, _ = _case(sorb, no, n)
+        plan = cx.plan_for(h1, h2, sorb, x.device).buf
+        out = []
+        for min_row in (65536, 1 << 40):
+            monkeypatch.setattr(RF, "TILE_SCRATCH_MIN_ROW", min_row)
+            fe = RF.ReduceFrontEnd(n, sorb, 2 * no, no, no, ns, torch.float64, x.device, 600, 3000 * n, want_pm1=False)
+            assert (fe.tile_scratch is not None) == (min_row == 65536)
+            fe.run(x, plan, eps, seed=11)
+            nu, flags, _ = fe.counters_host()
+            assert flags == 0
+            w, col, h, link, onv, drawn = fe.records()
+            assert int(drawn.sum()) > n * ns // 2
+            out.append((nu, w, col, h, onv, drawn, fe.row_sum.clone()))
+        a, b = out
+        assert a[0] == b[0] and all(torch.equal(u, v) for u, v in zip(a[1:], b[1:]))
+
+
 def test_short_rows_stay_on_the_front_end(fe2s2):
     from pynqs_amd import energy as E
 
