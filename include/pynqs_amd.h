@@ -324,7 +324,8 @@ int pynqs_reduce_sample(const uint64_t *bra, int64_t nbatch, int sorb, int nele,
  *   pynqs_reduce_onepass_geometry : [host] out[0] = segments (nbatch * chunks), out[1] = fixed slots per segment,
  *                                   out[2] = bytes of the de-duplication table for `dedup_slots` slots of this sorb
  *                                   (dedup_slots passed in out[2] on entry), out[3] = 1 if the fused form exists for
- *                                   this system (LDS budget), else 0
+ *                                   this system (LDS budget; with draws on rows of more than 65536 columns: provided
+ *                                   io->tile_scratch is given), else 0
  *   pynqs_reduce_onepass_list_capacity : [host] the largest io->cap_doubles with which pynqs_reduce_onepass keeps a segment's
  *                                   records in an LDS list -- its LIST form (one list per segment) or, without draws, the flushing
  *                                   form (the list is emptied as it fills: 2^30 - 1 = any capacity on rows of more than 65536

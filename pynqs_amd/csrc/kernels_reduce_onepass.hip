@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
                                                          uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
                                                          uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(!FLUSH || (!SAMPLED && !CACHED), "the flushing form has no draws");
+  static_assert(!FLUSH || !CACHED, "the flushing form is for long rows: no row cache");
   __shared__ uint32_t next_tile, list_n, bw_cnt, s_done, s_full;
   __shared__ int32_t bw_base;
   __shared__ double s_part[kBlock / 64 + 1];
@@ -1526,11 +1526,11 @@ void reduce_onepass_list_kernel(const uint64_t *__restrict__ bra, SDParams p, Pl
 
 // rows whose kept columns do not fit the list (deterministic): the list is emptied as it fills (FLUSH); ~40 KB of LDS at sorb 120, four
 // workgroups per CU: no register squeeze
-template <int LEN, typename T>
+template <int LEN, typename T, bool SAMPLED = false, bool GTILE = false>
 __global__ __launch_bounds__(kBlock) void reduce_onepass_list_flush_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
                                                                            uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
                                                                            uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
-  reduce_onepass_list_body<LEN, T, false, false, true>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
+  reduce_onepass_list_body<LEN, T, SAMPLED, false, true, GTILE>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
 }
 
 template <int LEN, typename T, bool GTILE = false>
@@ -1649,7 +1649,11 @@ extern "C" int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele,
   out4[0] = nbatch * (int64_t)nchunks;
   out4[1] = fixed;
   out4[2] = slots > 0 ? slots * dedup_slot_words(len) * 8 : 0;
-  out4[3] = onepass_lds(p, 8, max_tiles, eps_sample > 0, winner_list_cap(eps_sample)) + onepass_static_lds(len) <= 160 * 1024 ? 1 : 0;
+  // the look-back form, or (draws on long rows, io->tile_scratch given) the flushing LIST form with its tile sums in global memory
+  const bool lookback = onepass_lds(p, 8, max_tiles, eps_sample > 0, winner_list_cap(eps_sample)) + onepass_static_lds(len) <= 160 * 1024;
+  const bool flushing = eps_sample > 0 && p.nsd + 1 > 65536 &&
+                        onepass_list_lds(p, 8, max_tiles, true, 2048, (uint32_t)eps_sample, false, true) + 256 + onepass_static_lds(len) <= 160 * 1024;
+  out4[3] = lookback || flushing ? 1 : 0;
   return PYNQS_OK;
 }
 
@@ -1687,9 +1691,13 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   // of a segment's columns can be kept (a flush costs a sort of 2048 entries; the look-back form pays per tile instead: Fe2S2 with 9 % kept
   // 0.81 look-back against 2.45 ms, sorb 56 with 6 % 6.5 against 3.7, sorb 80 with 10 % / 40 % 103 / 292 against 71 / 269), and whenever
   // there is no de-duplication table (the look-back form needs one).  PYNQS_OP_FLUSH=0 / 1: never / wherever possible.
-  const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, false, kFlushList, 0u, false);
-  f.use_flush = !sampled && !f.use_list && flush_env != 0 && lds_flush + 256 <= 160 * 1024 &&
-                (p.nsd + 1 > kLongRow || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len);
+  // With draws (no row cache): on long rows, the kept list is flushed during the enumeration in the same way, the draws follow as before.
+  const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, sampled, kFlushList, (uint32_t)eps_sample, false, gtile);
+  const bool long_row = p.nsd + 1 > kLongRow;
+  f.use_flush = !f.use_list && flush_env != 0 && lds_flush + 256 <= 160 * 1024 &&
+                (sampled ? (!want_cache && (long_row || flush_env == 1))
+                         : (long_row || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len));
+  if (f.use_flush) f.use_gtile = gtile;
   if (f.use_flush) { f.P = kFlushList; f.lds = lds_flush; }
   return f;
 }
@@ -1719,7 +1727,9 @@ extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int 
   onepass_geometry(nbatch, p, eps_sample > 0, &nchunks, &chunk_len, &max_tiles, &fixed);
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
   auto listed = [&](uint64_t cap) {
-    const OnepassForm f = onepass_form(p, esz, max_tiles, fixed, cap, eps_sample, with_row_cache != 0, chunk_len, without_table != 0);
+    // (with draws and no row cache the caller is expected to pass io->tile_scratch: pynqs_reduce_onepass_tile_scratch_bytes)
+    const OnepassForm f = onepass_form(p, esz, max_tiles, fixed, cap, eps_sample, with_row_cache != 0, chunk_len, without_table != 0,
+                                       eps_sample > 0 && with_row_cache == 0);
     return (f.use_list || f.use_flush) && f.lds + onepass_static_lds(0) <= 160 * 1024;
   };
   *cap_doubles = -1;
@@ -1801,7 +1811,7 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
   do {                                                                                                                               \
-    auto kfn = use_flush ? reduce_onepass_list_flush_kernel<LEN, TT>                                                                 \
+    auto kfn = use_flush ? (use_gtile ? reduce_onepass_list_flush_kernel<LEN, TT, SM, SM> : reduce_onepass_list_flush_kernel<LEN, TT, SM, false>) \
              : use_list ? (use_cache ? reduce_onepass_list_kernel<LEN, TT, SM, SM>                                                   \
                                      : (SM ? (use_gtile ? reduce_onepass_list_redraw_kernel<LEN, TT, true> : reduce_onepass_list_redraw_kernel<LEN, TT, false>) \
                                            : reduce_onepass_list_kernel<LEN, TT, false, false>)) \

@@ -60,6 +60,7 @@ def _side_stream(device):
 # 10.6 / 10.4, sampled 13.0 / 14.6, 2.7 / 3.0 -- its other (look-back) form 22 / 6.1, 94 / 30, 96 / 38, sampled 68 / 14 and 54 / 16.
 FRONT_ROUTE = True
 FRONT_LONG_ROW = 65536   # (= kLongRow of kernels_reduce_onepass.hip)
+FRONT_SAMPLED_MIN_WALKERS = 512   # long rows with draws: the whole row is one workgroup's, fewer walkers than this leave CUs idle
 _FRONT_DENSE: "set[tuple]" = set()   # long-row systems whose kept records outgrew the LDS list (this process)
 # De-duplication of the x' costs random probes into a table of 2-4 slots per distinct determinant: 64 MB for Fe2S2 (8192 walkers, 1.5 M distinct
 # of 10 M records: it stays in the 256 MB cache and saves 85 % of the amplitude evaluations), 1.6 GB at sorb 80 with 4096 walkers, where
@@ -643,6 +644,8 @@ def _front_ok(x, h1e, sorb, nele, noa, nob, eps_sample) -> bool:
     limit = _long_row_cap(x.size(0), h1e, sorb, nele, noa, nob, eps_sample)
     if limit is None:
         return True
+    if int(eps_sample) > 0 and x.size(0) < FRONT_SAMPLED_MIN_WALKERS:
+        return False   # (one workgroup per walker: 256 walkers at sorb 184 19.5 ms against 15.4 multi-pass; 1024 walkers 56 against 63)
     return limit >= 0 and _dense_key(x.device, sorb, nele, noa, nob, eps_sample) not in _FRONT_DENSE
 
 

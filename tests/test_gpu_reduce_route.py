@@ -147,6 +147,11 @@ def test_semi_stochastic_long_rows_leave_the_front_end_when_the_list_overflows(m
     ab = lambda xx, func: pf.ansatz_batch(func, xx, 1 << 20, sorb, dev, torch.float64)  # noqa: E731
     for name, val in (("_FRONT_DENSE", set()), ("_FRONTS", {}), ("_FRONT_NODEDUP", {})):
         monkeypatch.setattr(E, name, val)
+    assert not E._front_ok(x, h1, sorb, 2 * no, no, no, ns)   # (few walkers with draws on long rows: the multi-pass path)
+    monkeypatch.setattr(E, "FRONT_SAMPLED_MIN_WALKERS", 1)
+    # (the routing exists for rows the flushing form cannot serve -- its LDS does not fit, PYNQS_OP_FLUSH=0: emulated by a capacity
+    # query that knows the plain LIST form only)
+    monkeypatch.setattr(RF, "list_capacity", lambda *a, **k: 2048 - RF.geometry(n, sorb, 2 * no, no, no, ns)[1])
     limit = RF.list_capacity(n, sorb, 2 * no, no, no, ns)
     assert 0 < limit < 2048 and E._front_ok(x, h1, sorb, 2 * no, no, no, ns)
     calls = {"front": 0, "multi": 0}
@@ -166,12 +171,48 @@ def test_semi_stochastic_long_rows_leave_the_front_end_when_the_list_overflows(m
     assert not E._front_ok(x, h1, sorb, 2 * no, no, no, ns)
     e3 = energies(0.47)
     assert calls["multi"] == 2 and calls["front"] == nf + 1
-    # the deterministic form of the same system is not affected (the flushing form has no limit)
-    assert E._front_ok(x, h1, sorb, 2 * no, no, no, 0)
+    assert E._front_ok(x, h1, sorb, 2 * no, no, no, 0)   # (the deterministic form has its own key)
     # same walkers without a diagonal above eps (NaN there, as in the reference), finite elsewhere
     ed = E.local_energy(x, h1, h2, m, ab, sorb, 2 * no, no, no, reduce_psi=True, eps=0.47)[0]
     assert bool((torch.isfinite(e2) == torch.isfinite(ed)).all()) and bool((torch.isfinite(e3) == torch.isfinite(ed)).all())
     assert int(torch.isfinite(e1).sum()) > n // 2
+
+
+@pytest.mark.parametrize("sorb,no,n,eps,ns", [(80, 20, 48, 0.47, 300), (136, 4, 40, 0.45, 100)])
+def test_semi_stochastic_flushing_form(sorb, no, n, eps, ns):
+    """Long rows with draws and more kept columns than the list holds: the kept list is flushed during the enumeration, the draws follow.
+    Kept records = the multi-pass kernels', bit for bit; every drawn record is a sub-eps column with weight (c / N) sign(H) S, S = the
+    row's sum of sub-eps |H| (eloc.py:257-298), and the counts of a row add up to N."""
+    from pynqs_amd import C_extension as cx, energy as E, reduce_front as RF
+
+    x, h1, h2, _ = _case(sorb, no, n)
+    assert RF.list_capacity(n, sorb, 2 * no, no, no, ns) == (1 << 30) - 1
+    fe, nu = E.reduce_front(x, h1, h2, sorb, 2 * no, no, no, eps, ns, seed=17, want_pm1=False)
+    assert fe.cap_doubles + fe.fixed > 2048 and fe.tile_scratch is not None
+    w, col, h, link, onv, drawn = fe.records()
+    row, col2, onv2, h2_, counts = E.reduce_compact(x, h1, h2, sorb, 2 * no, no, no, eps, sort=True)
+    kw, kc, kh, ko = w[~drawn], col[~drawn], h[~drawn], onv[~drawn]
+    k1 = torch.argsort((kw << 32) | kc.long(), stable=True)
+    assert torch.equal(kw[k1], row) and torch.equal(kc[k1], col2) and torch.equal(kh[k1], h2_) and torch.equal(ko[k1], onv2)
+    comb, hm = cx.get_comb_hij_fused(x, h1, h2, sorb, 2 * no, no, no)
+    sub = torch.where(hm.abs() < eps, hm.abs(), torch.zeros_like(hm))
+    S = sub.sum(1)
+    assert float((fe.row_sum[:n] - S).abs().max()) <= 1e-12 * float(S.max())
+    dw, dc, dh, do = w[drawn], col[drawn].long(), h[drawn], onv[drawn]
+    hd = hm[dw, dc]
+    assert bool((hd.abs() < eps).all()) and bool((hd != 0).all())
+    cnt = dh * ns / (torch.sign(hd) * fe.row_sum[dw])           # the multiplicity c of the record
+    assert float((cnt - cnt.round()).abs().max()) < 1e-9 and bool((cnt.round() >= 1).all())
+    tot = torch.zeros(n, dtype=torch.float64, device=x.device).index_add_(0, dw, cnt.round())
+    assert bool((tot == ns).all())
+    assert torch.equal(do, comb[dw, dc])
+    assert torch.equal(fe.uniq_onv[fe.rows_of(link)], onv)
+    # a column is drawn about as often as its share of S says (loose: chi-square-free check on the largest share)
+    share = (sub / S.unsqueeze(1)).max(1)
+    big = torch.zeros(n, dtype=torch.float64, device=x.device)
+    hit = dc == share.indices[dw]
+    big.index_add_(0, dw[hit], cnt.round()[hit])
+    assert float((big / ns - share.values).abs().max()) < 0.05
 
 
 def test_tile_sums_in_global_memory_draw_the_same_records(monkeypatch):

@@ -317,20 +317,28 @@ def test_get_nbatch_matches_the_reference_and_knows_the_fused_paths():
 
 
 def test_reduce_front_list_capacity_is_host_arithmetic():
-    """pynqs_reduce_onepass_list_capacity: the kept doubles per segment up to which the one-launch front end runs in one of its LIST forms
-    -- with draws: 1024 slots minus the fixed ones on short rows, 2048 on rows of more than 65536 columns; without draws the flushing form
-    extends that to a tenth of a segment's columns on short rows and to any capacity on long rows or without a de-duplication table;
-    -1 when the fixed slots alone exceed the list."""
+    """pynqs_reduce_onepass_list_capacity: the kept doubles per segment up to which the one-launch front end runs in one of its LIST forms.
+    Short rows: 1024 slots minus the fixed ones; without draws the flushing form extends that to a tenth of a segment's columns, and to any
+    capacity without a de-duplication table.  Rows of more than 65536 columns: any capacity (flushing form; with draws it keeps its tile sums
+    in io->tile_scratch, which also makes sorb 184 with whole rows possible: pynqs_reduce_onepass_geometry's out[3])."""
     from pynqs_amd import reduce_front as RF
 
     any_cap = (1 << 30) - 1
-    for args, slots in (((8192, 40, 30, 15, 15, 100), 1024), ((2048, 80, 40, 20, 20, 1000), 2048)):
+    for args in ((8192, 40, 30, 15, 15, 100), (4096, 56, 14, 7, 7, 200)):
         fixed = RF.geometry(*args)[1]
-        assert RF.list_capacity(*args) == slots - fixed == RF.list_capacity(*args, without_table=True)
+        assert RF.list_capacity(*args) == 1024 - fixed == RF.list_capacity(*args, without_table=True)
     assert RF.list_capacity(8192, 40, 30, 15, 15, 0) == 1024 - 168          # (7936 columns: a tenth is less than the list)
     assert RF.list_capacity(4096, 56, 14, 7, 7, 0) == 30976 // 10            # (sorb 56: 30724 columns in one segment of 30976)
     for args in ((8192, 40, 30, 15, 15, 0), (4096, 56, 14, 7, 7, 0)):
         assert RF.list_capacity(*args, without_table=True) == any_cap
-    for args in ((2048, 80, 40, 20, 20, 0), (4096, 120, 60, 30, 30, 0), (256, 120, 60, 30, 30, 0), (4096, 184, 92, 46, 46, 0)):
-        assert RF.list_capacity(*args) == any_cap
-    assert RF.list_capacity(4096, 184, 92, 46, 46, 1000) == -1   # 4248 fixed slots (singles) per walker
+    for args in ((2048, 80, 40, 20, 20, 0), (4096, 120, 60, 30, 30, 0), (256, 120, 60, 30, 30, 0), (4096, 184, 92, 46, 46, 0),
+                 (2048, 80, 40, 20, 20, 1000), (4096, 120, 60, 30, 30, 1000), (4096, 184, 92, 46, 46, 1000)):
+        assert RF.list_capacity(*args) == any_cap and RF.supported(*args)
+    assert int(N_lib().pynqs_reduce_onepass_tile_scratch_bytes(10, 120, 60, 30, 30, 0)) == 0
+    assert int(N_lib().pynqs_reduce_onepass_tile_scratch_bytes(10, 120, 60, 30, 30, 1000)) % 160 == 0 > -1
+
+
+def N_lib():
+    from pynqs_amd import _native as N
+
+    return N.lib()
