@@ -421,8 +421,9 @@ int pynqs_rbm_forward(const uint64_t *onv, int64_t n, int sorb, const double *we
  *   pynqs_rbm_children_table_bytes : [host] size of the table for nwalkers parents (-1 on bad arguments)
  *   pynqs_rbm_children_prepare     : table <- the parents' q_h, sum_h theta_h, a.x and the parameters' factor table
  *   pynqs_rbm_forward_children     : psi[r] for r < min(*count_dev, n) (count_dev may be NULL: all n rows; rows past the count are left alone)
- *   pynqs_rbm_forward_children_supported : 1 if the factor table ((2 sorb + 1) x (nhidden + 2) entries) fits 64 KB of LDS, else 0: the
- *                                    caller then uses pynqs_rbm_forward
+ *   pynqs_rbm_forward_children_supported : 1 for every valid (sorb, nhidden, flavour), else 0.  A factor table ((2 sorb + 1) x (nhidden + 2)
+ *                                    entries) of at most 64 KB is kept in LDS, a thread per row; a larger one (sorb x nhidden above
+ *                                    ~64 x 64) is read from the L2 by one wave per row, the lanes over the hidden units
  * Flavours and parameter layouts as pynqs_rbm_forward.  exp(-2 theta_h) is formed for the parents: if some Re theta_h < -340 the prepare
  * step raises a flag in the table and pynqs_rbm_forward_children computes every row from scratch instead (pynqs_rbm_forward's
  * algorithm inside the same kernel).  Values agree with pynqs_rbm_forward to rounding (typically

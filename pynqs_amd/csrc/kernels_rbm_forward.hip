@@ -364,6 +364,129 @@ __global__ __launch_bounds__(kChildBlock) void rbm_forward_children_kernel(const
   }
 }
 
+// The same for factor tables beyond the LDS (sorb x num_hidden above ~64 x 64: 235 KB at 120 x 120): ONE WAVE PER ROW, the lanes over the
+// hidden units.  Lane l forms q_h = q_h(parent) prod_{o in F} f_h(o) and its product of (1 + q_h) for h = l, l + 64, ...: the parent's row
+// and the (at most four) factor rows are read as consecutive 8- / 16-byte words by consecutive lanes, from the L2 (the factor table is shared
+// by every row, a parent's row by its few hundred children); the 64 partial products meet in a butterfly (mantissa and exponent kept apart:
+// Prod).  4 row loads per hidden unit instead of sorb multiply-adds.  What is the same for all lanes of the row (the parent, the flipped
+// orbitals, the table offsets) is computed on the scalar unit: the row number goes through readfirstlane, which tells the compiler so.
+template <int LEN, int FLAVOUR>
+__global__ __launch_bounds__(kBlock) void rbm_forward_children_wave_kernel(const uint64_t *__restrict__ onv, int64_t n, const int32_t *__restrict__ count_dev,
+                                                                           const int32_t *__restrict__ parent, const uint64_t *__restrict__ walkers,
+                                                                           int64_t nwalkers, const double *__restrict__ table,
+                                                                           const double *__restrict__ factors, int sorb, int H,
+                                                                           const double *__restrict__ W, const double *__restrict__ hb,
+                                                                           const double *__restrict__ vb, double *__restrict__ psi) {
+  constexpr bool CPLX = FLAVOUR == PYNQS_RBM_COMPLEX;
+  constexpr int C = CPLX ? 2 : 1;
+  const int HP = children_hp(H);
+  int64_t cnt = n;
+  if (count_dev) cnt = min((int64_t)max(*count_dev, 0), n);
+  if (factors[(size_t)(2 * sorb + 1) * HP * C] != 0.0) {  // (grid-uniform) parents out of range: every row from scratch, a thread per row
+    const int64_t rounds = (cnt + (int64_t)gridDim.x * kBlock - 1) / ((int64_t)gridDim.x * kBlock);
+    for (int64_t r = 0; r < rounds; ++r) {
+      const int64_t i = ((int64_t)r * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      const int64_t row = i < cnt ? i : cnt - 1;
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = onv[row * LEN + w];
+      Prod P;
+      double axr, axi;
+      rbm_forward_row<LEN, FLAVOUR>(ket, sorb, H, W, hb, vb, P, axr, axi);
+      if (i < cnt) write_psi<FLAVOUR>(psi, i, P, axr, axi);
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  // a wave takes kWaveRows consecutive rows at a time (the children of a walker follow each other in the distinct list: the parent's row and
+  // the factor rows of its occupied orbitals stay in the CU's L1)
+  constexpr int kWaveRows = 16;
+  for (int64_t i0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kWaveRows; i0 < cnt; i0 += nwaves * kWaveRows)
+  for (int64_t i = i0; i < min(i0 + kWaveRows, cnt); ++i) {  // (wave-uniform)
+    int64_t p = parent[i];
+    p = p < 0 || p >= nwalkers ? 0 : p;
+    int at[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) at[q] = 2 * sorb * HP;
+    int k = 0;
+#pragma unroll
+    for (int w = 0; w < LEN; ++w) {
+      const uint64_t xc = onv[i * LEN + w];
+      uint64_t d = xc ^ walkers[p * LEN + w];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (d && k < 4) {
+          const int b = __builtin_ctzll(d);
+          d &= d - 1;
+          const int r = (2 * (64 * w + b) + (((xc >> b) & 1ull) ? 0 : 1)) * HP;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == k) at[q] = r;
+          ++k;
+        }
+      }
+    }
+    const double *__restrict__ tp = table + (size_t)p * (size_t)(H + 2) * C;
+    Prod P;
+    for (int h = lane; h < H; h += 64) {
+      double qr = tp[(size_t)h * C], qi = CPLX ? tp[(size_t)h * C + 1] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double fr = factors[(size_t)(at[q] + h) * C];
+        if constexpr (CPLX) {
+          const double fi = factors[(size_t)(at[q] + h) * C + 1];
+          const double nr = qr * fr - qi * fi;
+          qi = fma(qr, fi, qi * fr);
+          qr = nr;
+        } else {
+          qr *= fr;
+        }
+      }
+      if constexpr (CPLX) {  // P *= 1 + q
+        const double u = 1.0 + qr;
+        const double nr = P.re * u - P.im * qi;
+        P.im = fma(P.re, qi, P.im * u);
+        P.re = nr;
+      } else {
+        P.re *= 1.0 + qr;
+      }
+      P.renorm();
+    }
+    // the lanes' products: mantissas multiplied, exponents added, in a butterfly (every lane ends with the full product)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const double orr = __shfl_xor(P.re, d), oi = CPLX ? __shfl_xor(P.im, d) : 0.0;
+      const int oe = __shfl_xor(P.e2, d);
+      if constexpr (CPLX) {
+        const double nr = P.re * orr - P.im * oi;
+        P.im = fma(P.re, oi, P.im * orr);
+        P.re = nr;
+      } else {
+        P.re *= orr;
+      }
+      P.e2 += oe;   // (mantissas in [0.5, 1): 64 of them multiply to >= 2^-64, no renormalisation on the way)
+    }
+    P.renorm();
+    if (lane == 0) {
+      double axr = tp[(size_t)(H + 1) * C], axi = CPLX ? tp[(size_t)(H + 1) * C + 1] : 0.0;
+      P.lin = tp[(size_t)H * C];
+      P.ang = CPLX ? tp[(size_t)H * C + 1] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        P.lin += factors[(size_t)(at[q] + H) * C];
+        axr += factors[(size_t)(at[q] + H + 1) * C];
+        if constexpr (CPLX) {
+          P.ang += factors[(size_t)(at[q] + H) * C + 1];
+          axi += factors[(size_t)(at[q] + H + 1) * C + 1];
+        }
+      }
+      write_psi<FLAVOUR>(psi, i, P, axr, axi);
+    }
+  }
+}
+
 }  // namespace pynqs
 
 using namespace pynqs;
@@ -400,9 +523,14 @@ static bool children_flavour_ok(int flavour) {
   return flavour == PYNQS_RBM_REAL || flavour == PYNQS_RBM_TANH || flavour == PYNQS_RBM_PHASE || flavour == PYNQS_RBM_COMPLEX;
 }
 
+// (every shape: the factor table in LDS when it fits 64 KB, else a wave per row with the table read from the L2)
 extern "C" int pynqs_rbm_forward_children_supported(int sorb, int nhidden, int flavour) {
   if (sorb < 1 || sorb > kMaxSorb || nhidden < 1 || !children_flavour_ok(flavour)) return 0;
-  return children_lds_bytes(sorb, nhidden, flavour) <= 64 * 1024 ? 1 : 0;
+  return 1;
+}
+static bool children_table_in_lds(int sorb, int nhidden, int flavour) {
+  static const int force = getenv("PYNQS_RBM_CHILDREN_WAVE") ? atoi(getenv("PYNQS_RBM_CHILDREN_WAVE")) : -1;  // 1: the wave form everywhere
+  return force != 1 && children_lds_bytes(sorb, nhidden, flavour) <= 64 * 1024;
 }
 
 extern "C" int64_t pynqs_rbm_children_table_bytes(int64_t nwalkers, int sorb, int nhidden, int flavour) {
@@ -447,7 +575,7 @@ extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const 
   pynqs::DeviceScope device_scope_(onv);
   if (n < 0 || n > 0x7fffffffll * kBlock || nwalkers < 0 || sorb < 1 || sorb > kMaxSorb || nhidden < 1) return set_error(PYNQS_EINVAL, "bad n/sorb/nhidden");
   if (!pynqs_rbm_forward_children_supported(sorb, nhidden, flavour))
-    return set_error(PYNQS_EINVAL, "rbm_forward_children: unsupported (bad flavour, or the factor table exceeds the LDS: use pynqs_rbm_forward)");
+    return set_error(PYNQS_EINVAL, "rbm_forward_children: bad flavour");
   if (n == 0) return PYNQS_OK;
   if (!onv || !parent || !walkers || !table || !psi || !weights || !hidden_bias || nwalkers == 0) return set_error(PYNQS_EINVAL, "null pointer");
   const int len = (sorb - 1) / 64 + 1;
@@ -458,7 +586,18 @@ extern "C" int pynqs_rbm_forward_children(const uint64_t *onv, int64_t n, const 
   const double *parents = (const double *)table;
   const double *factors = parents + (size_t)nwalkers * (size_t)(nhidden + 2) * (flavour == PYNQS_RBM_COMPLEX ? 2 : 1);
   hipStream_t st = (hipStream_t)stream;
-#define PYNQS_RC(F) hipLaunchKernelGGL((rbm_forward_children_kernel<LEN, F>), dim3(grid), dim3(kChildBlock), lds, st, onv, n, count_dev, parent, walkers, nwalkers, parents, factors, sorb, nhidden, weights, hidden_bias, visible_bias, psi)
+  const bool in_lds = children_table_in_lds(sorb, nhidden, flavour);
+  int64_t wblocks = (n + (kBlock / 64) * 16 - 1) / ((kBlock / 64) * 16);   // the wave form: a wave per 16 consecutive rows, strided
+  if (wblocks > 256 * 32) wblocks = 256 * 32;
+#define PYNQS_RC(F)                                                                                                                          \
+  do {                                                                                                                                       \
+    if (in_lds)                                                                                                                              \
+      hipLaunchKernelGGL((rbm_forward_children_kernel<LEN, F>), dim3(grid), dim3(kChildBlock), lds, st, onv, n, count_dev, parent, walkers,  \
+                         nwalkers, parents, factors, sorb, nhidden, weights, hidden_bias, visible_bias, psi);                                \
+    else                                                                                                                                     \
+      hipLaunchKernelGGL((rbm_forward_children_wave_kernel<LEN, F>), dim3((uint32_t)wblocks), dim3(kBlock), 0, st, onv, n, count_dev,        \
+                         parent, walkers, nwalkers, parents, factors, sorb, nhidden, weights, hidden_bias, visible_bias, psi);               \
+  } while (0)
   DISPATCH_LEN(len, {
     switch (flavour) {
       case PYNQS_RBM_REAL: PYNQS_RC(PYNQS_RBM_REAL); break;

@@ -104,9 +104,12 @@ def test_rbm_forward_kernel_matches_the_module(kind, sorb, H):
     torch.testing.assert_close(got, want, rtol=1e-11, atol=0 if kind != "pRBM" else 1e-11)
 
 
-@pytest.mark.parametrize("rbm_type,sorb,no,H", [("complex", 40, 15, 40), ("real", 40, 15, 80), ("tanh", 12, 3, 7), ("pRBM", 72, 6, 9), ("complex", 136, 4, 11)])
+@pytest.mark.parametrize("rbm_type,sorb,no,H", [("complex", 40, 15, 40), ("real", 40, 15, 80), ("tanh", 12, 3, 7), ("pRBM", 72, 6, 9), ("complex", 136, 4, 11),
+                                                ("real", 120, 30, 120), ("complex", 136, 4, 150), ("tanh", 80, 20, 70), ("pRBM", 120, 6, 200),
+                                                ("complex", 184, 4, 368), ("real", 184, 4, 3)])
 def test_rbm_forward_children_matches_the_plain_forward(rbm_type, sorb, no, H):
-    """pynqs_rbm_theta + pynqs_rbm_forward_children on the distinct x' of a REDUCE front end (each row from its parent walker, <= 4 orbitals
+    """(the factor table in LDS, and -- sorb x H above ~64 x 64 -- read from the L2 by a wave per row)
+    pynqs_rbm_theta + pynqs_rbm_forward_children on the distinct x' of a REDUCE front end (each row from its parent walker, <= 4 orbitals
     flipped) against pynqs_rbm_forward on the same rows: 1e-11 relative (the additions run in a different order; typical 5e-15, the worst rows have a factor 2cosh theta_h near zero); rows past the device
     count are left alone; the parents really are parents."""
     import bench as B
@@ -116,7 +119,8 @@ def test_rbm_forward_children_matches_the_plain_forward(rbm_type, sorb, no, H):
     n = 96
     x = B.synth_walkers(n, sorb, no, no, 3).to(dev)
     h1, h2 = B.synth_integrals(sorb)
-    fe, nu = E.reduce_front(x, h1.to(dev), h2.to(dev), sorb, 2 * no, no, no, 0.3, 40, None, seed=5, pm1_dtype=torch.float64)
+    eps = 0.4995 if (sorb, no) == (120, 30) else 0.3   # (sorb 120 at half filling has 1.2e6 columns per row)
+    fe, nu = E.reduce_front(x, h1.to(dev), h2.to(dev), sorb, 2 * no, no, no, eps, 40, None, seed=5, pm1_dtype=torch.float64)
     assert nu > n
     par = fe.uniq_parent[:nu].long()
     d = (fe.uniq_onv[:nu] ^ x[par]).cpu().numpy()
@@ -138,7 +142,7 @@ def test_rbm_forward_children_matches_the_plain_forward(rbm_type, sorb, no, H):
     cx.rbm_forward_children(fe.uniq_onv, fe.uniq_parent, x, W, hb, vb, sorb, rbm_type, count=fe.counters, out=out)
     assert close(out[:nu], cx.rbm_forward(fe.uniq_onv[:nu].contiguous(), W, hb, vb, sorb, rbm_type))
     assert bool((out[nu:] == 7.0).all())
-    assert not cx.rbm_forward_children_supported(184, 368, "complex")
+    assert cx.rbm_forward_children_supported(184, 368, "complex")   # (a factor table beyond the LDS: a wave per row)
 
 
 def test_rbm_forward_children_falls_back_when_the_parents_leave_the_range():
