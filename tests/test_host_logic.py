@@ -56,7 +56,7 @@ def test_host_entry_points():
     assert lib.pynqs_rbm_children_table_bytes(8192, 40, 40, N.RBM_COMPLEX) == 8192 * 42 * 16 + 81 * 43 * 16 + 8
     assert lib.pynqs_rbm_children_table_bytes(10, 40, 80, N.RBM_REAL) == 10 * 82 * 8 + 81 * 83 * 8 + 8
     assert lib.pynqs_rbm_forward_children_supported(40, 40, N.RBM_COMPLEX) == 1 and lib.pynqs_rbm_forward_children_supported(40, 80, N.RBM_REAL) == 1
-    assert lib.pynqs_rbm_forward_children_supported(120, 240, N.RBM_REAL) == 0 and lib.pynqs_rbm_forward_children_supported(40, 40, 7) == 0
+    assert lib.pynqs_rbm_forward_children_supported(120, 240, N.RBM_REAL) == 1 and lib.pynqs_rbm_forward_children_supported(40, 40, 7) == 0  # (beyond the LDS: a wave per row)
     assert lib.pynqs_rbm_grad_workspace(8192, 40, 40, N.RBM_COMPLEX) == 256 * (40 * 41 + 41) * 16
     assert lib.pynqs_rbm_grad_workspace(33, 40, 80, N.RBM_REAL) == 2 * (80 * 41 + 41) * 8 and lib.pynqs_rbm_grad_workspace(8, 40, 40, N.RBM_TANH) == -1
     # the complex-parameter RBM kernel: windowed beyond the LDS, refused only when the per-hidden-unit arrays alone do not fit
@@ -324,9 +324,9 @@ def test_reduce_front_list_capacity_is_host_arithmetic():
     from pynqs_amd import reduce_front as RF
 
     any_cap = (1 << 30) - 1
-    for args in ((8192, 40, 30, 15, 15, 100), (4096, 56, 14, 7, 7, 200)):
-        fixed = RF.geometry(*args)[1]
-        assert RF.list_capacity(*args) == 1024 - fixed == RF.list_capacity(*args, without_table=True)
+    assert RF.list_capacity(8192, 40, 30, 15, 15, 1000) == 1024 - 168 == RF.list_capacity(8192, 40, 30, 15, 15, 1000, without_table=True)  # (row cache)
+    assert RF.list_capacity(8192, 40, 30, 15, 15, 100) == 1024 - 168 and RF.list_capacity(4096, 56, 14, 7, 7, 200) == 30976 // 10
+    assert RF.list_capacity(8192, 40, 30, 15, 15, 100, without_table=True) == any_cap
     assert RF.list_capacity(8192, 40, 30, 15, 15, 0) == 1024 - 168          # (7936 columns: a tenth is less than the list)
     assert RF.list_capacity(4096, 56, 14, 7, 7, 0) == 30976 // 10            # (sorb 56: 30724 columns in one segment of 30976)
     for args in ((8192, 40, 30, 15, 15, 0), (4096, 56, 14, 7, 7, 0)):
