@@ -562,8 +562,10 @@ def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: in
     pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
     key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype, bool(want_pm1), int(slot), bool(route))
     fe = _FRONTS.pop(key, None)
+    caps = _FRONT_NODEDUP.get(_nodedup_key(x.device, n, sorb, nele, noa, nob, eps_sample)) if (route and FRONT_NODEDUP) else None
+    if fe is not None and caps is not None and fe.dedup:
+        fe = None   # (a workspace from before the decision to drop the table, e.g. the second slot of total_energy's look-ahead)
     if fe is None:
-        caps = _FRONT_NODEDUP.get(_nodedup_key(x.device, n, sorb, nele, noa, nob, eps_sample)) if (route and FRONT_NODEDUP) else None
         fe = _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1) if caps is None else \
             _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, caps[0], caps[1], dedup=False)
     if seed is None:
