@@ -1691,13 +1691,16 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   // of a segment's columns can be kept (a flush costs a sort of 2048 entries; the look-back form pays per tile instead: Fe2S2 with 9 % kept
   // 0.81 look-back against 2.45 ms, sorb 56 with 6 % 6.5 against 3.7, sorb 80 with 10 % / 40 % 103 / 292 against 71 / 269), and whenever
   // there is no de-duplication table (the look-back form needs one).  PYNQS_OP_FLUSH=0 / 1: never / wherever possible.
-  // With draws (no row cache) the kept list is flushed during the enumeration in the same way, under the same rule; the draws follow as
-  // before (sorb 56, 200 draws, 2 % / 6 % kept: 6.2 / 7.1 ms look-back -> 1.6 / 2.2 flushing and table-less; Fe2S2, 9 %: 1.37 stays).
-  const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, sampled, kFlushList, (uint32_t)eps_sample, false, gtile);
+  // With draws the kept list is flushed during the enumeration in the same way, under the same rule; the draws follow as before (sorb 56,
+  // 200 draws, 2 % / 6 % kept: 6.2 / 7.1 ms look-back -> 1.6 / 2.2 flushing and table-less; Fe2S2, 9 %: 1.37 stays).  A row cache is not
+  // used by this form: when the LIST form with the cache does not fit, flushing without it beats the look-back form (sorb 56, 1000 draws:
+  // 6.2 / 3.8 -> 2.6 / 1.9 ms).
+  const bool gtile_f = sampled && have_tile_scratch;
+  const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, sampled, kFlushList, (uint32_t)eps_sample, false, gtile_f);
   const bool long_row = p.nsd + 1 > kLongRow;
   f.use_flush = !f.use_list && flush_env != 0 && lds_flush + 256 <= 160 * 1024 &&
-                !(sampled && want_cache) && (long_row || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len);
-  if (f.use_flush) f.use_gtile = gtile;
+                (long_row || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len);
+  if (f.use_flush) { f.use_gtile = gtile_f; f.use_cache = false; }
   if (f.use_flush) { f.P = kFlushList; f.lds = lds_flush; }
   return f;
 }

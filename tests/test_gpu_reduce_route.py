@@ -182,7 +182,7 @@ def test_semi_stochastic_long_rows_leave_the_front_end_when_the_list_overflows(m
     assert int(torch.isfinite(e1).sum()) > n // 2
 
 
-@pytest.mark.parametrize("sorb,no,n,eps,ns", [(80, 20, 48, 0.47, 300), (136, 4, 40, 0.45, 100), (56, 7, 64, 0.47, 100)])
+@pytest.mark.parametrize("sorb,no,n,eps,ns", [(80, 20, 48, 0.47, 300), (136, 4, 40, 0.45, 100), (56, 7, 64, 0.47, 100), (56, 7, 64, 0.47, 1000)])
 def test_semi_stochastic_flushing_form(sorb, no, n, eps, ns):
     """Long rows with draws and more kept columns than the list holds: the kept list is flushed during the enumeration, the draws follow.
     Kept records = the multi-pass kernels', bit for bit; every drawn record is a sub-eps column with weight (c / N) sign(H) S, S = the
@@ -193,7 +193,7 @@ def test_semi_stochastic_flushing_form(sorb, no, n, eps, ns):
     long_row = E.get_Num_SinglesDoubles(sorb, no, no) + 1 > E.FRONT_LONG_ROW   # (sorb 56: a short row, sparse enough for the flushing form)
     assert RF.list_capacity(n, sorb, 2 * no, no, no, ns) == ((1 << 30) - 1 if long_row else 30976 // 10)
     fe, nu = E.reduce_front(x, h1, h2, sorb, 2 * no, no, no, eps, ns, seed=17, want_pm1=False)
-    assert fe.cap_doubles + fe.fixed > 2048 and (fe.tile_scratch is not None) == long_row and fe.row_cache is None
+    assert fe.cap_doubles + fe.fixed > 2048 and (fe.tile_scratch is not None) == long_row   # (ns = 1000 at sorb 56: a row cache is allocated and not used)
     assert fe.cap_doubles <= RF.list_capacity(n, sorb, 2 * no, no, no, ns)
     w, col, h, link, onv, drawn = fe.records()
     row, col2, onv2, h2_, counts = E.reduce_compact(x, h1, h2, sorb, 2 * no, no, no, eps, sort=True)

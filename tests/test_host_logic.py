@@ -324,7 +324,7 @@ def test_reduce_front_list_capacity_is_host_arithmetic():
     from pynqs_amd import reduce_front as RF
 
     any_cap = (1 << 30) - 1
-    assert RF.list_capacity(8192, 40, 30, 15, 15, 1000) == 1024 - 168 == RF.list_capacity(8192, 40, 30, 15, 15, 1000, without_table=True)  # (row cache)
+    assert RF.list_capacity(8192, 40, 30, 15, 15, 1000) == 1024 - 168 and RF.list_capacity(4096, 56, 14, 7, 7, 1000) == 30976 // 10  # (beyond the cached LIST form: flushing, no cache)
     assert RF.list_capacity(8192, 40, 30, 15, 15, 100) == 1024 - 168 and RF.list_capacity(4096, 56, 14, 7, 7, 200) == 30976 // 10
     assert RF.list_capacity(8192, 40, 30, 15, 15, 100, without_table=True) == any_cap
     assert RF.list_capacity(8192, 40, 30, 15, 15, 0) == 1024 - 168          # (7936 columns: a tenth is less than the list)
