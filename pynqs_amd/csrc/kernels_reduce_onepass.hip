@@ -27,7 +27,7 @@ namespace pynqs {
 // -DPYNQS_OP_STAMPS: the LIST kernel notes wall_clock64() at its phase boundaries per workgroup (tools/onepass_stamps.py reads them through
 // pynqs_debug_stamps); nothing of this exists in the product build
 #ifdef PYNQS_OP_STAMPS
-__device__ unsigned long long g_stamps[8192][10];
+__device__ unsigned long long g_stamps[8192][16];  // 0-9: phase boundaries; 10-13: the flushing form's sums over its rounds
 #define PYNQS_STAMP(k) do { if (threadIdx.x == 0 && walker < 8192) g_stamps[walker][k] = wall_clock64(); } while (0)
 // (the flushing form: time spent between two marks, summed over the rounds, into stamp slot k)
 #define PYNQS_STAMP_MARK() unsigned long long stamp_mark_ = wall_clock64()
@@ -1184,7 +1184,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   // order and every taken tile is finished before a flush, so the flushes cover consecutive ranges of tiles = ascending columns
   uint32_t flushed = 0;  // records of this segment written by earlier rounds
   uint32_t needed = 0;   // kept columns so far, whether they had room or not
-  PYNQS_STAMP_ZERO(6); PYNQS_STAMP_ZERO(7); PYNQS_STAMP_ZERO(8); PYNQS_STAMP_ZERO(9);
+  PYNQS_STAMP_ZERO(10); PYNQS_STAMP_ZERO(11); PYNQS_STAMP_ZERO(12); PYNQS_STAMP_ZERO(13);
   PYNQS_STAMP_MARK();
   for (;;) {
   const uint32_t room = FLUSH ? (cap > flushed ? min(cap - flushed, P) : 0u) : cap;
@@ -1203,7 +1203,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   const bool last = !FLUSH || s_done != 0u;
   const uint32_t ntot = list_n;
   PYNQS_STAMP(2);
-  if constexpr (FLUSH) PYNQS_STAMP_ADD(6);  // enumeration (with the wait for the slowest wave)
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(10);  // enumeration (with the wait for the slowest wave)
   const uint32_t n = min(ntot, room);
   needed += ntot;
   if constexpr (!FLUSH) {
@@ -1236,7 +1236,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
     }
   }
   PYNQS_STAMP(4);
-  if constexpr (FLUSH) PYNQS_STAMP_ADD(7);  // sort
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(11);  // sort
   // the values, from their order of arrival into the sorted order: every thread fetches its entries' values, then (barrier) stores them
   const int64_t out_base = seg_base + flushed;
   {
@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
       if (i < n) o.rec_w[out_base + i] = mine_w[r];
     }
   }
-  if constexpr (FLUSH) PYNQS_STAMP_ADD(8);  // values into sorted order
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(12);  // values into sorted order
   for (uint32_t i0 = 0; i0 < n; i0 += kBlock) {
     const uint32_t i = i0 + tid;
     bool won = false;
@@ -1280,7 +1280,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
     if (i < n) o.rec_link[out_base + i] = final_link<LEN, T>(o, link, mine);
   }
   flushed += n;
-  if constexpr (FLUSH) PYNQS_STAMP_ADD(9);  // kets, probes, rows, links
+  if constexpr (FLUSH) PYNQS_STAMP_ADD(13);  // kets, probes, rows, links
   if (last) break;
   __syncthreads();  // (everybody is done with the list)
   if (tid == 0) list_n = 0;
@@ -1863,6 +1863,6 @@ extern "C" int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA
 
 #ifdef PYNQS_OP_STAMPS
 extern "C" int pynqs_debug_stamps(unsigned long long *out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pynqs::g_stamps), sizeof(unsigned long long) * 8192 * 10);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pynqs::g_stamps), sizeof(unsigned long long) * 8192 * 16);
 }
 #endif

@@ -18,9 +18,9 @@ for _ in range(3):
     fe.run(x, plan, 1e-2, 3, None)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(N.LIB_PATH)
-out = np.zeros((8192, 10), dtype=np.uint64)
+out = np.zeros((8192, 16), dtype=np.uint64)
 assert lib.pynqs_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
-t = out.astype(np.float64)
+t = out[:, :10].astype(np.float64)
 names = ["walker tables", "phase A (enumeration, row cache, kept list)", "record counts", "sort of the kept list (incl. barrier)", "kept records: kets, probes, rows, links",
          "tile sums from the cached row", "tile-level draws, scans", "draws inside the tiles + emission", "drawn records: kets, probes, rows, links"]
 dt = np.diff(t, axis=1) / 100.0  # wall_clock64: 100 MHz
