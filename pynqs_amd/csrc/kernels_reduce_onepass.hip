@@ -994,6 +994,9 @@ struct ListDrawSink {
   uint32_t *pend;
   uint32_t tile;
   bool nodraw = false;
+  const uint32_t *tlist = nullptr;  // (optional) the drawn tiles, ascending: visit_tiles then walks this list instead of asking skip_tile per tile
+  uint32_t ndrawn = 0;
+  __device__ __forceinline__ uint32_t remap(uint32_t k) const { return tlist ? (k < ndrawn ? tlist[k] : 0xffffffffu) : k; }
 
   __device__ __forceinline__ void entry(uint32_t idx, uint32_t col, T h, double incl) const {
     S.prefix[idx] = incl;
@@ -1134,7 +1137,7 @@ __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz
     }
     if (!cached) b += (kBlock / 64) * kDrawLdsPerWave;
   }
-  const size_t list = (size_t)P * 8, pend = (size_t)nsample * 4;
+  const size_t list = (size_t)P * 8, pend = (size_t)nsample * 4 * (gtile ? 2 : 1);  // (gtile: + the list of the drawn tiles)
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
 }
 
@@ -1371,6 +1374,29 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
       dinfo[i] = (off << 16) | c;
       off += c;
     }
+    uint32_t *tlist = pend + nsample;  // GTILE: the drawn tiles in ascending order (LDS, after the draw slots' columns)
+    uint32_t ndrawn = 0;
+    if constexpr (GTILE) {
+      uint32_t nd = 0;
+      for (uint32_t i = b0; i < b1; ++i) nd += (dinfo[i] & 0xffffu) ? 1u : 0u;  // (this thread's own stores above)
+      uint32_t dscan = nd;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ov = __shfl_up(dscan, d);
+        if (lane >= d) dscan += ov;
+      }
+      __syncthreads();  // (s_parti is free again)
+      if (lane == 63) s_parti[wave] = dscan;
+      __syncthreads();
+      uint32_t dbefore = 0;
+      for (int w = 0; w < kBlock / 64; ++w) {
+        if (w < wave) dbefore += s_parti[w];
+        ndrawn += s_parti[w];
+      }
+      uint32_t doff = dbefore + dscan - nd;
+      for (uint32_t i = b0; i < b1; ++i)
+        if (dinfo[i] & 0xffffu) tlist[doff++] = i;
+    }
     if (tid == 0) next_tile = 0;
     __syncthreads();
     PYNQS_STAMP(7);
@@ -1464,6 +1490,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
     } else if (!(o.debug & 16u)) {
       ListDrawSink<LEN, T> sink{eps, S, dinfo, Srow / (double)nsample, key, (int64_t)walker * nsample, o.srec_col, o.srec_w, pend, 0xffffffffu};
       sink.nodraw = (o.debug & 8u) != 0;
+      if constexpr (GTILE) { sink.tlist = tlist; sink.ndrawn = ndrawn; }
       visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
       sink.flush();
     }

@@ -109,6 +109,14 @@ struct sink_can_pause : std::false_type {};
 template <typename S>
 struct sink_can_pause<S, std::void_t<decltype(std::declval<S &>().pause())>> : std::true_type {};
 
+// optional member of a sink: uint32_t remap(uint32_t k) -- the k-th tile a wave takes is tile remap(k) (0xffffffff: none left): a pass over
+// a LIST of tiles instead of all of them (the draw pass of the semi-stochastic REDUCE on long rows: ~900 drawn tiles of 4768, and asking
+// skip_tile for each of the others is a load from global memory when the draw counts live there)
+template <typename S, typename = void>
+struct sink_can_remap : std::false_type {};
+template <typename S>
+struct sink_can_remap<S, std::void_t<decltype(std::declval<S &>().remap(0u))>> : std::true_type {};
+
 template <int LEN, typename T, typename Sink, bool EXACT = true, int QUARTER = kDiagTile / 4>
 __device__ __forceinline__ bool visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
@@ -150,6 +158,7 @@ __device__ __forceinline__ bool visit_tiles(const SDParams &p, const PlanLayout 
     uint32_t tile = 0;
     if (lane == 0) tile = atomicAdd(next_tile, 1u);
     tile = __builtin_amdgcn_readfirstlane(tile);
+    if constexpr (sink_can_remap<Sink>::value) tile = sink.remap(tile);
     if (tile >= ntiles) break;
     sink.tile_begin(tile);  // wave-uniform; everything until the next call belongs to this tile, in a fixed order
     if constexpr (sink_can_skip<Sink>::value) {
