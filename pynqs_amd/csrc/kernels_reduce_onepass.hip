@@ -994,6 +994,7 @@ struct ListDrawSink {
   uint32_t *pend;
   uint32_t tile;
   bool nodraw = false;
+  uint32_t info_cur = 0;            // dinfo[tile], read once per tile (global memory on long rows: three dependent loads per drawn tile otherwise)
   const uint32_t *tlist = nullptr;  // (optional) the drawn tiles, ascending: visit_tiles then walks this list instead of asking skip_tile per tile
   uint32_t ndrawn = 0;
   __device__ __forceinline__ uint32_t remap(uint32_t k) const { return tlist ? (k < ndrawn ? tlist[k] : 0xffffffffu) : k; }
@@ -1053,7 +1054,7 @@ struct ListDrawSink {
   __device__ __forceinline__ void flush() {  // wave-uniform
     if (tile == 0xffffffffu) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t info = dinfo[tile];
+    const uint32_t info = info_cur;
     const uint32_t draws = info & 0xffffu;
     const uint32_t ncols = *S.ncols;
     const double total = *S.run;
@@ -1087,11 +1088,12 @@ struct ListDrawSink {
       pos += __popcll(m);
     }
   }
-  __device__ __forceinline__ bool skip_tile(uint32_t t) const { return (dinfo[t] & 0xffffu) == 0u; }
+  __device__ __forceinline__ bool skip_tile(uint32_t) const { return (info_cur & 0xffffu) == 0u; }  // (asked after tile_begin)
   __device__ __forceinline__ void tile_begin(uint32_t t) {
     flush();
     tile = t;
-    if ((dinfo[t] & 0xffffu) == 0u) return;
+    info_cur = dinfo[t];
+    if ((info_cur & 0xffffu) == 0u) return;
     const int lane = threadIdx.x & 63;
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < kOneTileCols; i += 64) S.hits[i] = 0u;
