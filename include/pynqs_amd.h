@@ -381,11 +381,24 @@ typedef struct pynqs_reduce_io {
                            the sub-eps |H| and the tiles' draw counts then live there instead of the LDS (12 bytes per tile: 57 KB per
                            workgroup at sorb 120, which leaves one workgroup per CU); for rows of more than ~65536 columns */
   int64_t tile_scratch_bytes;
+  float *row_f32;       /* optional, eps_sample > 0: float[nbatch][stride] scratch, stride = ncomb rounded up to a multiple of 16, 64-byte aligned
+                           (pynqs_reduce_onepass_row_f32_elements).  With it -- and where pynqs_reduce_onepass_wants_row_f32 says 1: rows of up to
+                           8192 columns, Fe2S2 -- the enumeration leaves the row's sub-eps matrix elements there as float32 (kept columns: 0) and
+                           the same workgroup then locates the N draws in it: segments of 16 columns, their sums in float64, one lane per draw
+                           (binary search over the segments, 64 bytes of the row read back), hit counts by the rank of a column's bit in a bitmap.
+                           P(column j) = float32(|H_j|) / sum of those (relative 6e-8 of the reference's |H_j| / S); the weight of a drawn record
+                           is the reference's (c / N) sign(H_j) S with S summed in float64.  The drawn records fill the first slots of
+                           srec_* in ascending column order.  row_cache / tile_scratch are not used then. */
 } pynqs_reduce_io;
 int pynqs_reduce_onepass_geometry(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample, int64_t *out4);
 int64_t pynqs_reduce_onepass_tile_scratch_bytes(int64_t nbatch, int sorb, int nele, int noA, int noB, int eps_sample);
 int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
                                        int with_row_cache, int without_table, int64_t *cap_doubles);
+/* 1 when a call with these arguments takes the round-4 semi-stochastic form if io->row_f32 is given (rows of up to 8192 columns, at most
+ * 16383 draws, kept records within the list: Fe2S2), 0 when it would not (leave row_f32 NULL then), -1 on bad arguments;
+ * ..._row_f32_elements: floats io->row_f32 must hold for nbatch walkers (-1 on bad arguments). */
+int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample, int64_t cap_doubles);
+int64_t pynqs_reduce_onepass_row_f32_elements(int64_t nbatch, int sorb, int nele, int noA, int noB);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                          int dtype, double eps, int eps_sample, uint64_t seed, const pynqs_reduce_io *io, void *stream);
 int pynqs_reduce_contract(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,

@@ -81,13 +81,15 @@ class ReduceIO(C.Structure):
                 ("srec_col", _vp), ("srec_w", _vp), ("srec_onv", _vp), ("srec_link", _vp), ("row_sum", _vp),
                 ("dedup_table", _vp), ("uniq_onv", _vp), ("uniq_pm1", _vp), ("pm1_dtype", C.c_int32), ("lut_is_hash", C.c_int32),
                 ("lut_table", _vp), ("lut_nkeys", _i64), ("counters", _vp), ("seed_dev", _vp), ("row_cache", _vp), ("uniq_parent", _vp),
-                ("tile_scratch", _vp), ("tile_scratch_bytes", _i64)]
+                ("tile_scratch", _vp), ("tile_scratch_bytes", _i64), ("row_f32", _vp)]
 
 
 SIGNATURES.update({
     "pynqs_reduce_onepass_geometry": (_int, [_i64, _int, _int, _int, _int, _int, C.POINTER(_i64)]),
     "pynqs_reduce_onepass_tile_scratch_bytes": (_i64, [_i64, _int, _int, _int, _int, _int]),
     "pynqs_reduce_onepass_list_capacity": (_int, [_i64, _int, _int, _int, _int, _int, _int, _int, _int, C.POINTER(_i64)]),
+    "pynqs_reduce_onepass_wants_row_f32": (_int, [_i64, _int, _int, _int, _int, _int, _int, _i64]),
+    "pynqs_reduce_onepass_row_f32_elements": (_i64, [_i64, _int, _int, _int, _int]),
     "pynqs_reduce_onepass": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _int, C.c_uint64, C.POINTER(ReduceIO), _vp]),
     "pynqs_rbm_forward": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _int, _int, _vp, _vp]),
     "pynqs_rbm_children_table_bytes": (_i64, [_i64, _int, _int, _int]),
