@@ -141,3 +141,42 @@ def test_local_energies_with_the_examples_bdg_rnn_amplitude(env, fe2s2):
             energy.SS_KEYS = old
         np.testing.assert_allclose(p.cpu().numpy(), b["psi_ss"], rtol=1e-13)
         np.testing.assert_allclose(e.cpu().numpy(), b["eloc_ss"], rtol=0, atol=TOL)
+
+
+@pytest.mark.parametrize("kind", ["real", "complex"])
+@pytest.mark.parametrize("sampled", [False, True])
+def test_rbm_forward_children_against_the_reference_energies(kind, sampled, fe2s2):
+    """pynqs_rbm_forward_children (14 % of the default bench step) pinned DIRECTLY on the reference's numbers, not on pynqs_rbm_forward:
+    front end -> amplitudes of the distinct x' from their parent walkers -> contraction must give the reference's REDUCE local energies
+    and psi(x) (vmc/energy/eloc.py:205-324 with the reference's RBM, vmc/ansatz/rbm/rbm.py:186-211 / the complex128 module) at 1e-8 Ha absolute:
+    deterministic (eloc_e2e_fe2s2.npz, eloc_complex_module.npz: eps = 1e-2) and semi-stochastic with the kernel's own draws replayed into the
+    reference (eloc_reduce_sampled_fe2s2.npz: 200 draws)."""
+    from pynqs_amd import C_extension as cx, energy as E
+
+    dev = torch.device("cuda")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    d0, dc, d2 = golden("eloc_e2e_fe2s2.npz"), golden("eloc_complex_module.npz"), golden("eloc_flip_multipsi_fe2s2.npz")
+    gs, dr = golden("eloc_reduce_sampled_fe2s2.npz"), golden("reduce_draws_fe2s2.npz")
+    h1e, h2e = T(fe2s2["h1e"]), T(fe2s2["h2e"])
+    if kind == "real":
+        W, hb, vb, flav = T(d0["W"]), T(d0["hb"]), T(d0["vb"]), "real"
+    else:
+        src = d2 if sampled else dc  # (the sampled fixture's complex module is the one of eloc_flip_multipsi_fe2s2.npz)
+        W, hb, vb, flav = T(src["Wc"]), T(src["hbc"]), T(src["vbc"]), "complex"
+    if sampled:
+        x, N, seed = T(gs["x"]), int(gs["eps_sample"]), int(dr["kernel_seed"])
+        want_e = gs["eloc_plain" if kind == "real" else "eloc_complex"]
+        want_p = gs["psi_plain" if kind == "real" else "psi_complex"]
+    else:
+        src = d0 if kind == "real" else dc
+        x, N, seed = T(src["x"]), 0, 0
+        want_e, want_p = src["eloc_reduce"], src["psi_reduce"]
+    E._FRONTS.clear()
+    fe, nu = E.reduce_front(x, h1e, h2e, 40, 30, 15, 15, 1e-2, N, None, seed=seed, want_pm1=False)
+    assert cx.rbm_forward_children_supported(40, W.size(0), flav)
+    psi_u = cx.rbm_forward_children(fe.uniq_onv[:nu].contiguous(), fe.uniq_parent, x, W, hb, vb, 40, flav)
+    eloc, psi_x = fe.contract(psi_u)
+    de = np.abs(eloc.cpu().numpy() - want_e).max()
+    dp = np.abs(psi_x.cpu().numpy() - want_p).max() / np.abs(want_p).max()
+    assert de <= TOL, f"{kind} sampled={sampled}: max |dE_loc| = {de} Ha (|E|max {np.abs(want_e).max()})"
+    assert dp <= 1e-12, f"{kind} sampled={sampled}: psi(x) differs by {dp} relative"

@@ -250,3 +250,64 @@ def test_short_rows_stay_on_the_front_end(fe2s2):
     x = torch.from_numpy(fe2s2["ci_space"][:64].copy()).cuda()
     h1 = torch.from_numpy(fe2s2["h1e"]).cuda()
     assert E._long_row_cap(64, h1, 40, 30, 15, 15, 0) is None and E._front_ok(x, h1, 40, 30, 15, 15, 0) and E._front_ok(x, h1, 40, 30, 15, 15, 100)
+
+
+@pytest.mark.parametrize("sorb,no,n,eps,ns,dedup", [
+    (80, 20, 300, 0.3, 0, True),         # flushing LIST form, rows cut into chunks
+    (80, 20, 5000, 0.49, 0, True),       # flushing LIST form, whole rows
+    (136, 4, 4100, 0.47, 0, False),      # table-less (three words)
+    (120, 30, 64, 0.4995, 0, True),      # BASELINE configs[2]'s shape: 30 alpha 30 beta, two words, 1.19e6 columns
+    (184, 46, 8, 0.4999, 0, True),       # configs[4]'s shape: 46 alpha 46 beta, three words, 6.6e6 columns
+    (80, 20, 48, 0.47, 300, True),       # semi-stochastic flushing form, tile sums in global memory
+    (136, 4, 40, 0.45, 100, True),
+    (120, 30, 16, 0.4995, 200, True),
+    (184, 46, 4, 0.4999, 100, True),
+    (56, 7, 64, 0.47, 1000, True),       # short rows, sparse: flushing with draws
+])
+def test_long_row_forms_against_the_oracle(sorb, no, n, eps, ns, dedup):
+    """The direct leg for the forms above (the other tests compare them with the multi-pass kernels of this library, which share
+    plan_tiles.h / plan_dev.h with them): on the first walkers of the batch the kept records are exactly |<x|H|x'>| >= eps of the CPU
+    oracle's row (oracle/pynqs_oracle.c, pinned to the reference bit for bit) -- set, values and kets --, the drawn records are sub-eps
+    columns of that row with whole hit counts adding up to N and weights (c / N) sign(H) S (vmc/energy/eloc.py:257-298), and every
+    link leads to the record's determinant."""
+    import numpy as np
+    from oracle import oracle as O
+    from pynqs_amd import C_extension as cx, energy as E, reduce_front as RF
+
+    x, h1, h2, _ = _case(sorb, no, n)
+    dev = x.device
+    m = min(n, 4 if sorb < 150 else 2)
+    if dedup:
+        E._FRONTS.clear()
+        fe, nu = E.reduce_front(x, h1, h2, sorb, 2 * no, no, no, eps, ns, seed=23, want_pm1=False)
+    else:
+        _, _, _, _, counts = E.reduce_compact(x, h1, h2, sorb, 2 * no, no, no, eps, sort=True)
+        fe = RF.ReduceFrontEnd(n, sorb, 2 * no, no, no, ns, torch.float64, dev, int(counts.max()) + 8, int(counts.sum()) + 64, want_pm1=False, dedup=False)
+        fe.run(x, cx.plan_for(h1, h2, sorb, dev).buf, eps, 23)
+        assert fe.counters_host()[1] == 0
+    walker, col, w, link, onv, drawn = fe.records()
+    sel = walker < m
+    rows = fe.rows_of(link[sel])
+    assert torch.equal(fe.uniq_onv[rows], onv[sel])
+    walker, col, w, onv, drawn = walker[sel].cpu(), col[sel].cpu().long(), w[sel].cpu(), onv[sel].cpu(), drawn[sel].cpu()
+    co, ho = O.comb_hij_fused(x[:m].cpu().numpy(), h1.cpu().numpy(), h2.cpu().numpy(), sorb, 2 * no, no, no)
+    ho = torch.from_numpy(ho)
+    keep = ho.abs() >= eps
+    got = torch.zeros_like(keep)
+    got[walker[~drawn], col[~drawn]] = True
+    assert torch.equal(got, keep), "kept set differs from the oracle's |H| >= eps"
+    assert torch.equal(w[~drawn], ho[walker[~drawn], col[~drawn]]), "kept values differ from the oracle's"
+    kets = torch.from_numpy(co).reshape(m, ho.shape[1], -1)[walker, col]
+    assert torch.equal(onv, kets), "a record's determinant is not the oracle's x'"
+    if ns:
+        S = torch.where(keep, torch.zeros_like(ho), ho.abs()).sum(1)
+        assert float(((fe.row_sum[:m].cpu() - S) / S).abs().max()) < 1e-12
+        assert not bool(keep[walker[drawn], col[drawn]].any()) and bool((ho[walker[drawn], col[drawn]] != 0).all())
+        hits = w[drawn] * ns / (torch.sign(ho[walker[drawn], col[drawn]]) * S[walker[drawn]])
+        assert float((hits - hits.round()).abs().max()) < 1e-6 and bool((hits.round() >= 1).all())
+        tot = torch.zeros(m, dtype=torch.float64).index_add_(0, walker[drawn], hits.round())
+        assert bool((tot == ns).all())
+        flat = walker[drawn] * ho.shape[1] + col[drawn]
+        assert flat.unique().numel() == flat.numel()
+    else:
+        assert not bool(drawn.any())

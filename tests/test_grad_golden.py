@@ -48,3 +48,30 @@ def test_graphed_grad_matches_reference_gpu():
         for name, p in m.named_parameters():
             w = want[name]
             np.testing.assert_allclose(p.grad.cpu().numpy(), w, rtol=RTOL, atol=RTOL * np.abs(w).max(), err_msg=f"{kind} {name}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_fused_rbm_grad_matches_reference_gpu(world):
+    """pynqs_rbm_grad / grad.FusedRbmGrad (the analytic estimator the default bench step runs) DIRECTLY against the gradients the reference's
+    energy_grad.py:118-184 produced under DDP (grad_fe2s2.npz), all four cases, at world size 1 and on the two ranks' shards of the world-size-2
+    run (DDP averages the ranks' gradients: energy_grad.py:167-181)."""
+    from conftest import golden
+    from pynqs_amd.grad import FusedRbmGrad
+
+    onv = golden("eloc_e2e_fe2s2.npz")["x"]
+    for kind, amd, use_pow in GRAD_CASES:
+        acc, want = None, None
+        for rank in range(world):
+            m, states, prob, eloc, e_total, powr, dt, _amd, want = grad_case(kind, amd, use_pow, "cuda", rank, world)
+            k, res = divmod(32, world)
+            b = rank * k + min(rank, res)
+            x = torch.from_numpy(np.ascontiguousarray(onv[b:b + states.size(0)])).cuda()
+            fg = FusedRbmGrad(m, 40)
+            loss = fg(x, prob, eloc, e_total, powr)
+            assert loss.shape == (1,) and loss.dtype == torch.float64
+            got = {name: p.grad.detach().cpu().numpy().copy() for name, p in m.named_parameters()}
+            acc = got if acc is None else {nm: acc[nm] + got[nm] for nm in got}
+        assert set(acc) == set(want)
+        for name, w in want.items():
+            np.testing.assert_allclose(acc[name] / world, w, rtol=RTOL, atol=RTOL * np.abs(w).max(), err_msg=f"{kind} {amd} ws{world} {name}")
