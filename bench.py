@@ -599,7 +599,7 @@ class ReduceVmcStep(Workload):
     bound = "valu"
 
     def __init__(self, tag, sorb, nele, noA, noB, h1, h2, walkers, dev, eps=1e-2, eps_sample=1000, micro_batch=50000, graphed=True,
-                 fused_amplitudes=True):
+                 fused_amplitudes=True, module=None, module_dtype=torch.complex128, fp_batch=0, autograd_grad=None):
         import torch.distributed as dist
 
         from pynqs_amd import _native as N, C_extension as cx, energy as E, grad as G, reduce_front as RF
@@ -609,12 +609,14 @@ class ReduceVmcStep(Workload):
 
         self.N, self.cx, self.G, self.RF = N, cx, G, RF
         self.name = f"{tag}_reduce_vmc_step"
-        self.kernel, self.pmc_name, self.path = "reduce_onepass_list_kernel", f"{tag}_reduce_vmc_step", "plan"
+        self.kernel, self.pmc_name, self.path = "reduce_onepass_list_rowout_kernel", f"{tag}_reduce_vmc_step", "plan"
         self.sorb, self.nele, self.noA, self.noB, self.dev = sorb, nele, noA, noB, dev
         self.eps, self.eps_sample = eps, eps_sample
         self.h1, self.h2, self.x = h1.to(dev), h2.to(dev), walkers.to(dev).contiguous()
         self.n = self.x.size(0)
         _, self.ncomb = algorithmic_bytes_dropin(sorb, nele, noA, noB)
+        # B_fused(walker) = integral gathers + the walker's words + the result (16 bytes: complex E_loc)
+        self.fused_bytes_per_walker = dropin_byte_parts(sorb, nele, noA, noB)[0] + 8 * ((sorb - 1) // 64 + 1) + 16
         st = torch.cuda.current_stream(dev)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -625,6 +627,14 @@ class ReduceVmcStep(Workload):
         m = ComplexRBM(0.02 * (torch.rand(sorb, sorb, 2, generator=g, dtype=torch.float64) - 0.5),
                        0.02 * (torch.rand(sorb, 2, generator=g, dtype=torch.float64) - 0.5),
                        0.05 * (torch.rand(sorb, 2, generator=g, dtype=torch.float64) - 0.5)).to(dev)
+        # module given (extra.fe2s2_reduce_vmc_step_module_*): ANY nn.Module on the +-1 rows of the distinct x', in chunks of fp_batch rows; then the
+        # amplitudes and the gradient are PyTorch's (no RBM kernels): what an ansatz outside this package gets
+        if module is not None:
+            m, fused_amplitudes = module.to(dev), False
+        self.module_dtype, self.fp_batch = module_dtype, int(fp_batch)
+        if autograd_grad is None:
+            autograd_grad = os.environ.get("PYNQS_BENCH_AUTOGRAD_GRAD") == "1" or module is not None
+        self.fused_amplitudes = fused_amplitudes
         self.module = m
         self.nqs = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev.index]) if dist.is_initialized() and not graphed else m
         self.micro_batch = micro_batch
@@ -643,18 +653,19 @@ class ReduceVmcStep(Workload):
         self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
         # the estimator's gradient: for an RBM analytically from the packed walkers (pynqs_rbm_grad; --autograd-grad: the module's forward +
         # backward replayed from a HIP graph, what any other ansatz gets); either way one all-reduce of the flat gradient buffer
-        self.graphed = (G.FusedRbmGrad(m, sorb) if os.environ.get("PYNQS_BENCH_AUTOGRAD_GRAD") != "1" else
-                        G.GraphedGrad(m, self.n, sorb, torch.complex128, dev)) if graphed else None
+        self.graphed = (G.FusedRbmGrad(m, sorb) if not autograd_grad else G.GraphedGrad(m, self.n, sorb, module_dtype, dev)) if graphed else None
         self.fused_grad = isinstance(self.graphed, G.FusedRbmGrad)
         if self.graphed is not None:
             self.graphed.events = []
         self.phase_events = []
         self.stats = self.eloc = self.psi_x = None
-        self.roofline_note = ("one launch: enumeration of all columns (exact matrix elements, cached per row in global memory), kept-column list sorted in LDS, "
-                              "in-kernel multinomial draw from the cached row, hash-table de-duplication, records with direct row links, the distinct x' with their parent "
-                              "walkers; `achieved` counts vector-ALU wave-instructions (PMC passes of the final tree) but the kernel is neither issue- nor HBM-bound: the 128 L2 "
-                              "channels are busy 96 % of its cycles (66.7 M requests per launch: row cache 37 %, de-duplication 25 %, integral gathers 20 %; tools/pmc_tcc.sh), "
-                              "`traffic` = L2 misses, half of them the row cache's trip to the Infinity Cache and back")
+        self.roofline_note = ("one launch: enumeration of all columns (exact matrix elements; the sub-eps ones also as float32 through global memory), kept-column list "
+                              "sorted in LDS, the N draws located one lane per draw in segments of 16 columns (binary search + 64 bytes read back), hit counts by the rank of "
+                              "a column's bit in an LDS bitmap, hash-table de-duplication (four 16-byte coherent probes per thread side by side), records with direct row "
+                              "links, the distinct x' with their parent walkers.  The kernel is bound by its VECTOR INSTRUCTIONS: `achieved` = SQ_INSTS_VALU per launch / "
+                              "live kernel time against the 2-cycle issue peak (`frac_of_4cycle_issue`: against the rate one wave sustains); `algorithmic_frac` is SURVEY "
+                              "8(d)'s HBM form (the 2 MiB integral plan lives in the L2, so it says how far the kernel is from being memory-bound, not how good it is); "
+                              "`traffic` = (2 FETCH_SIZE + WRITE_SIZE) x 1024 of the same profile")
 
     def step(self):
         st = torch.cuda.current_stream(self.dev)
@@ -675,7 +686,8 @@ class ReduceVmcStep(Workload):
                 psi_u = self.cx.rbm_forward(fe.uniq_onv, m_.params_weights, m_.params_hidden_bias, m_.params_visible_bias, self.sorb, "complex")
         else:
             with torch.no_grad():
-                psi_u = self.module(fe.uniq_pm1)
+                rows, fp = fe.uniq_pm1, self.fp_batch
+                psi_u = self.module(rows) if not fp else torch.cat([self.module(rows[i:i + fp]) for i in range(0, rows.size(0), fp)])
         ev[2].record(st)
         self.eloc, self.psi_x = fe.contract(psi_u)
         ev[3].record(st)
@@ -690,7 +702,7 @@ class ReduceVmcStep(Workload):
         if self.graphed is not None:
             self.loss = self.graphed(self.x if self.fused_grad else states, self.prob, self.eloc, self.stats[0])
         else:
-            self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, torch.complex128, self.micro_batch)
+            self.loss = self.G.grad(self.nqs, states, self.prob, self.eloc, self.stats[0], 1.0, self.module_dtype, self.micro_batch)
         ev[5].record(st)
         self.phase_events.append(ev)
         return ev[0], ev[1]
@@ -816,6 +828,139 @@ class ReduceVmcStep(Workload):
                 "one_thread": {"value": v1, "unit": "local energies/s", "cores": 1, "sample": f"{r1} x the same on the first {s1} walkers ({el1:.1f} s)"}}
 
 
+class ReduceTotalEnergy(Workload):
+    """BASELINE configs[2] / configs[4] at their STATED sizes (sorb 120 with 8192 walkers, sorb 184 with 4096 = the shard of
+    32768 walkers over 8 GPUs; synthetic integrals -- no such system ships with the reference): deterministic REDUCE local energies
+    through energy.total_energy exactly as a caller gets them -- fused-aware chunks of walkers (public_function.get_nbatch(fused=...)), the
+    front end of chunk k + 1 on a second stream while the amplitudes of chunk k are formed (etot.py:24-169), the one-launch front end in its
+    flushing LIST form, table-less once the x' prove distinct, RBM amplitudes of the distinct x' from their parent walkers, contraction.
+    A step = one total_energy call over all walkers.  The amplitude is a real RBM (alpha = 1, seeded): a stand-in for the config's
+    Transformer, which is outside this package (the determinant side is what is measured; `step_phases_gpu_ms` separates the two).
+    Roofline: SURVEY 8(d)'s B_fused (integral gathers counted once each + walker + result) per walker x walkers / the step's GPU time against
+    8 TB/s -- these rows ARE gather-bound: the 153 / 838 MiB plan does not fit the L2 and every column's integral is a 128-byte line fill."""
+
+    bound = "hbm"
+    roofline_algorithmic = True
+
+    def __init__(self, tag, sorb, no, walkers, dev, eps):
+        from pynqs_amd import C_extension as cx, energy as E, public_function as pf
+        from pynqs_amd.rbm import RealRBM
+
+        self.E, self.pf = E, pf
+        self.name, self.kernel, self.path = f"{tag}_reduce_vmc_step", "reduce_onepass_list_flush_kernel", "plan"
+        self.sorb, self.nele, self.noA, self.noB, self.dev, self.eps = sorb, 2 * no, no, no, dev, eps
+        h1, h2 = synth_integrals(sorb)
+        self.h1, self.h2 = h1.to(dev), h2.to(dev)
+        total, self.ncomb = algorithmic_bytes_dropin(sorb, 2 * no, no, no)
+        g_, o_, i_ = dropin_byte_parts(sorb, 2 * no, no, no)
+        self.gather_bytes_per_walker, self.out_bytes_per_walker, self.in_bytes_per_walker = g_, 8, i_
+        self.bytes_per_walker = g_ + i_ + 8          # B_fused: gathers + walker words + one float64 result
+        st = torch.cuda.current_stream(dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        self.plan_obj = cx.plan_for(self.h1, self.h2, sorb, dev)
+        self.plan = self.plan_obj.buf
+        e1.record(st); e1.synchronize()
+        self.plan_build_ms = e0.elapsed_time(e1)
+        g = torch.Generator().manual_seed(1)
+        r = lambda *shape: torch.rand(*shape, generator=g, dtype=torch.float64) - 0.5  # noqa: E731
+        self.module = RealRBM(0.02 * r(sorb, sorb), 0.02 * r(sorb), 0.05 * r(sorb)).to(dev)
+        self.ab = lambda xx, func: pf.ansatz_batch(func, xx, 1 << 22, sorb, dev, torch.float64)  # noqa: E731
+        x = synth_walkers(walkers, sorb, no, no, 4321).to(dev)
+        # (the synthetic diagonal falls below eps for a few walkers: NaN there as in the reference, which total_energy refuses -- keep the others)
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            fin = [torch.isfinite(E.local_energy(x[b:b + 1024].contiguous(), self.h1, self.h2, self.module, self.ab, sorb, 2 * no, no, no, reduce_psi=True, eps=eps)[0])
+                   for b in range(0, walkers, 1024)]
+            self.x = x[torch.cat(fin)].contiguous()
+            self.n = self.x.size(0)
+            self.walkers_per_call = E.auto_nbatch(self.x, self.h1, sorb, 2 * no, no, no, self.module, None, torch.double, True, 0, False, False, False, False)
+            for _ in range(2):  # sizing calls (buffers, the decision to drop the de-duplication table)
+                self._call()
+        finally:
+            torch.set_default_dtype(old)
+        self.prob = torch.full((self.n,), 1.0 / self.n, dtype=torch.float64, device=dev)
+        self.stats = self.eloc = None
+        self.roofline_note = (f"whole total_energy call ({self.n} walkers in chunks of {self.walkers_per_call}: front end + amplitudes + contraction), not the "
+                              "kernel alone; `kernel_only` = the flushing LIST kernel on one chunk, HIP events around the launch")
+
+    def _call(self):
+        return self.E.total_energy(self.x, 0, -1, self.h1, self.h2, self.module, self.sorb, self.nele, self.noA, self.noB, reduce_psi=True, eps=self.eps)[0]
+
+    def step(self):
+        st = torch.cuda.current_stream(self.dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            e0.record(st)
+            self.eloc = self._call()
+            e1.record(st)
+        finally:
+            torch.set_default_dtype(old)
+        from pynqs_amd.distributed import get_world_size
+        from pynqs_amd.stats import dist_stats_moments
+
+        self.stats = dist_stats_moments(self.eloc, self.prob, None, get_world_size())
+        return e0, e1
+
+    def kernel_only(self, reps=5):
+        """the front-end kernel alone on the first chunk (what local_energy launches for it), HIP events around the launch"""
+        E = self.E
+        m = min(self.n, self.walkers_per_call)
+        xs = self.x[:m].contiguous()
+        fe = None
+        for f in E._FRONTS.values():
+            if f.n == m and f.sorb == self.sorb and f.eps_sample == 0:
+                fe = f
+        if fe is None:
+            return None
+        st = torch.cuda.current_stream(self.dev)
+        fe.run(xs, self.plan, self.eps, 0, None)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fe.run(xs, self.plan, self.eps, 0, None)
+        e1.record(st); e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        alg = self.bytes_per_walker * m
+        return {"kernel": self.kernel, "walkers": m, "kernel_ms": ms, "table_less": not fe.dedup, "algorithmic_bytes_per_launch": alg,
+                "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "columns_per_s": self.ncomb * m / (ms * 1e-3)}
+
+    def _oracle_eloc(self, m, nthreads=0, batch=2):
+        """the reference's _reduce_psi by the CPU oracle: materialise comb + Hmat (OpenMP over walkers), |H| >= eps, the RBM on the kept x' (numpy), contract"""
+        from oracle import oracle as O
+
+        W, hb, vb = (t.detach().cpu().numpy() for t in (self.module.weights, self.module.hidden_bias, self.module.visible_bias))
+        out = np.empty(m)
+        for b in range(0, m, batch):  # (a few walkers at a time: 28.6 / 212 MB of drop-in output per walker; one OpenMP thread per walker)
+            xs = self.x[b:min(b + batch, m)].cpu().numpy()
+            co, ho = O.comb_hij_fused(xs, self.h1.cpu().numpy(), self.h2.cpu().numpy(), self.sorb, self.nele, self.noA, self.noB, nthreads=nthreads)
+            for i in range(xs.shape[0]):
+                keep = np.abs(ho[i]) >= self.eps
+                psi = O.rbm_real_psi(np.ascontiguousarray(co[i][keep]), self.sorb, W, hb, vb)
+                p0 = O.rbm_real_psi(np.ascontiguousarray(xs[i:i + 1]), self.sorb, W, hb, vb)[0]
+                out[b + i] = (ho[i][keep] * psi).sum() / p0
+        return out
+
+    def parity_gate(self):
+        m = min(self.n, 4 if self.sorb < 150 else 2)
+        want = self._oracle_eloc(m)
+        de = float(np.abs(self.eloc[:m].cpu().numpy() - want).max())
+        return bool(de <= 1e-8), de
+
+    def cpu_baseline(self, budget_s=20.0):
+        cores = min(len(os.sched_getaffinity(0)), 16 if self.sorb < 150 else 8)  # (one thread per walker of a batch; 212 MB of output per walker at sorb 184)
+        t0 = time.perf_counter(); self._oracle_eloc(cores, cores, cores); per = time.perf_counter() - t0
+        sample = cores * int(max(1, min(self.n // cores, 8, budget_s * 0.8 / max(per, 1e-6))))
+        t0 = time.perf_counter(); self._oracle_eloc(sample, cores, cores); el = time.perf_counter() - t0
+        return {"value": sample / el, "unit": "local energies/s", "cores": cores, "kind": "port",
+                "sample": f"oracle (C restatement, one OpenMP thread per walker: comb + Hmat materialised, |H| >= eps, the RBM on the kept x', contraction; "
+                          f"eloc.py:243-318) on the first {sample} walkers, {cores} at a time ({el:.1f} s)"}
+
+
 class DecoderAmplitude(torch.nn.Module):
     """Stand-in for BASELINE.json's 'Transformer ansatz' (DecoderWaveFunction defaults d_model 32, 6 layers,
     8 heads, vmc/ansatz/transformer/decoder.py:43-69): an autoregressive decoder over the sorb/2 spatial orbitals (4 occupation
@@ -842,38 +987,47 @@ class DecoderAmplitude(torch.nn.Module):
         return torch.exp(0.5 * logp) * torch.cos(self.phase(hid[:, -1]).squeeze(-1))
 
 
+WALKER_OFFSET = None  # --scaling strong: first walker of this rank's shard (weak scaling: rank * walkers)
+
+
 def make_workload(name: str, walkers: int, rank: int, dev, path: str = "plan", keys: int = 65536, graphed: bool = True) -> Workload:
+    first = rank * walkers if WALKER_OFFSET is None else WALKER_OFFSET
     if name == "fe2s2_reduce_vmc_step":
         d = load_fe2s2()
         ci = d["ci_space"]
-        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        idx = (np.arange(walkers) + first) % ci.shape[0]
         return ReduceVmcStep("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
                              torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev, graphed=graphed,
                              fused_amplitudes=os.environ.get("PYNQS_BENCH_TORCH_AMPLITUDES") != "1")
     if name == "fe2s2_vmc_step":
         d = load_fe2s2()
         ci = d["ci_space"]
-        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        idx = (np.arange(walkers) + first) % ci.shape[0]
         return VmcStep("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
                        torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), torch.from_numpy(ci.copy()), dev, graphed=graphed)
     if name == "fe2s2_eloc_sample_space":
         d = load_fe2s2()
         ci = d["ci_space"]
-        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        idx = (np.arange(walkers) + first) % ci.shape[0]
         return SampleSpaceFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
                                 torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), torch.from_numpy(ci.copy()), dev)
     if name == "fe2s2_eloc_rbm":
         d = load_fe2s2()
         ci = d["ci_space"]
-        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        idx = (np.arange(walkers) + first) % ci.shape[0]
         return RbmFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
                         torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev)
     if name == "fe2s2_dropin":
         d = load_fe2s2()
         ci = d["ci_space"]
-        idx = (np.arange(walkers) + rank * walkers) % ci.shape[0]
+        idx = (np.arange(walkers) + first) % ci.shape[0]
         return DropinFused("fe2s2", int(d["sorb"]), int(d["nele"]), int(d["noA"]), int(d["noB"]), torch.from_numpy(d["h1e"]),
                            torch.from_numpy(d["h2e"]), torch.from_numpy(np.ascontiguousarray(ci[idx])), dev, path)
+    if name.startswith("syn") and name.endswith("_reduce_vmc_step"):
+        sorb = int(name[3:-16])
+        no = {56: 7, 120: 30, 184: 46}.get(sorb, sorb // 4)
+        eps = {56: 0.47, 120: 0.49995, 184: 0.49999}.get(sorb, 0.49)
+        return ReduceTotalEnergy(f"syn{sorb}", sorb, no, walkers, dev, eps)
     if name.startswith("syn") and name.endswith("_eloc_rbm"):
         sorb = int(name[3:-9])
         no = {56: 7, 120: 30, 184: 46}.get(sorb, sorb // 4)
@@ -907,6 +1061,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="fe2s2_reduce_vmc_step")
     ap.add_argument("--walkers", type=int, default=8192, help="walkers per GPU")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --walkers per GPU; strong: --total-walkers split over the GPUs as the reference splits its unique samples (SURVEY 8(e))")
+    ap.add_argument("--total-walkers", type=int, default=65536, help="--scaling strong: walkers of the whole job (BASELINE configs[3]: 65536)")
     ap.add_argument("--keys", type=int, default=65536, help="sample-space size of the syn<sorb>_eloc_sample_space workloads")
     ap.add_argument("--path", default="plan", choices=["plan", "direct"], help="integral-plan kernels or direct packed-triangle kernels")
     ap.add_argument("--no-comb", action="store_true", help="diagnostic: skip the comb output (Hmat only)")
@@ -958,7 +1115,18 @@ def main():
         os.environ["PYNQS_BENCH_TORCH_AMPLITUDES"] = "1"
     if args.autograd_grad:
         os.environ["PYNQS_BENCH_AUTOGRAD_GRAD"] = "1"
-    wl = make_workload(args.workload, args.walkers, rank, dev, args.path, args.keys, not args.eager_grad)
+    walkers_here = args.walkers
+    if args.scaling == "strong":
+        # contiguous shards, the first total % world ranks one walker longer (utils/distributed/comm.py:108-111, public_function.py:720-746),
+        # probabilities pre-scaled by the world size (vmc/sample.py:772)
+        global WALKER_OFFSET
+        from pynqs_amd.distributed import shard_bounds
+
+        b_, e_ = shard_bounds(args.total_walkers, world, rank)
+        walkers_here, WALKER_OFFSET = e_ - b_, b_
+    wl = make_workload(args.workload, walkers_here, rank, dev, args.path, args.keys, not args.eager_grad)
+    if args.scaling == "strong" and hasattr(wl, "prob"):
+        wl.prob.fill_(world / args.total_walkers)
     if args.no_comb:
         wl.comb_ptr = None
 
@@ -1018,6 +1186,16 @@ def main():
         t = kern_ms * 1e-3
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_{getattr(w, 'pmc_name', w.name)}.json")
         pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+        # a stored profile counts only if it was measured on THESE native sources (tools/pmc_roofline.py stores their sha256): a stale one
+        # is named, and nothing derived from its counters is quoted
+        from pynqs_amd.build import source_hash
+
+        stale = bool(pmc) and pmc.get("csrc_sha256") != source_hash()
+        stale_note = None
+        if stale:
+            stale_note = {"stale": True, "profile": os.path.basename(pmc_path), "profile_sha256": pmc.get("csrc_sha256"), "tree_sha256": source_hash(),
+                          "note": "the stored counters were measured on other native sources: re-run tools/pmc_roofline.py; counter-derived fields are omitted"}
+            pmc = {}
         traffic = pmc.get("hbm_bytes_per_launch")
         if traffic is not None and pmc.get("walkers"):
             traffic = traffic * w.n / pmc["walkers"]
@@ -1043,11 +1221,25 @@ def main():
                    "traffic": traffic, "kernel_ms": kern_ms, "valu_instructions_per_launch": insts,
                    "columns_per_s": w.ncomb * w.n / t,
                    "source": pmc.get("source", f"no {os.path.basename(pmc_path)}: instruction count unknown")}
+            # SURVEY 8(d)'s form beside it: algorithmic bytes of the fused path (integral gathers counted once each + the walker + the result),
+            # the counters' HBM-side bytes, the L2 hit rate of the launch
+            alg = getattr(w, "fused_bytes_per_walker", getattr(w, "bytes_per_walker", None))
+            if alg is not None:
+                out["algorithmic_bytes_per_launch"] = alg * w.n
+                out["algorithmic_frac"] = alg * w.n / t / 1e9 / HBM_PEAK_GBS
+            if traffic:
+                out["hbm_traffic_frac"] = traffic / t / 1e9 / HBM_PEAK_GBS
+            if pmc.get("l2_hit_rate") is not None:
+                out["l2_hit_rate"] = pmc["l2_hit_rate"]
+            if pmc.get("rocprof_kernel_avg_ns"):
+                out["rocprof_kernel_ms"] = pmc["rocprof_kernel_avg_ns"] * 1e-6
         else:
             plan_bytes = w.plan.numel() * w.plan.element_size() if getattr(w, "plan", None) is not None else w.gather_bytes_per_walker * w.n
             mandatory = (w.out_bytes_per_walker + w.in_bytes_per_walker) * w.n + min(w.gather_bytes_per_walker * w.n, plan_bytes)
-            ach = mandatory / t / 1e9
             alg = w.bytes_per_walker * w.n
+            # (rows whose integral plan does not fit the L2 -- the total_energy workloads: every column's integral is a line fill of its own,
+            # SURVEY 8(d)'s algorithmic bytes ARE the traffic model; `mandatory` would count the 153 / 838 MiB plan once)
+            ach = (alg if getattr(w, "roofline_algorithmic", False) else mandatory) / t / 1e9
             out = {"bound": "hbm", "kernel": w.kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                    "traffic": traffic, "kernel_ms": kern_ms, "hbm_mandatory_bytes_per_launch": mandatory,
                    "algorithmic_bytes_per_launch": alg, "algorithmic_frac": alg / t / 1e9 / HBM_PEAK_GBS}
@@ -1055,6 +1247,8 @@ def main():
                 out["hbm_traffic_frac"] = traffic / t / 1e9 / HBM_PEAK_GBS
         if getattr(w, "roofline_note", None):
             out["note"] = w.roofline_note
+        if stale_note:
+            out["stale_profile"] = stale_note
         return out
 
     el, kern_ms = timed(wl, args.warmup, args.steps)
@@ -1062,7 +1256,7 @@ def main():
 
     if rank == 0:
         ok_c, dh = wl.parity_gate()
-        total_walkers = wl.n * world * args.steps
+        total_walkers = (args.total_walkers if args.scaling == "strong" else wl.n * world) * args.steps
         out = {
             "metric": "local energies/sec (whole node)" if not isinstance(wl, DropinFused) else "S+D rows/sec: enumerate + <x|H|x'> materialised, no psi (whole node)",
             "value": total_walkers / el,
@@ -1072,7 +1266,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": ("REHEARSAL (all ranks on one GPU, gloo): not a measurement; " if rehearsal else "") +
@@ -1094,6 +1288,10 @@ def main():
                       else "oracle too slow at this size (tests/ cover the kernel at sizes it finishes)",
         }
         if isinstance(wl, (VmcStep, ReduceVmcStep)):
+            if phases is not None:
+                # what crosses xGMI per step: one packed all-reduce of the moments, one of the flat gradient buffer (+ the loss)
+                phases["stats_allreduce_bytes"] = 4 * 8
+                phases["grad_allreduce_bytes"] = int(sum(p.numel() for p in wl.module.parameters()) + 1) * 8
             out["step_phases_gpu_ms"] = phases
             out["config"]["amplitude_module"] = "complex128 RBM, alpha = 1 (stand-in for the example's BDG-RNN), AD_MAX_DIM = %d as in example/Fe2S2 (one micro-batch for 8192 walkers)" % wl.micro_batch
         if isinstance(wl, (VmcStep, ReduceVmcStep)):
@@ -1107,6 +1305,10 @@ def main():
             out["config"].update({"method": "REDUCE (vmc/energy/eloc.py:205-324), the Fe2S2 example's setting", "eps": wl.eps, "eps_sample": wl.eps_sample,
                                   "amplitudes_on_distinct_rows": ("pynqs_rbm_forward_children (from the parent walkers' hidden-unit factors by table multiplications)" if getattr(wl, "from_parents", False) else "pynqs_rbm_forward (one kernel, from the packed determinants)") if wl.fused_amplitudes
                                   else "the PyTorch module on the +-1 rows"})
+        if isinstance(wl, ReduceTotalEnergy):
+            out["roofline"]["kernel_only"] = wl.kernel_only()
+            out["config"].update({"method": "REDUCE (vmc/energy/eloc.py:205-324) through total_energy (etot.py:24-169)", "eps": wl.eps, "walkers_per_local_energy_call": wl.walkers_per_call,
+                                  "amplitude_module": "real RBM, alpha = 1 (stand-in for the config's Transformer), amplitudes of the distinct x' by pynqs_rbm_forward_children"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
     # secondary measurements (same run, N = 1 only): drop-in rows, the other fused local energies and the larger word counts
@@ -1115,7 +1317,9 @@ def main():
         for name, nw, steps in (("fe2s2_vmc_step", args.walkers, 300), ("fe2s2_dropin", args.walkers, 2000), ("fe2s2_eloc_sample_space", args.walkers, 1000), ("fe2s2_eloc_rbm", args.walkers, 500),
                                 ("syn56_eloc_rbm", 4096, 200), ("syn120_dropin", 64, 500), ("syn184_dropin", 16, 200),
                                 ("syn120_eloc_sample_space", args.walkers, 10), ("syn120_eloc_rbm", 512, 10),
-                                ("syn184_eloc_sample_space", args.walkers, 10), ("syn184_eloc_rbm", 128, 3)):
+                                ("syn184_eloc_sample_space", args.walkers, 10), ("syn184_eloc_rbm", 128, 3),
+                                # BASELINE configs[2] / configs[4] at their stated sizes: deterministic REDUCE through total_energy
+                                ("syn120_reduce_vmc_step", 8192, 5), ("syn184_reduce_vmc_step", 4096, 3)):
             try:
                 w2 = make_workload(name, nw, rank, dev, args.path)
                 el2, k2 = timed(w2, max(2, steps // 10), steps)
@@ -1127,12 +1331,44 @@ def main():
                                             else "oracle too slow at this size (tests/ cover the kernel at sizes it finishes)"}
                 if hasattr(w2, "phases_ms"):
                     extra[w2.name]["step_phases_gpu_ms"] = w2.phases_ms()
-                if name in ("fe2s2_dropin", "fe2s2_eloc_rbm", "fe2s2_vmc_step") and not args.no_cpu_baseline:
+                if isinstance(w2, ReduceTotalEnergy):
+                    extra[w2.name]["roofline"]["kernel_only"] = w2.kernel_only()
+                    extra[w2.name]["walkers_per_local_energy_call"] = w2.walkers_per_call
+                if name in ("fe2s2_dropin", "fe2s2_eloc_rbm", "fe2s2_vmc_step", "syn120_reduce_vmc_step", "syn184_reduce_vmc_step") and not args.no_cpu_baseline:
                     extra[w2.name]["cpu_baseline"] = w2.cpu_baseline(budget_s=8.0)
                 del w2
                 torch.cuda.empty_cache()
             except Exception as e:  # pragma: no cover  (keeps the primary line intact)
                 extra[name] = {"error": repr(e)}
+        # the default (semi-stochastic) step with a GENERIC ansatz: the amplitudes of the distinct x' by a PyTorch module on their +-1 rows and the
+        # gradient estimator by autograd -- what any ansatz outside this package gets (SURVEY 8(d)(ii'): determinant-side ms and forward ms apart)
+        try:
+            d5 = load_fe2s2()
+            ci5 = d5["ci_space"]
+            args5 = ("fe2s2", int(d5["sorb"]), int(d5["nele"]), int(d5["noA"]), int(d5["noB"]), torch.from_numpy(d5["h1e"]), torch.from_numpy(d5["h2e"]),
+                     torch.from_numpy(np.ascontiguousarray(ci5[np.arange(args.walkers) % ci5.shape[0]])), dev)
+            torch.manual_seed(7)
+            for tag5, steps5, kw5 in (("fe2s2_reduce_vmc_step_module_rbm_torch", 20, dict(fused_amplitudes=False, autograd_grad=True)),
+                                      ("fe2s2_reduce_vmc_step_module_decoder_torch", 2,
+                                       dict(module=DecoderAmplitude(int(d5["sorb"])).double().eval(), module_dtype=torch.float64, fp_batch=100_000, graphed=False))):
+                old5 = torch.get_default_dtype()
+                torch.set_default_dtype(torch.float64)
+                try:
+                    w5 = ReduceVmcStep(*args5, **kw5)
+                    el5, k5 = timed(w5, 2, steps5)
+                    ph5 = w5.phases_ms()
+                finally:
+                    torch.set_default_dtype(old5)
+                det5 = ph5["reduce_front_end_kernel_ms"] + ph5["contraction_kernel_ms"] + ph5["stats_allreduce_ms"]
+                extra[tag5] = {"value": w5.n * steps5 / el5, "unit": "local energies/s", "walkers": w5.n, "ms_per_step": el5 / steps5 * 1e3, "step_phases_gpu_ms": ph5,
+                               "determinant_side_ms": det5, "ansatz_forward_ms": ph5["amplitudes_on_distinct_rows_ms"], "gradient_ms": ph5["grad_ms"],
+                               "ansatz": "pynqs_amd.rbm.ComplexRBM (complex128, alpha = 1) as a PyTorch module on all rows of the distinct list; gradient: autograd replayed from a HIP graph"
+                                         if "rbm" in tag5 else "autoregressive Transformer decoder stand-in (d_model 32, 6 layers, 8 heads, f64, random weights) in chunks of 100 000 rows; gradient: eager autograd",
+                               "parity": "tests/test_gpu_reduce_golden_r3.py (the same front end + contraction with modules, 1e-8 Ha against the reference)"}
+                del w5
+                torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            extra["fe2s2_reduce_vmc_step_module"] = {"error": repr(e)}
         # (ii') of SURVEY.md 8(d): enumeration + |<x|H|x'>| >= eps compaction (count and emit passes, nothing materialised),
         # what an external PyTorch ansatz is fed with; eps keeps about 1 % of the columns
         try:

@@ -23,6 +23,19 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash() -> str:
+    """sha256 over the native sources (csrc/*.hip, csrc/*.h, include/pynqs_amd.h; names and contents): what a stored profile of a kernel
+    (profiles/pmc_*.json, written by tools/pmc_roofline.py) was measured on -- bench.py refuses to quote a profile of another tree."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(_HERE, "..", "include", "pynqs_amd.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -550,7 +550,7 @@ def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1,
 
 def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
                         lut=None, seed: Optional[int] = None, pm1_dtype: Optional[torch.dtype] = None, want_pm1: bool = True, slot: int = 0,
-                        route: bool = False):
+                        route: bool = False, consumer=None):
     """Enqueue the fused REDUCE front end for the walkers x on the CURRENT stream (buffers cached per (device, batch size, system,
     eps_sample, slot)) together with an asynchronous copy of its counters to pinned host memory; returns a ticket for reduce_front_finish.
     Nothing is waited for: a caller can enqueue the front end of the NEXT chunk of walkers on a second stream while the ansatz works on
@@ -570,6 +570,8 @@ def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: in
             _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, caps[0], caps[1], dedup=False)
     if seed is None:
         seed = _draw_seed() if eps_sample > 0 else 0
+    if consumer is not None:
+        fe.record_stream(consumer)  # (the caller launches on one stream and reads the workspace on another)
     fe.run(x, plan.buf, eps, seed, lut)
     host = torch.empty(4, dtype=torch.int32, pin_memory=True)
     host.copy_(fe.counters, non_blocking=True)
@@ -1024,13 +1026,20 @@ def total_energy(
         side = _side_stream(device)
         ht_, rbm_fwd_ = _reduce_front_options(ansatz, WF_LUT, dtype, use_multi_psi, use_spin_flip)
 
+        xc = x.contiguous()  # (once, on the main stream: the chunks are views of it, no copy kernel runs between the streams)
+
         def launch(k: int) -> None:
-            xs = x[starts[k]:ends[k]].contiguous()
-            side.wait_stream(main) if k == 0 else None
+            xs = xc[starts[k]:ends[k]]
+            if k == 0:
+                side.wait_stream(main)  # (xc and whatever else the caller wrote on the main stream; later launches read nothing newer than that --
+                #                          waiting every time would hold chunk k + 1's front end back until chunk k - 1 has been contracted)
             if k >= 2:
                 side.wait_event(done[k - 2])  # the workspace of slot k % 2 is free once chunk k - 2 has been contracted
             with torch.cuda.stream(side):
-                tickets[k] = reduce_front_launch(xs, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht_, want_pm1=not rbm_fwd_, slot=k % 2, route=True)
+                # (consumer: the workspace is allocated in the side stream's pool and read on the main stream -- the allocator must not hand
+                # its memory out again while main-stream work on it is pending)
+                tickets[k] = reduce_front_launch(xs, h1e, h2e, sorb, nele, noa, nob, eps, int(eps_sample), ht_, want_pm1=not rbm_fwd_, slot=k % 2, route=True,
+                                                 consumer=main)
 
         launch(0)
     begin = 0

@@ -165,6 +165,13 @@ class ReduceFrontEnd:
         io.row_f32 = self.row_f32.data_ptr() if self.row_f32 is not None else None
         return io
 
+    def record_stream(self, stream) -> None:
+        """The buffers are (also) used on `stream`: when this front end was allocated under another stream's context (total_energy's
+        look-ahead), the caching allocator must wait for that stream's pending work before it hands the memory out again."""
+        for t in vars(self).values():
+            if isinstance(t, Tensor) and t.is_cuda:
+                t.record_stream(stream)
+
     # ---- launches -------------------------------------------------------------------------------------------------------
     def run(self, x: Tensor, plan: Tensor, eps: float, seed: int = 0, lut=None) -> None:
         """Enqueue the front end for the walkers `x` (uint8 [n, 8 len]).  `lut`: the hash table of a WavefunctionLUT (its

@@ -52,3 +52,24 @@ def test_the_default_reduce_step_runs_on_two_ranks():
     out = _run(["--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--walkers", "256"], 2, {"PYNQS_BENCH_REHEARSAL": "1"})
     assert out["n_gpus"] == 2 and out["config"]["workload"] == "fe2s2_reduce_vmc_step" and out["config"]["eps_sample"] == 1000
     assert out["value"] > 0 and np.isfinite(out["check"]["grad_l2"]) and out["parity"]["exact_part_bit_exact"]
+
+
+@pytest.mark.parametrize("ranks", [4, 5])
+def test_strong_scaling_with_uneven_shards(ranks):
+    """--scaling strong: 1027 walkers of the whole job split as the reference splits its unique samples (utils/distributed/comm.py:108-111:
+    the first total % world ranks one walker longer; probabilities pre-scaled by the world size, vmc/sample.py:772) over 4 and 5 ranks
+    (the GPU box admits six processes on its card, the test runner being one of them; the 8-rank case is the driver's, on 8 GPUs) must reproduce the one-rank moments and
+    gradient of the same 1027 walkers."""
+    common = ["--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--workload", "fe2s2_vmc_step", "--scaling", "strong", "--total-walkers", "1027"]
+    many = _run(common, ranks, {"PYNQS_BENCH_REHEARSAL": "1"})
+    one = _run(common, 1)
+    assert many["n_gpus"] == ranks and many["scaling"] == "strong" and one["scaling"] == "strong"
+    assert many["config"]["walkers_per_gpu"] == 1027 // ranks + (1 if 1027 % ranks else 0)   # (rank 0 holds one of the longer shards)
+    assert one["config"]["walkers_per_gpu"] == 1027
+    ph = many["step_phases_gpu_ms"]
+    assert ph["stats_allreduce_bytes"] == 32 and ph["grad_allreduce_bytes"] > 0
+    a, b = many["check"], one["check"]
+    np.testing.assert_allclose(a["mean_eloc"], b["mean_eloc"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a["var_eloc"], b["var_eloc"], rtol=1e-9)
+    np.testing.assert_allclose(a["grad_l2"], b["grad_l2"], rtol=1e-9)
+    np.testing.assert_allclose(a["grad_first"], b["grad_first"], rtol=1e-8, atol=1e-12)

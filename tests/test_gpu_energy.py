@@ -192,6 +192,34 @@ def test_total_energy_look_ahead_on_a_second_stream(env, eps_sample):
         np.testing.assert_allclose(out[True].cpu().numpy(), env["d"]["eloc_reduce"], rtol=0, atol=TOL)
 
 
+def test_total_energy_look_ahead_with_a_non_contiguous_batch(env):
+    """The walkers as a strided view (every other row of a larger tensor) under the look-ahead: the chunks are made contiguous once, on the
+    main stream, before anything is enqueued on the second one (a per-chunk copy on the main stream raced with the side stream's kernel);
+    the small buffers force the overflow / regrow path of a look-ahead workspace as well."""
+    energy = env["energy"]
+    args = (env["h1e"], env["h2e"], env["rbm"], 40, 30, 15, 15)
+    x = env["x"]
+    wide = torch.zeros((2 * x.size(0), x.size(1)), dtype=torch.uint8, device=x.device)
+    wide[0::2] = x
+    wide[1::2] = x.flip(0)
+    xv = wide[0::2]
+    assert not xv.is_contiguous() and torch.equal(xv, x)
+    old_rbm, energy.FUSED_RBM = energy.FUSED_RBM, False
+    try:
+        energy._FRONTS.clear()
+        want = energy.total_energy(x, 5, 100000, *args, reduce_psi=True, eps=1e-2)[0]
+        for _ in range(3):  # (first pass: fresh workspaces that overflow and are regrown; then the cached ones)
+            got = energy.total_energy(xv, 5, 100000, *args, reduce_psi=True, eps=1e-2)[0]
+            assert torch.equal(got, want)
+        energy._FRONTS.clear()
+        got = energy.total_energy(xv, 5, 100000, *args, reduce_psi=True, eps=1e-4)[0]   # (hundreds of kept columns: every first launch overflows)
+        want4 = energy.total_energy(x, -1, 100000, *args, reduce_psi=True, eps=1e-4)[0]
+        assert float((got - want4).abs().max()) < 1e-10
+    finally:
+        energy.FUSED_RBM = old_rbm
+    np.testing.assert_allclose(want.cpu().numpy(), env["d"]["eloc_reduce"], rtol=0, atol=TOL)
+
+
 def test_spin_flip_helpers_and_eps0_consistency(env):
     """Helper forms (packed / occupation rows) agree, and REDUCE with eps = 0 equals SIMPLE for the projected form.  (Parity of the
     projected and multi-psi local energies themselves against the reference's Python: test_gpu_energy_flip.py.)"""
