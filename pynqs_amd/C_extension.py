@@ -128,18 +128,25 @@ _PLAN_REBUILD_WARN = 16
 
 
 def plan_for(h1e: Tensor, h2e: Tensor, sorb: int, device: "torch.device | None" = None) -> "IntegralPlan | None":
-    """Cached IntegralPlan for these tensor objects (None when sorb is odd -> direct kernels).  The cache is keyed on the
-    tensor OBJECTS (identity, version counter, storage address): keep h1e / h2e alive between calls.  `device`: where
-    host-resident integrals are staged (the walkers' device)."""
+    """Cached IntegralPlan for these tensors (None when sorb is odd -> direct kernels).  The cache is keyed on the tensor objects
+    (identity, or any alias of a cached object that is still alive; version counter, storage address): keep h1e / h2e alive between
+    calls -- a fresh copy of equal integrals is a new plan (content is not compared).  `device`: where host-resident integrals are
+    staged (the walkers' device)."""
     import weakref
 
     if sorb % 2 or sorb < 2:
         return None
     ver = (_ver(h1e), _ver(h2e), h1e.data_ptr(), h2e.data_ptr())
     trackable = ver[0] >= 0 and ver[1] >= 0  # (inference-mode tensors have no version counter: in-place edits would go unnoticed)
+    def same(ref, t):
+        # the cached tensor object itself, or -- while that object is alive, so that its storage cannot have been freed and handed out
+        # again -- another tensor object over the same memory (a view, .detach(), a re-wrapped parameter): same address, shape, strides, dtype
+        o = ref()
+        return o is t or (o is not None and o.data_ptr() == t.data_ptr() and o.shape == t.shape and o.stride() == t.stride() and o.dtype == t.dtype)
+
     for i, (r1, r2, v, s, pl) in enumerate(_PLANS if trackable else ()):
-        if r1() is h1e and r2() is h2e and v == ver and s == sorb and (device is None or device.type != "cuda" or pl.device == device
-                                                                       or h1e.device.type == "cuda"):
+        if same(r1, h1e) and same(r2, h2e) and v == ver and s == sorb and (device is None or device.type != "cuda" or pl.device == device
+                                                                           or h1e.device.type == "cuda"):
             if i:
                 _PLANS.insert(0, _PLANS.pop(i))
             return pl

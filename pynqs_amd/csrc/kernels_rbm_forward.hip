@@ -292,16 +292,20 @@ __global__ __launch_bounds__(kChildBlock) void rbm_forward_children_kernel(const
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * kChildBlock + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * kChildBlock) {
     int64_t p = parent[i];
-    p = p < 0 || p >= nwalkers ? 0 : p;
+    // a row that is NOT its parent with at most four orbitals flipped (a parent index out of range, a row the caller put there itself) is
+    // computed from scratch below instead of being truncated to four flips silently
+    bool stranger = p < 0 || p >= nwalkers;
+    p = stranger ? 0 : p;
     // the rows of the factor table for the flipped orbitals ("no flip" for the unused slots)
     int at[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) at[q] = 2 * sorb * HP;
-    int k = 0;
+    int k = 0, nflip = 0;
 #pragma unroll
     for (int w = 0; w < LEN; ++w) {
       const uint64_t xc = onv[i * LEN + w];
       uint64_t d = xc ^ walkers[p * LEN + w];
+      nflip += __popcll(d);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (d && k < 4) {
@@ -360,6 +364,16 @@ __global__ __launch_bounds__(kChildBlock) void rbm_forward_children_kernel(const
         axi += wl[(size_t)(at[q] + H + 1) * C + 1];
       }
     }
+    stranger = stranger || nflip > 4;
+    if (__ballot(stranger)) {  // (rare: the whole wave walks the parameters, the strangers keep the result)
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = onv[i * LEN + w];
+      Prod P2;
+      double a2r, a2i;
+      rbm_forward_row<LEN, FLAVOUR>(ket, sorb, H, W, hb, vb, P2, a2r, a2i);
+      if (stranger) { P = P2; axr = a2r; axi = a2i; }
+    }
     write_psi<FLAVOUR>(psi, i, P, axr, axi);
   }
 }
@@ -406,15 +420,17 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_children_wave_kernel(const
   for (int64_t i0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * kWaveRows; i0 < cnt; i0 += nwaves * kWaveRows)
   for (int64_t i = i0; i < min(i0 + kWaveRows, cnt); ++i) {  // (wave-uniform)
     int64_t p = parent[i];
-    p = p < 0 || p >= nwalkers ? 0 : p;
+    bool stranger = p < 0 || p >= nwalkers;  // (see the kernel above)
+    p = stranger ? 0 : p;
     int at[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) at[q] = 2 * sorb * HP;
-    int k = 0;
+    int k = 0, nflip = 0;
 #pragma unroll
     for (int w = 0; w < LEN; ++w) {
       const uint64_t xc = onv[i * LEN + w];
       uint64_t d = xc ^ walkers[p * LEN + w];
+      nflip += __popcll(d);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         if (d && k < 4) {
@@ -427,6 +443,16 @@ __global__ __launch_bounds__(kBlock) void rbm_forward_children_wave_kernel(const
           ++k;
         }
       }
+    }
+    if (stranger || nflip > 4) {  // (wave-uniform, rare: from scratch, every lane the same row)
+      uint64_t ket[LEN];
+#pragma unroll
+      for (int w = 0; w < LEN; ++w) ket[w] = onv[i * LEN + w];
+      Prod P2;
+      double a2r, a2i;
+      rbm_forward_row<LEN, FLAVOUR>(ket, sorb, H, W, hb, vb, P2, a2r, a2i);
+      if (lane == 0) write_psi<FLAVOUR>(psi, i, P2, a2r, a2i);
+      continue;
     }
     const double *__restrict__ tp = table + (size_t)p * (size_t)(H + 2) * C;
     Prod P;

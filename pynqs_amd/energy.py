@@ -44,6 +44,11 @@ FUSED_SAMPLED = True  # REDUCE with eps_sample > 0: select and draw on chip (red
 FUSED_RBM = True  # SIMPLE method: evaluate a real RBM ansatz inside the kernel (pynqs_eloc_rbm) instead of calling the module
 OVERLAP = __import__("os").environ.get("PYNQS_OVERLAP", "1") != "0"  # total_energy: front end of the next walker chunk on a second stream
 _SIDE_STREAMS: dict = {}
+# The caches below (front-end workspaces, routing decisions, timed kernel choices) are process-wide and guarded by ONE lock: a workspace is
+# popped by the call that uses it and put back when that call has its counters, so two threads never share one; decisions are written once
+# per key.  reset_caches() drops everything (e.g. between two systems in one process).  The C ABI underneath has no global state at all.
+_LOCK = __import__("threading").RLock()
+_CALL_TOKEN: list = [None]  # the total_energy call in progress (an object per call): what per-parameter-state caches of local_energy are valid for
 
 
 def _side_stream(device):
@@ -248,19 +253,16 @@ def _key_major(nkeys: int, sorb: int, noa: int, nob: int, probe: Optional[Callab
         return True
     if nkeys >= hi * ncomb:
         return False
-    if probe is None or not SS_AUTOTUNE or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
-        return nkeys <= ratio * ncomb  # (a probe synchronises: never inside a graph capture)
+    from .distributed import get_world_size as _ws
+
+    if probe is None or not SS_AUTOTUNE or _ws() > 1 or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        # (a probe synchronises: never inside a graph capture; and never with several ranks -- the ranks do not reach this point in the same
+        # calls (an empty shard never calls local_energy, the per-process cache answers some ranks and not others): the fixed ratio decides,
+        # the same on every rank)
+        return nkeys <= ratio * ncomb
     key = (sorb, noa, nob, (4 * nkeys).bit_length(), tag)  # table sizes in steps of sqrt(2)... of 2 with two guard bits: [2^k/4 steps]
     if key not in _SS_CHOICE:
-        from .distributed import get_world_size
-
-        choice = bool(probe()) if get_rank() == 0 or get_world_size() == 1 else False
-        if get_world_size() > 1:  # one answer for all ranks (every rank reaches this point with the same key in the same call)
-            import torch.distributed as dist
-
-            t = torch.tensor([int(choice)], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.broadcast(t, 0)
-            choice = bool(t.item())
+        choice = bool(probe())
         _SS_CHOICE[key] = choice
         import logging
 
@@ -530,8 +532,12 @@ def _long_row_cap(n, h1e, sorb, nele, noa, nob, eps_sample) -> Optional[int]:
     return RF.list_capacity(n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype)
 
 
-def _nodedup_key(device, n, sorb, nele, noa, nob, eps_sample) -> tuple:
-    return (str(device), int(n), sorb, nele, noa, nob, int(eps_sample))
+def _nodedup_key(device, n, sorb, nele, noa, nob, eps_sample, eps=None) -> tuple:
+    return (str(device), int(n), sorb, nele, noa, nob, int(eps_sample), None if eps is None else float(eps))
+
+
+FRONT_NODEDUP_RECHECK = 64   # routed calls after which the decision (table or no table) for a (system, batch size, eps) is measured again:
+_FRONT_NODEDUP_CALLS: dict = {}  # the first VMC iterations see the most diverse walkers; a run must not stay table-less once they concentrate
 
 
 def _new_front(n, x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d=None, cap_u=None, dedup=True):
@@ -561,8 +567,17 @@ def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: in
     n = x.size(0)
     pm1_dtype = pm1_dtype or (torch.float32 if torch.get_default_dtype() == torch.float32 else torch.float64)
     key = (str(x.device), n, sorb, nele, noa, nob, int(eps_sample), h1e.dtype, pm1_dtype, bool(want_pm1), int(slot), bool(route))
-    fe = _FRONTS.pop(key, None)
-    caps = _FRONT_NODEDUP.get(_nodedup_key(x.device, n, sorb, nele, noa, nob, eps_sample)) if (route and FRONT_NODEDUP) else None
+    with _LOCK:
+        fe = _FRONTS.pop(key, None)
+    caps = None
+    if route and FRONT_NODEDUP:
+        nk = _nodedup_key(x.device, n, sorb, nele, noa, nob, eps_sample, eps)
+        if nk in _FRONT_NODEDUP and slot == 0:
+            _FRONT_NODEDUP_CALLS[nk] = _FRONT_NODEDUP_CALLS.get(nk, 0) + 1
+            if _FRONT_NODEDUP_CALLS[nk] >= FRONT_NODEDUP_RECHECK:   # measure again: this call runs with the table and counts
+                _FRONT_NODEDUP.pop(nk)
+                _FRONT_NODEDUP_CALLS[nk] = 0
+        caps = _FRONT_NODEDUP.get(nk)
     if fe is not None and caps is not None and fe.dedup:
         fe = None   # (a workspace from before the decision to drop the table, e.g. the second slot of total_energy's look-ahead)
     if fe is None:
@@ -602,19 +617,32 @@ def reduce_front_finish(t):
         fe = _new_front(x.size(0), x, h1e, sorb, nele, noa, nob, eps_sample, pm1_dtype, want_pm1, cap_d, cap_u, dedup=fe.dedup)
         fe.run(x, t["plan"].buf, t["eps"], t["seed"], t["lut"])
         cnt = fe.counters_host()
-    nk = _nodedup_key(x.device, x.size(0), sorb, nele, noa, nob, eps_sample)
+    nk = _nodedup_key(x.device, x.size(0), sorb, nele, noa, nob, eps_sample, t["eps"])
     if t["route"] and FRONT_NODEDUP and fe.dedup and nk not in _FRONT_NODEDUP:
         # the first call for this system and batch size: how many of the records were distinct?  (one more read-back, once)
         records = fe.count_records()
         list_ok = fe.cap_doubles <= RF.list_capacity(x.size(0), sorb, nele, noa, nob, int(eps_sample), h1e.dtype, without_table=True)
-        if list_ok and t["lut"] is None and cnt[0] > FRONT_NODEDUP_RATIO * records:
+        import logging
+
+        drop = bool(list_ok and t["lut"] is None and cnt[0] > FRONT_NODEDUP_RATIO * records)
+        logging.getLogger("pynqs_amd").info("REDUCE front end, sorb %d, %d walkers, eps %g: %d of %d records distinct -> %s", sorb, x.size(0), t["eps"], cnt[0],
+                                            records, "no de-duplication table from now on" if drop else "de-duplication table kept")
+        if drop:
             _FRONT_NODEDUP[nk] = (fe.cap_doubles, int(records * 1.05) + 4096)
             return fe, cnt[0]   # (not kept: the next call builds the table-less front end)
         _FRONT_NODEDUP[nk] = None
-    _FRONTS[t["key"]] = fe  # (most recently used last)
-    while len(_FRONTS) > _MAX_FRONTS:
-        _FRONTS.pop(next(iter(_FRONTS)))
+    with _LOCK:
+        _FRONTS[t["key"]] = fe  # (most recently used last)
+        while len(_FRONTS) > _MAX_FRONTS:
+            _FRONTS.pop(next(iter(_FRONTS)))
     return fe, cnt[0]
+
+
+def reset_caches() -> None:
+    """Drop every process-wide cache of this module: front-end workspaces, the table / no-table and front-end / multi-pass decisions,
+    timed kernel choices.  (Results never depend on them; which FORM of a kernel a call takes does.)"""
+    with _LOCK:
+        _FRONTS.clear(); _FRONT_NODEDUP.clear(); _FRONT_NODEDUP_CALLS.clear(); _FRONT_DENSE.clear(); _SS_CHOICE.clear()
 
 
 def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
@@ -683,8 +711,9 @@ def local_energy(
                 # f on the sample-space keys (the reference stores f in the table's dtype, flip.py:392): once per parameter state, not once
                 # per chunk of walkers -- total_energy calls this function for every chunk, and the table has up to 1e5-1e6 keys
                 extra = ansatz.module.extra
-                stamp = (id(extra), WF_LUT.bra_key.data_ptr(), WF_LUT.bra_key.size(0), str(WF_LUT.dtype),
-                         tuple((id(q), q._version) for q in extra.parameters()) if hasattr(extra, "parameters") else None)
+                # valid within ONE total_energy call (its token): parameters updated through `p.data.add_` -- the reference's own GD step,
+                # vmc/optim/_base.py:619 -- keep their version counters, so nothing across calls proves that f is still current
+                stamp = (id(extra), WF_LUT.bra_key.data_ptr(), WF_LUT.bra_key.size(0), str(WF_LUT.dtype), _CALL_TOKEN[0])
                 cached = getattr(WF_LUT, "_pynqs_f_keys", None)
                 if cached is not None and cached[0] == stamp and stamp[4] is not None:
                     f_keys = cached[1]
@@ -1000,6 +1029,7 @@ def total_energy(
     device = x.device
     eloc = torch.zeros(dim, device=device).to(dtype)
     sloc = torch.zeros_like(eloc)
+    _CALL_TOKEN[0] = object()
     assert fp_batch > 0 or fp_batch == -1
     assert nbatch > 0 or nbatch in (-1, 0)
     if nbatch == 0:
@@ -1068,6 +1098,7 @@ def total_energy(
         eloc[begin:end] = _eloc
         sloc[begin:end] = _sloc
         begin = end
+    _CALL_TOKEN[0] = None
     if torch.any(torch.isnan(eloc)):
         raise ValueError("The Local energy exists nan")
     return eloc, sloc, torch.zeros(1, device=device, dtype=dtype)

