@@ -18,7 +18,9 @@
 //                 determinants: key and row of a slot come together), ONE allocation of rows per 1024 records, direct links
 // P(column j) = w32_j / S' -- |H_j| rounded to float32, relative 6e-8 -- the multinomial law of torch.multinomial(prob, N, replacement=True) up
 // to that rounding; the weight of a drawn record is exactly the reference's (c / N) sign(H_j) S with the float64 S.
-// LDS (over the staging scratch and the kept list of the enumeration): pfx f64[513] | bitmap u32[256] | kpre u32[256] | rec u32[N].
+// LDS (over the staging scratch of the enumeration): pfx f64[513] | bitmap u32[256] | kpre u32[256]; the drawn records' slots rec u32[N] and
+// the kept records' columns are the caller's (reduce_list.h).  Kept and drawn records are resolved together: one round of probes, one
+// allocation of rows per workgroup instead of two.
 #pragma once
 #include "reduce_common.h"
 
@@ -30,7 +32,8 @@ constexpr uint32_t kNoRec = 0xffffffffu;
 
 __host__ __device__ inline size_t draw_lds_bytes(uint32_t nsample) {
   auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  return al((size_t)(2 * kBlock + 1) * 8) + (size_t)kBlock * 8 + al((size_t)nsample * 4);
+  (void)nsample;  // (the drawn records' slots are the caller's)
+  return al((size_t)(2 * kBlock + 1) * 8) + (size_t)kBlock * 8;
 }
 // elements between the rows of io->row_f32 (rows start 64-byte aligned and end in zeros)
 __host__ __device__ inline size_t draw_row_stride(uint32_t ncomb) { return ((size_t)ncomb + kDrawSeg - 1) & ~(size_t)(kDrawSeg - 1); }
@@ -137,10 +140,13 @@ __device__ __forceinline__ V draw_block_scan(V v, V *s_part, V *total) {
 
 // Every thread of the workgroup must call (barriers inside).  lds: draw_lds_bytes(nsample) bytes nobody else uses any more.
 // w: this walker's row of float32 elements, kDrawSeg-aligned and padded with zeros to a multiple of kDrawSeg.
+// rec: [nsample] words of LDS for the drawn records; kcol / nkept / seg_base: the kept records' columns in slot order (0xffffffff: an empty
+// slot), their number and the first slot of the segment -- they are resolved here, together with the drawn ones.
 template <int LEN, typename T>
-__device__ __forceinline__ void rowout_draws(unsigned char *lds, const SDParams &p, const LdsLayout &L, const Walker<LEN> &wk, const float *__restrict__ w,
-                                             uint32_t nsample, uint64_t seed, uint64_t walker, double Srow, const OnepassOut<T> &o, uint32_t *bw_cnt,
-                                             int32_t *bw_base, uint32_t *s_full, double *s_part, uint32_t *s_parti) {
+__device__ __forceinline__ void rowout_draws(unsigned char *lds, uint32_t *rec, const uint32_t *kcol, uint32_t nkept, int64_t seg_base, const SDParams &p,
+                                             const LdsLayout &L, const Walker<LEN> &wk, const float *__restrict__ w, uint32_t nsample, uint64_t seed,
+                                             uint64_t walker, double Srow, const OnepassOut<T> &o, uint32_t *bw_cnt, int32_t *bw_base, uint32_t *s_full,
+                                             double *s_part, uint32_t *s_parti) {
   constexpr int NT = kBlock, K = 4, SEG = kDrawSeg;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x;
@@ -151,7 +157,7 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, const SDParams 
   double *pfx = reinterpret_cast<double *>(lds);                                      // [2 NT + 1] the segments' starting sums
   uint32_t *bitmap = reinterpret_cast<uint32_t *>(lds + al((size_t)(2 * NT + 1) * 8));  // [NT] the drawn columns
   uint32_t *kpre = bitmap + NT;                                                       // [NT] drawn columns before each word
-  uint32_t *rec = kpre + NT;                                                          // [N] per distinct drawn column (ascending): count << 16 | sign << 15 | column
+  // rec[N]: per distinct drawn column (ascending): count << 16 | sign << 15 | column
   // ---- the segments' sums of the float32 values in float64 (thread t: segments 2 t, 2 t + 1), their starting sums ----
   double ls[2];
 #pragma unroll
@@ -175,6 +181,9 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, const SDParams 
   pfx[2 * tid + 1] = incl - ls[1];
   if (tid == NT - 1) pfx[2 * NT] = total;
   __syncthreads();
+#ifdef PYNQS_OP_STAMPS
+  if (threadIdx.x == 0 && walker < 8192) g_stamps[walker][7] = wall_clock64();
+#endif
   const double scale = Srow / (double)nsample;
   const uint64_t key = op_mix64((o.seed_dev ? seed + *o.seed_dev : seed) ^ op_mix64(walker));
   const bool any_width = total > 0.0;
@@ -270,34 +279,52 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, const SDParams 
   }
   __syncthreads();
   const uint32_t nd = nbw ? kpre[nbw - 1] + (uint32_t)__popc(bitmap[nbw - 1]) : 0u;  // distinct drawn columns
+#ifdef PYNQS_OP_STAMPS
+  if (threadIdx.x == 0 && walker < 8192) g_stamps[walker][8] = wall_clock64();
+#endif
   if (o.debug & 128u) return;
-  // ---- the drawn records (ascending columns, like the reference's unique): columns, weights, kets, probes, rows of the new determinants, links ----
+  // ---- ALL records of the walker, kept (slot order) and drawn (ascending columns, like the reference's unique), four per thread side by
+  //      side: columns, weights, kets, probes, ONE allocation of rows for the new determinants, links ----
   constexpr int32_t kNoRecord = -0x7fffffff;
   for (uint32_t i = nd + tid; i < nsample; i += NT) o.srec_col[sbase + i] = -1;  // (unused draw slots)
-  for (uint32_t i0 = 0; i0 < nd; i0 += K * NT) {
+  const uint32_t nrec = nkept + nd;
+  for (uint32_t i0 = 0; i0 < nrec; i0 += K * NT) {
     bool act[K], won[K];
     uint32_t slot[K];
     int32_t lk[K], rowhint[K];
     uint64_t ket[K][LEN];
+    int64_t dst[K];  // >= 0: kept record, rec_link[dst]; < 0: drawn record, srec_link[-1 - dst]
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t i = i0 + k * NT + tid;
-      act[k] = i < nd; won[k] = false; slot[k] = 0; lk[k] = kNoRecord; rowhint[k] = -1;
+      act[k] = false; won[k] = false; slot[k] = 0; lk[k] = kNoRecord; rowhint[k] = -1; dst[k] = 0;
 #pragma unroll
       for (int ww = 0; ww < LEN; ++ww) ket[k][ww] = wk.w[ww];
-      if (!act[k]) continue;
-      const uint32_t e = rec[i], col = e & 0x7fffu;
-      const int64_t at = sbase + i;
-      o.srec_col[at] = (int32_t)col;
-      const double val = scale * (double)(e >> 16);
-      o.srec_w[at] = (T)(((e >> 15) & 1u) ? -val : val);
+      if (i >= nrec) continue;
+      uint32_t col;
+      if (i < nkept) {
+        col = kcol[i];
+        if (col == kNoRec) continue;
+        dst[k] = seg_base + i;
+      } else {
+        const uint32_t e = rec[i - nkept];
+        col = e & 0x7fffu;
+        const int64_t at = sbase + (i - nkept);
+        dst[k] = -1 - at;
+        o.srec_col[at] = (int32_t)col;
+        const double val = scale * (double)(e >> 16);
+        o.srec_w[at] = (T)(((e >> 15) & 1u) ? -val : val);
+      }
+      act[k] = true;
       if (col) {
         const Excitation x = decode(col - 1, p, L);
         make_ket<LEN>(wk, x, ket[k]);
       }
-      if (o.srec_onv) {
+      uint64_t *onv = dst[k] >= 0 ? o.rec_onv : o.srec_onv;
+      if (onv) {
+        const int64_t g = dst[k] >= 0 ? dst[k] : -1 - dst[k];
 #pragma unroll
-        for (int ww = 0; ww < LEN; ++ww) o.srec_onv[at * LEN + ww] = ket[k][ww];
+        for (int ww = 0; ww < LEN; ++ww) onv[g * LEN + ww] = ket[k][ww];
       }
     }
     bool fast = false;
@@ -320,7 +347,7 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, const SDParams 
       if (lk[k] >= 0 && rows[k] < 0 && rowhint[k] >= 0 && (uint32_t)rowhint[k] < o.ucap) link = rowhint[k] | kDirectLink;
       else if (o.debug & 4096u) link = lk[k];  // (timing ablation: no second look at a slot whose row was not out yet)
       else link = final_link<LEN, T>(o, lk[k], rows[k]);
-      o.srec_link[sbase + i0 + k * NT + tid] = link;
+      if (dst[k] >= 0) o.rec_link[dst[k]] = link; else o.srec_link[-1 - dst[k]] = link;
     }
   }
 }

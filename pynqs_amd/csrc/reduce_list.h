@@ -2,7 +2,6 @@
 // kernels_reduce_rowout.hip: the semi-stochastic kernel for rows whose float32 copy goes through global memory, round 4).
 #pragma once
 #include "reduce_common.h"
-#include "reduce_draw.h"
 
 namespace pynqs {
 
@@ -21,6 +20,10 @@ __device__ unsigned long long g_stamps[8192][16];  // 0-9: phase boundaries; 10-
 #define PYNQS_STAMP_ADD(k) do { } while (0)
 #define PYNQS_STAMP_ZERO(k) do { } while (0)
 #endif
+
+}  // namespace pynqs
+#include "reduce_draw.h"
+namespace pynqs {
 
 struct DrawLds {
   double *prefix;
@@ -71,6 +74,7 @@ struct ListKeepSink {
   uint32_t pause_at = 0;          // FLUSH: the list is emptied once it holds more than this
   unsigned long long tag = 0ull;  // FLUSH: bit 63 for the entries of every tile but tile 0
   float *__restrict__ frow = nullptr;  // ROWOUT: this walker's row of float32 sub-eps elements (global)
+  uint32_t *kbm = nullptr;             // ROWOUT: bitmap of the kept columns (LDS): a kept column's place among the records is the rank of its bit
   template <bool F = FLUSH, typename = std::enable_if_t<F>>
   __device__ __forceinline__ bool pause() const {
     return __builtin_amdgcn_readfirstlane(__atomic_load_n(list_n, __ATOMIC_RELAXED)) > pause_at;
@@ -85,6 +89,7 @@ struct ListKeepSink {
         list_key[k] = FLUSH ? (((unsigned long long)col << 32) | k | tag) : (((unsigned long long)col << 32) | k);
         rec_w[k] = h;
       }
+      if constexpr (ROWOUT) atomicOr(&kbm[col >> 5], 1u << (col & 31u));
     } else if constexpr (SAMPLED && !CACHED) {
       sub += (double)a;
     }
@@ -117,6 +122,7 @@ struct ListKeepSink {
     if (a >= eps) {
       const uint32_t k = atomicAdd(list_n, 1u);
       if (k < cap) { list_key[k] = ((unsigned long long)col << 32) | k; rec_w[k] = h; }
+      if constexpr (ROWOUT) atomicOr(&kbm[col >> 5], 1u << (col & 31u));
     } else if constexpr (SAMPLED && !CACHED) {
       sub += (double)a;
     }
@@ -293,9 +299,8 @@ __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz
     }
     if (!cached && !rowout) b += (kBlock / 64) * kDrawLdsPerWave;
   }
-  if (rowout) {  // (the draws work over the staging scratch, the tile sums and the kept list, all of them done with by then: reduce_draw.h)
-    const size_t enumeration = b + (((size_t)P * 8 + 15) & ~(size_t)15), draws = list_scratch_offset(p) + draw_lds_bytes(nsample);
-    return enumeration > draws ? enumeration : draws;
+  if (rowout) {  // kept list | bitmap of the kept columns | the drawn records' slots; the draws' other arrays lie over the staging scratch (reduce_draw.h)
+    return b + (((size_t)P * 8 + 15) & ~(size_t)15) + (size_t)kBlock * 4 + (((size_t)nsample * 4 + 15) & ~(size_t)15);
   }
   const size_t list = (size_t)P * 8, pend = (size_t)nsample * 4 * (gtile ? 2 : 1);  // (gtile: + the list of the drawn tiles)
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
@@ -334,12 +339,15 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   // decides between 7 and 8 workgroups per CU)
   unsigned long long *list_key = reinterpret_cast<unsigned long long *>(after);
   uint32_t *pend = reinterpret_cast<uint32_t *>(after);           // phase C re-uses the list's memory
+  uint32_t *kbm = reinterpret_cast<uint32_t *>(after + (((size_t)P * 8 + 15) & ~(size_t)15));  // ROWOUT: [kBlock] words (rows of up to 8192 columns)
+  uint32_t *drec = kbm + kBlock;                                                                // ROWOUT: the drawn records' slots [nsample]
   if constexpr (SAMPLED) {
     for (uint32_t i = tid; i < max_tiles; i += kBlock) { tsum[i] = 0.0; dinfo[i] = 0u; }
     if constexpr (!ROWOUT) {
       for (uint32_t i = tid; i < nsample; i += kBlock) o.srec_col[(int64_t)walker * nsample + i] = -1;
-    } else {  // (the zeros behind the row's last column)
+    } else {  // (the zeros behind the row's last column; the bitmap of the kept columns)
       for (size_t i = p.nsd + 1 + tid; i < draw_row_stride(p.nsd + 1); i += kBlock) o.row_f32[(size_t)walker * draw_row_stride(p.nsd + 1) + i] = 0.0f;
+      kbm[tid] = 0u;
     }
   }
   Walker<LEN> wk;
@@ -359,7 +367,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   {
     ListKeepSink<LEN, T, SAMPLED, CACHED, FLUSH, ROWOUT> sink{eps, &list_n, list_key, o.rec_w + seg_base + flushed, room, tsum, 0xffffffffu, 0.0,
                                                               CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
-    if constexpr (ROWOUT) sink.frow = o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1);
+    if constexpr (ROWOUT) { sink.frow = o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1); sink.kbm = kbm; }
     if constexpr (FLUSH) sink.pause_at = P - (kBlock / 64) * kMaxKeptPerTile - 64;  // (every wave may be in the middle of a tile)
     const bool exhausted =
         visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
@@ -384,6 +392,62 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
       }
     }
     for (uint32_t i = n + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
+  }
+  if constexpr (ROWOUT) {
+    // ---- no sort: a kept column's slot is the RANK of its bit in the bitmap (block scan of the words' popcounts) -- ascending columns like
+    //      the reference's boolean mask, whatever the waves' timing was; the records are resolved later, together with the drawn ones ----
+    uint32_t *kpre = reinterpret_cast<uint32_t *>(smem + list_scratch_offset(p));  // (over the staging scratch: the enumeration is over)
+    {
+      uint32_t dummy;
+      const uint32_t c = (uint32_t)__popc(kbm[tid]);
+      const uint32_t inc = draw_block_scan<uint32_t>(c, s_parti, &dummy);
+      kpre[tid] = inc - c;
+    }
+    __syncthreads();
+    PYNQS_STAMP(3);
+    constexpr int kMaxPer = 4;  // n <= 1024
+    T mine_w[kMaxPer];
+    uint32_t mine_c[kMaxPer], mine_r[kMaxPer];
+#pragma unroll
+    for (int r = 0; r < kMaxPer; ++r) {
+      const uint32_t i = (uint32_t)r * kBlock + tid;
+      mine_r[r] = 0xffffffffu; mine_c[r] = 0; mine_w[r] = T(0);
+      if (i < n) {
+        const unsigned long long e = list_key[i];
+        mine_c[r] = (uint32_t)(e >> 32);
+        mine_w[r] = o.rec_w[seg_base + (uint32_t)(e & 0xffffffffull)];
+        mine_r[r] = kpre[mine_c[r] >> 5] + (uint32_t)__popc(kbm[mine_c[r] >> 5] & ((1u << (mine_c[r] & 31u)) - 1u));
+      }
+    }
+    __syncthreads();
+    uint32_t *kcol = reinterpret_cast<uint32_t *>(list_key);  // the kept columns in slot order (over the list, which has been read)
+    for (uint32_t i = tid; i < cap; i += kBlock) kcol[i] = 0xffffffffu;  // (a slot that stays empty -- overflow -- must not be decoded)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kMaxPer; ++r) {
+      if (mine_r[r] < cap) {
+        o.rec_w[seg_base + mine_r[r]] = mine_w[r];
+        o.rec_col[seg_base + mine_r[r]] = (int32_t)mine_c[r];
+        kcol[mine_r[r]] = mine_c[r];
+      }
+    }
+    PYNQS_STAMP(4);
+    PYNQS_STAMP(5);
+    // S: the tiles' exact sums in tile order (their own sums were formed lane by lane + butterfly: nothing depends on the waves' timing)
+    if (wave == 0) {
+      double sl = 0.0;
+      for (uint32_t i = lane; i < max_tiles; i += 64) sl += tsum[i];
+      sl = op_wave_sum(sl);
+      if (lane == 0) { s_part[kBlock / 64] = sl; if (o.row_sum) o.row_sum[walker] = sl; }
+    }
+    __syncthreads();  // (also: the row in global memory is complete, kcol is complete, the staging scratch / tile sums are done with)
+    const double Srow = s_part[kBlock / 64];
+    __syncthreads();
+    PYNQS_STAMP(6);
+    rowout_draws<LEN, T>(smem + list_scratch_offset(p), drec, kcol, n, seg_base, p, L, wk, o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1), nsample, seed,
+                         walker, Srow, o, &bw_cnt, &bw_base, &s_full, s_part, s_parti);
+    PYNQS_STAMP(9);
+    return;
   }
   for (uint32_t i = n + tid; i < P; i += kBlock) list_key[i] = ~0ull;
   __syncthreads();
@@ -466,23 +530,6 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
     for (uint32_t i = flushed + tid; i < o.fixed; i += kBlock) o.rec_col[seg_base + i] = -1;
   }
   PYNQS_STAMP(5);
-  if constexpr (ROWOUT) {
-    // S: the tiles' exact sums in tile order (their own sums were formed lane by lane + butterfly: nothing depends on the waves' timing)
-    if (wave == 0) {
-      double sl = 0.0;
-      for (uint32_t i = lane; i < max_tiles; i += 64) sl += tsum[i];
-      sl = op_wave_sum(sl);
-      if (lane == 0) { s_part[kBlock / 64] = sl; if (o.row_sum) o.row_sum[walker] = sl; }
-    }
-    __syncthreads();  // (also: the row in global memory is complete, the staging scratch / tile sums / kept list are done with)
-    const double Srow = s_part[kBlock / 64];
-    __syncthreads();
-    PYNQS_STAMP(6);
-    rowout_draws<LEN, T>(smem + list_scratch_offset(p), p, L, wk, o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1), nsample, seed, walker, Srow, o, &bw_cnt,
-                         &bw_base, &s_full, s_part, s_parti);
-    PYNQS_STAMP(9);
-    return;
-  }
   if constexpr (SAMPLED) {
     const uint32_t ncomb = p.nsd + 1;
     const T *__restrict__ hrow = CACHED ? o.row_cache + (size_t)walker * ncomb : nullptr;

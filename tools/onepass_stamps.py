@@ -1,7 +1,7 @@
 """Per-workgroup phase timestamps of the semi-stochastic REDUCE front end: mean duration of every phase of a workgroup's life, 8192 Fe2S2
 walkers.  Needs a library whose kernels_reduce_onepass.hip was compiled with -DPYNQS_OP_STAMPS, e.g.
-  cd pynqs_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DPYNQS_OP_STAMPS -c kernels_reduce_onepass.hip -o /tmp/s.o &&
-  hipcc --offload-arch=gfx950 -fPIC -shared -o ../../build_ab/libpynqs_stamps.so $(ls build/*.o | grep -v kernels_reduce_onepass.o) /tmp/s.o
+  cd pynqs_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DPYNQS_OP_STAMPS -c kernels_reduce_rowout.hip -o /tmp/s.o &&
+  hipcc --offload-arch=gfx950 -fPIC -shared -o ../../build_ab/libpynqs_stamps.so $(ls build/*.o | grep -v kernels_reduce_rowout.o) /tmp/s.o
   PYNQS_AMD_LIB=$PWD/build_ab/libpynqs_stamps.so python tools/onepass_stamps.py"""
 import ctypes, os, sys
 import numpy as np, torch
@@ -21,8 +21,8 @@ lib = ctypes.CDLL(N.LIB_PATH)
 out = np.zeros((8192, 16), dtype=np.uint64)
 assert lib.pynqs_debug_stamps(out.ctypes.data_as(ctypes.c_void_p)) == 0
 t = out[:, :10].astype(np.float64)
-names = ["walker tables", "phase A (enumeration, row cache, kept list)", "record counts", "sort of the kept list (incl. barrier)", "kept records: kets, probes, rows, links",
-         "tile sums from the cached row", "tile-level draws, scans", "draws inside the tiles + emission", "drawn records: kets, probes, rows, links"]
+names = ["walker tables", "phase A (enumeration, float32 row, kept list)", "record counts", "sort of the kept list (incl. barrier)", "kept records: kets, probes, rows, links",
+         "S", "segment sums of the row read back, their scan", "draws located, hit counts by bitmap rank", "drawn records: kets, probes, rows, links"]
 dt = np.diff(t, axis=1) / 100.0  # wall_clock64: 100 MHz
 print("mean per workgroup (us):")
 for k, nm in enumerate(names):
