@@ -19,4 +19,4 @@ a.record()
 for i in range(50):
     fe.run(x, plan, eps, 3 + i, None)
 b.record(); b.synchronize()
-print(f"ROWLDS={os.environ.get('PYNQS_OP_ROWLDS', '-')} DEBUG={os.environ.get('PYNQS_OP_DEBUG', '0')} N={N}: {a.elapsed_time(b) / 50 * 1e3:.1f} us per {n} walkers, counters {fe.counters.tolist()}")
+print(f"DEBUG={os.environ.get('PYNQS_OP_DEBUG', '0')} N={N}: {a.elapsed_time(b) / 50 * 1e3:.1f} us per {n} walkers, counters {fe.counters.tolist()}")
