@@ -572,7 +572,9 @@ def reduce_front_launch(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: in
     caps = None
     if route and FRONT_NODEDUP:
         nk = _nodedup_key(x.device, n, sorb, nele, noa, nob, eps_sample, eps)
-        if nk in _FRONT_NODEDUP and slot == 0:
+        if _FRONT_NODEDUP.get(nk) is not None and slot == 0:
+            # (only the table-less state is revisited: being stuck WITH a table costs probes, being stuck without one costs an ansatz
+            # evaluation per duplicate; counting the records of a call is a read-back of its own)
             _FRONT_NODEDUP_CALLS[nk] = _FRONT_NODEDUP_CALLS.get(nk, 0) + 1
             if _FRONT_NODEDUP_CALLS[nk] >= FRONT_NODEDUP_RECHECK:   # measure again: this call runs with the table and counts
                 _FRONT_NODEDUP.pop(nk)
