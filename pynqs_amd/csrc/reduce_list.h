@@ -277,7 +277,11 @@ __host__ __device__ constexpr int list_quarter(bool sampled) { return sampled ? 
 // `cached` (row-cache form): the draws read the row back and never enumerate again, so the waves' draw areas share the memory of the
 // staging scratch of phase A (barriers lie between the two uses): 8 KB less per workgroup, 5 instead of 4 workgroups per CU for Fe2S2
 __host__ __device__ inline size_t list_scratch_offset(const SDParams &p) { return (lds_fixed_bytes(p) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, bool sampled, bool cached) {
+__host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, bool sampled, bool cached, bool rowout = false) {
+  if (rowout) {  // the draws' arrays (reduce_draw.h) lie over the staging scratch once the enumeration is over: at least that much (float32 integrals: 4 KB of scratch)
+    const size_t scratch = esz * (size_t)(list_quarter(sampled) * (kBlock / 64)), draw = draw_lds_bytes(0);
+    return (list_scratch_offset(p) + (scratch > draw ? scratch : draw) + 15) & ~(size_t)15;
+  }
   const size_t scratch = esz * (size_t)(list_quarter(sampled) * (kBlock / 64)), draw = (kBlock / 64) * kCachedDrawLdsPerWave;
   if (cached) return (list_scratch_offset(p) + (scratch > draw ? scratch : draw) + 15) & ~(size_t)15;
   return (lds_fixed_bytes(p) + scratch + 15) & ~(size_t)15;
@@ -291,7 +295,7 @@ __host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, b
 // sorb 120 are 57 KB, which with the draw areas and the list leaves ONE workgroup per CU
 __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample,
                                                    bool cached, bool gtile = false, bool rowout = false) {
-  size_t b = list_base_lds(p, esz, sampled, cached);
+  size_t b = list_base_lds(p, esz, sampled, cached, rowout);
   if (sampled) {
     if (!gtile) {
       b += (size_t)max_tiles * 8;
@@ -326,7 +330,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   const int64_t seg_base = (int64_t)slot * cap;
   if (tid == 0) { next_tile = 0; list_n = 0; bw_cnt = 0; s_done = 0; s_full = 0; }
   static_assert(!GTILE || (SAMPLED && !CACHED), "tile sums in global memory: the re-enumerating semi-stochastic form only");
-  unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED, CACHED);
+  unsigned char *extra = smem + list_base_lds(p, sizeof(T), SAMPLED, CACHED, ROWOUT);
   unsigned char *tile_mem = GTILE ? o.tile_scratch + (size_t)walker * o.tile_stride : extra;
   double *tsum = reinterpret_cast<double *>(tile_mem);
   uint32_t *dinfo = reinterpret_cast<uint32_t *>(tile_mem + (SAMPLED ? (size_t)max_tiles * 8 : 0));

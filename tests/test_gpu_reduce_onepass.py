@@ -215,6 +215,32 @@ def test_float32_integrals():
     assert not keep[walker[drawn], col[drawn].long()].any()
 
 
+@pytest.mark.parametrize("noA,noB,N", [(5, 7, 1025), (4, 4, 1000), (6, 2, 2500)])
+def test_float32_integrals_with_draws(noA, noB, N):
+    """float32 integrals through the round-4 kernel: the staging scratch of the enumeration is 4 KB then, less than the draws' arrays that
+    lie over it afterwards (a layout that only counted the scratch let them run into the tile sums and the kept list: tools/fuzz_draws.py
+    found drawn 'columns' that were the OR of two); also more than 1024 draws (the located columns wait in the draw slots' link words)."""
+    x, h1e, h2e, comb, hm = _setup(16, noA, noB, 18, seed=9, dtype=torch.float32)
+    eps = 0.45
+    fe, nu = _front(x, h1e, h2e, 16, noA, noB, eps, N, seed=3)
+    assert fe.row_f32 is not None
+    walker, col, w, link, onv, drawn = fe.records()
+    keep = hm.abs() >= eps
+    k = ~drawn
+    got = torch.zeros_like(keep)
+    got[walker[k], col[k].long()] = True
+    assert torch.equal(got, keep) and torch.equal(w[k], hm[walker[k], col[k].long()])
+    dc, dw = col[drawn].long(), walker[drawn]
+    assert int(dc.max()) < hm.size(1) and not keep[dw, dc].any() and torch.equal(onv[drawn], comb[dw, dc])
+    S = torch.where(keep, torch.zeros_like(hm), hm.abs()).double().sum(1)
+    hits = w[drawn].double().abs() * N / S[dw]
+    assert float((hits - hits.round()).abs().max()) < 2e-2
+    tot = torch.zeros(18, dtype=torch.float64, device=x.device).index_add_(0, dw, hits.round())
+    assert torch.equal(tot, torch.full_like(tot, float(N)))
+    flat = dw * hm.size(1) + dc
+    assert bool((flat[1:] > flat[:-1]).all())
+
+
 @pytest.mark.parametrize("N", [0, 300])
 def test_step_is_graph_capturable(N, fe2s2):
     """reduce_front.ReduceStep: front end -> module on ALL rows of the distinct list -> contraction with static shapes, nothing read back;
