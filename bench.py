@@ -1197,7 +1197,9 @@ def main():
                           "note": "the stored counters were measured on other native sources: re-run tools/pmc_roofline.py; counter-derived fields are omitted"}
             pmc = {}
         traffic = pmc.get("hbm_bytes_per_launch")
-        if traffic is not None and pmc.get("walkers"):
+        if traffic is not None and hasattr(w, "walkers_per_call"):
+            traffic = traffic * w.n / w.walkers_per_call   # (a step = several launches of the kernel, one per chunk of walkers: the counters are per launch)
+        elif traffic is not None and pmc.get("walkers"):
             traffic = traffic * w.n / pmc["walkers"]
         if hasattr(w, "flops_per_walker"):  # f64 vector-ALU bound kernel
             ach = w.flops_per_walker * w.n / t / 1e12
