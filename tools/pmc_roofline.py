@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--kernel", default=None, help="substring of the dominant kernel's name (default: the pynqs kernel with the largest total time)")
     ap.add_argument("--pmc-name", default=None, help="profiles/pmc_<this>.json (default: the workload's name)")
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--keep-raw", action="store_true", help="keep rocprofv3's CSVs under gpurun_out/pmc_<tag>/ (tens of MB per workload; gpurun copies at most 64 MiB back)")
     a, extra = ap.parse_known_args()
     tag = a.tag or f"r04_{a.workload}"
     out = os.path.join(ROOT, "gpurun_out", "pmc_" + tag)
@@ -56,12 +57,20 @@ def main():
         print(f"[pmc_roofline] {name}: rc {rc}", flush=True)
     # ---- summarise ----
     lines, stats = [], {}
+    # per-dispatch durations (the MEDIAN is what is quoted: a workload's first launches -- sizing calls with other buffer shapes, a call that still
+    # carries a de-duplication table -- are not the steady state, and a run has only a few dozen launches)
+    durs = defaultdict(list)
+    for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            durs[r["Kernel_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    med = lambda v: sorted(v)[len(v) // 2] if v else None  # noqa: E731
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             stats[r["Name"]] = dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=float(r["TotalDurationNs"]) if "TotalDurationNs" in r else float(r["AverageNs"]) * int(r["Calls"]))
     lines.append(f"== {tag}: rocprofv3 --kernel-trace --stats of `{' '.join(bench[1:])} --steps {a.steps} --warmup 5` ==")
     for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ns"])[:25]:
-        lines.append(f"{k[:120]:120s} calls={v['calls']:5d} avg_us={v['avg_ns'] / 1e3:10.2f} total_ms={v['total_ns'] / 1e6:9.3f}")
+        mk_ = max(durs, key=lambda q: len(os.path.commonprefix([q, k]))) if durs else None
+        lines.append(f"{k[:120]:120s} calls={v['calls']:5d} avg_us={v['avg_ns'] / 1e3:10.2f} median_us={(med(durs[mk_]) if mk_ else 0) / 1e3:10.2f} total_ms={v['total_ns'] / 1e6:9.3f}")
     pmc, meta = defaultdict(lambda: defaultdict(list)), {}
     for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -70,10 +79,10 @@ def main():
                 continue
             pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = {x: r.get(x) for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "SGPR_Count")}
-    lines += ["", "== rocprofv3 --pmc (separate passes), mean per dispatch =="]
+    lines += ["", "== rocprofv3 --pmc (separate passes), MEDIAN per dispatch =="]
     means = {}
     for k, d in pmc.items():
-        means[k] = {c: sum(v) / len(v) for c, v in d.items()}
+        means[k] = {c: med(v) for c, v in d.items()}   # (medians: see above)
         lines.append(k[:160])
         lines.append("   " + " ".join(f"{x}={y}" for x, y in meta[k].items()))
         for c, m in sorted(means[k].items()):
@@ -99,7 +108,9 @@ def main():
     hit, miss = m.get("TCC_HIT_sum"), m.get("TCC_MISS_sum")
     walkers = a.walkers or 8192
     js = {"source": f"profiles/{tag}.txt (tools/pmc_roofline.py --workload {a.workload}: rocprofv3 --kernel-trace --stats + separate --pmc passes of the tree with this sha256)",
-          "csrc_sha256": sha, "workload": a.workload, "walkers": walkers, "kernel": dom, "rocprof_kernel_avg_ns": stats[dom]["avg_ns"], "rocprof_kernel_calls": stats[dom]["calls"],
+          "csrc_sha256": sha, "workload": a.workload, "walkers": walkers, "kernel": dom,
+          "rocprof_kernel_avg_ns": (med(durs[max(durs, key=lambda k: len(os.path.commonprefix([k, dom])))]) if durs else None) or stats[dom]["avg_ns"],
+          "rocprof_kernel_mean_ns": stats[dom]["avg_ns"], "rocprof_kernel_calls": stats[dom]["calls"], "statistic": "median per dispatch (durations and counters)",
           "valu_insts_per_launch": m.get("SQ_INSTS_VALU"), "salu_insts_per_launch": m.get("SQ_INSTS_SALU"), "lds_insts_per_launch": m.get("SQ_INSTS_LDS"),
           "wave_cycles": m.get("SQ_WAVE_CYCLES"), "wait_any_cycles": m.get("SQ_WAIT_ANY"), "busy_cycles": m.get("SQ_BUSY_CYCLES"),
           "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
@@ -109,6 +120,10 @@ def main():
     name = a.pmc_name or a.workload
     json.dump(js, open(os.path.join(ROOT, "profiles", f"pmc_{name}.json"), "w"), indent=1)
     print(json.dumps(js, indent=1))
+    if not a.keep_raw:
+        import shutil
+
+        shutil.rmtree(out, ignore_errors=True)
     return 0
 
 
