@@ -659,8 +659,8 @@ class ReduceVmcStep(Workload):
             self.graphed.events = []
         self.phase_events = []
         self.stats = self.eloc = self.psi_x = None
-        self.roofline_note = ("one launch: enumeration of all columns (exact matrix elements; the sub-eps ones also as float32 through global memory), kept-column list "
-                              "sorted in LDS, the N draws located one lane per draw in segments of 16 columns (binary search + 64 bytes read back), hit counts by the rank of "
+        self.roofline_note = ("one launch: enumeration of all columns (exact matrix elements; the sub-eps ones also as float32 through global memory), kept columns "
+                              "placed by the rank of their bit in an LDS bitmap, the N draws located one lane per draw in segments of 16 columns (binary search + 64 bytes read back), hit counts by the rank of "
                               "a column's bit in an LDS bitmap, hash-table de-duplication (four 16-byte coherent probes per thread side by side), records with direct row "
                               "links, the distinct x' with their parent walkers.  The kernel is bound by its VECTOR INSTRUCTIONS: `achieved` = SQ_INSTS_VALU per launch / "
                               "live kernel time against the 2-cycle issue peak (`frac_of_4cycle_issue`: against the rate one wave sustains); `algorithmic_frac` is SURVEY "
