@@ -210,3 +210,28 @@ def test_rbm_forward_children_computes_strangers_from_scratch(sorb, no, H):
     keep[idx] = False
     assert torch.equal(got[keep], good[keep])                     # everybody else: untouched
     assert bool(((good - want).abs() <= 1e-11 * want.abs()).all())
+
+
+def test_integral_plan_is_reused_for_equal_content(fe2s2):
+    """The plan cache hits by tensor identity (and aliases) first, then by the integrals' CONTENT: a caller that re-creates equal integrals
+    on every call (`.to(device)` of a host array, a reloaded file) gets the cached plan back instead of a rebuild; changed content (in place, or
+    a fresh tensor) is a new plan."""
+    from pynqs_amd import C_extension as cx
+
+    dev = torch.device("cuda")
+    h1 = torch.from_numpy(fe2s2["h1e"]); h2 = torch.from_numpy(fe2s2["h2e"])
+    a1, a2 = h1.to(dev), h2.to(dev)
+    p0 = cx.plan_for(a1, a2, 40, dev)
+    assert cx.plan_for(a1, a2, 40, dev) is p0                          # identity
+    assert cx.plan_for(a1.view(-1), a2.detach(), 40, dev) is p0        # aliases of live tensors
+    b1, b2 = h1.to(dev), h2.to(dev)                                    # fresh copies, equal content
+    assert b2.data_ptr() != a2.data_ptr() and cx.plan_for(b1, b2, 40, dev) is p0
+    assert cx.plan_for(b1, b2, 40, dev) is p0                          # (and by identity from now on)
+    c2 = h2.to(dev) * (1.0 + 1e-9)
+    p1 = cx.plan_for(h1.to(dev), c2, 40, dev)
+    assert p1 is not p0 and not torch.equal(p1.buf, p0.buf)
+    b2[777] *= 2.0                                                     # in place: the version counter says so
+    p2 = cx.plan_for(b1, b2, 40, dev)
+    assert p2 is not p0 and p2 is not p1
+    f1, f2 = h1.float().to(dev), h2.float().to(dev)                    # another dtype is another plan
+    assert cx.plan_for(f1, f2, 40, dev) is not p0
