@@ -829,8 +829,9 @@ class ReduceVmcStep(Workload):
 
 
 class ReduceTotalEnergy(Workload):
-    """BASELINE configs[2] / configs[4] at their STATED sizes (sorb 120 with 8192 walkers, sorb 184 with 4096 = the shard of
-    32768 walkers over 8 GPUs; synthetic integrals -- no such system ships with the reference): deterministic REDUCE local energies
+    """BASELINE configs[1] / configs[2] / configs[4] at their STATED sizes (N2-sized sorb 56 with 4096 walkers and an RBM -- the
+    config's own ansatz family --, sorb 120 with 8192 walkers, sorb 184 with 4096 = the shard of 32768 walkers over 8 GPUs; synthetic
+    integrals -- no such system ships with the reference): deterministic REDUCE local energies
     through energy.total_energy exactly as a caller gets them -- fused-aware chunks of walkers (public_function.get_nbatch(fused=...)), the
     front end of chunk k + 1 on a second stream while the amplitudes of chunk k are formed (etot.py:24-169), the one-launch front end in its
     flushing LIST form, table-less once the x' prove distinct, RBM amplitudes of the distinct x' from their parent walkers, contraction.
@@ -951,7 +952,55 @@ class ReduceTotalEnergy(Workload):
         de = float(np.abs(self.eloc[:m].cpu().numpy() - want).max())
         return bool(de <= 1e-8), de
 
+    def _reference_baseline(self, budget_s):
+        """sorb <= 64: the reference's own CPU extension (oracle/_ref, MAX_SORB_LEN 1) running the reference's deterministic _reduce_psi
+        (get_comb_tensor -> get_hij_torch -> |H| >= eps -> unique -> onv_to_tensor + the module on the host -> scatter -> contraction, eloc.py:243-318)"""
+        ref_dir = os.path.join(ROOT, "oracle", "_ref")
+        if not (self.sorb <= 64 and os.path.exists(os.path.join(ref_dir, "C_extension.so"))):
+            return None
+        sys.path.insert(0, ref_dir)
+        import C_extension as ref  # noqa: the reference module
+
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        x, h1, h2 = self.x.cpu(), self.h1.cpu(), self.h2.cpu()
+        mod = type(self.module)(*(p.detach().cpu() for p in (self.module.weights, self.module.hidden_bias, self.module.visible_bias)))
+        sorb, nele, noA, noB, eps = self.sorb, self.nele, self.noA, self.noB, self.eps
+        old = torch.get_default_dtype()
+
+        def fn(m):
+            xs = x[:m].contiguous()
+            comb = ref.get_comb_tensor(xs, sorb, nele, noA, noB, False)[0]
+            ncomb, L8 = comb.size(1), comb.size(2)
+            hij = ref.get_hij_torch(xs, comb, h1, h2, sorb, nele)
+            sel = torch.where(hij.abs().flatten() >= eps)[0]
+            uniq, inv = torch.unique(comb.reshape(-1, L8)[sel], dim=0, return_inverse=True)
+            with torch.no_grad():
+                psi = mod(ref.onv_to_tensor(uniq, sorb))[inv]
+            full = torch.zeros(m * ncomb, dtype=psi.dtype)
+            full[sel] = psi
+            full = full.reshape(m, ncomb)
+            return ((full.T / full[:, 0]).T * hij).sum(-1)
+
+        try:
+            torch.set_default_dtype(torch.float64)
+            torch.set_num_threads(cores)
+            t0 = time.perf_counter(); fn(16); per = (time.perf_counter() - t0) / 16
+            sample = int(max(16, min(self.n, 512, budget_s * 0.4 / max(per, 1e-9))))
+            reps, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s * 0.8 and reps < 50:
+                e = fn(sample); reps += 1
+            el = time.perf_counter() - t0
+        finally:
+            torch.set_default_dtype(old)
+        de = float((e - self.eloc[:sample].cpu()).abs().max())
+        return {"value": sample * reps / el, "unit": "local energies/s", "cores": cores, "kind": "reference",
+                "sample": f"{reps} x (reference get_comb_tensor + get_hij_torch + |H| >= eps + unique + module on the host + contraction, eloc.py:243-318) on the "
+                          f"first {sample} walkers ({el:.1f} s)", "max_abs_diff_eloc_gpu_vs_reference_same_walkers": de}
+
     def cpu_baseline(self, budget_s=20.0):
+        r = self._reference_baseline(budget_s)
+        if r is not None:
+            return r
         cores = min(len(os.sched_getaffinity(0)), 16 if self.sorb < 150 else 8)  # (one thread per walker of a batch; 212 MB of output per walker at sorb 184)
         t0 = time.perf_counter(); self._oracle_eloc(cores, cores, cores); per = time.perf_counter() - t0
         sample = cores * int(max(1, min(self.n // cores, 8, budget_s * 0.8 / max(per, 1e-6))))
@@ -1321,7 +1370,7 @@ def main():
                                 ("syn120_eloc_sample_space", args.walkers, 10), ("syn120_eloc_rbm", 512, 10),
                                 ("syn184_eloc_sample_space", args.walkers, 10), ("syn184_eloc_rbm", 128, 3),
                                 # BASELINE configs[2] / configs[4] at their stated sizes: deterministic REDUCE through total_energy
-                                ("syn120_reduce_vmc_step", 8192, 5), ("syn184_reduce_vmc_step", 4096, 3)):
+                                ("syn56_reduce_vmc_step", 4096, 20), ("syn120_reduce_vmc_step", 8192, 5), ("syn184_reduce_vmc_step", 4096, 3)):
             try:
                 w2 = make_workload(name, nw, rank, dev, args.path)
                 el2, k2 = timed(w2, max(2, steps // 10), steps)
@@ -1336,7 +1385,7 @@ def main():
                 if isinstance(w2, ReduceTotalEnergy):
                     extra[w2.name]["roofline"]["kernel_only"] = w2.kernel_only()
                     extra[w2.name]["walkers_per_local_energy_call"] = w2.walkers_per_call
-                if name in ("fe2s2_dropin", "fe2s2_eloc_rbm", "fe2s2_vmc_step", "syn120_reduce_vmc_step", "syn184_reduce_vmc_step") and not args.no_cpu_baseline:
+                if name in ("fe2s2_dropin", "fe2s2_eloc_rbm", "fe2s2_vmc_step", "syn56_reduce_vmc_step", "syn120_reduce_vmc_step", "syn184_reduce_vmc_step") and not args.no_cpu_baseline:
                     extra[w2.name]["cpu_baseline"] = w2.cpu_baseline(budget_s=8.0)
                 del w2
                 torch.cuda.empty_cache()

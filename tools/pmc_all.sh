@@ -18,6 +18,7 @@ run syn120_dropin syn120_dropin 64
 run syn184_dropin syn184_dropin 16
 run syn120_eloc_sample_space syn120_eloc_sample_space_indexed 0
 run syn184_eloc_sample_space syn184_eloc_sample_space_indexed 0
+run syn56_reduce_vmc_step syn56_reduce_vmc_step 4096 --kernel reduce_onepass_list_flush_kernel
 run syn120_reduce_vmc_step syn120_reduce_vmc_step 0 --kernel reduce_onepass_list_flush_kernel
 run syn184_reduce_vmc_step syn184_reduce_vmc_step 4096 --kernel reduce_onepass_list_flush_kernel
 ls gpurun_out/profiles_out
