@@ -645,7 +645,7 @@ struct OnepassForm {
   size_t lds;
   bool use_split = false;  // LIST kernel with the row's float32 copy in global memory and the draws of reduce_draw.h (kernels_reduce_rowout.hip)
 };
-constexpr uint32_t kFlushList = 2048;  // list slots of the flushing form
+// (list slots of the flushing form: flush_list_slots(), reduce_list.h)
 static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tiles, uint32_t fixed, uint64_t cap_doubles, int eps_sample,
                                 bool have_cache, uint32_t chunk_len, bool no_table, bool have_tile_scratch = false, bool have_row_f32 = false) {
   static const int list_env = getenv("PYNQS_OP_LIST") ? atoi(getenv("PYNQS_OP_LIST")) : -1;
@@ -683,12 +683,13 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   // used by this form: when the LIST form with the cache does not fit, flushing without it beats the look-back form (sorb 56, 1000 draws:
   // 6.2 / 3.8 -> 2.6 / 1.9 ms).
   const bool gtile_f = sampled && have_tile_scratch;
-  const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, sampled, kFlushList, (uint32_t)eps_sample, false, gtile_f);
+  const uint32_t flush_P = flush_list_slots((p.sorb - 1) / 64 + 1, sampled);
+  const size_t lds_flush = onepass_list_lds(p, esz, max_tiles, sampled, flush_P, (uint32_t)eps_sample, false, gtile_f);
   const bool long_row = p.nsd + 1 > kLongRow;
   f.use_flush = !f.use_list && flush_env != 0 && lds_flush + 256 <= 160 * 1024 &&
                 (long_row || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len);
   if (f.use_flush) { f.use_gtile = gtile_f; f.use_cache = false; }
-  if (f.use_flush) { f.P = kFlushList; f.lds = lds_flush; }
+  if (f.use_flush) { f.P = flush_P; f.lds = lds_flush; }
   return f;
 }
 

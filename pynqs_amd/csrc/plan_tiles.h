@@ -117,11 +117,14 @@ struct sink_can_remap : std::false_type {};
 template <typename S>
 struct sink_can_remap<S, std::void_t<decltype(std::declval<S &>().remap(0u))>> : std::true_type {};
 
-template <int LEN, typename T, typename Sink, bool EXACT = true, int QUARTER = kDiagTile / 4>
+// UU: pair slots per lane and tile.  Everything that sizes buffers by the tile (the semi-stochastic forms' draw areas, the look-back buffers,
+// max_tiles_per_chunk) assumes PYNQS_U; a sink that keeps nothing per tile may ask for deeper tiles = more gathers in flight per lane.
+template <int LEN, typename T, typename Sink, bool EXACT = true, int QUARTER = kDiagTile / 4, int UU = PYNQS_U>
 __device__ __forceinline__ bool visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
                                             uint32_t chunk_len, uint32_t odd_base, uint32_t *next_tile, Sink &sink) {
-  constexpr int U = PYNQS_U;           // pair slots per lane and tile (2*U gathers in flight)
+  constexpr int U = UU;                // pair slots per lane and tile (2*U gathers in flight)
+  static_assert(UU >= PYNQS_U && UU % PYNQS_U == 0, "max_tiles_per_chunk (sized for PYNQS_U) must stay an upper bound");
   constexpr uint32_t kTile = 64u * U;  // pair slots per tile
   const int lane = threadIdx.x & 63;
   const uint32_t ncomb = p.nsd + 1;

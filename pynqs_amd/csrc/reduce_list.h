@@ -310,6 +310,19 @@ __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
 }
 
+// Tile depth of the flushing form.  Three-word determinants (sorb > 128) have 33 KB of walker tables: with the list and the staging scratch two
+// workgroups per CU = 2 waves per SIMD, each with 2 PYNQS_U gathers per lane in flight -- 9 MB in flight chip-wide, 4.7 TB/s at ~2 us of
+// latency.  The deterministic form keeps nothing per tile, so its tiles are twice as deep there (8 gathers per lane);
+// a wave in mid-tile may then hold 512 kept columns back, and the list has 4096 slots for the pause threshold to stay above half of it.
+#ifndef PYNQS_U_LONG
+#define PYNQS_U_LONG (3 * PYNQS_U)
+#endif
+__host__ __device__ constexpr int flush_tile_depth(int len, bool sampled, bool flush) { return (flush && !sampled && len >= 3) ? PYNQS_U_LONG : PYNQS_U; }
+__host__ __device__ constexpr uint32_t flush_list_slots(int len, bool sampled, bool flush = true) {
+  return flush_tile_depth(len, sampled, flush) > PYNQS_U ? 4096u : 2048u;
+}
+static_assert((kBlock / 64) * 128 * PYNQS_U_LONG + 64 < 4096 && (kBlock / 64) * 128 * PYNQS_U + 64 < 2048, "the pause threshold of the flushing form");
+
 template <int LEN, typename T, bool SAMPLED, bool CACHED, bool FLUSH = false, bool GTILE = false, bool ROWOUT = false>
 __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restrict__ bra, const SDParams &p, const PlanLayout &pl, uint32_t nchunks,
                                                          uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
@@ -372,9 +385,10 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
     ListKeepSink<LEN, T, SAMPLED, CACHED, FLUSH, ROWOUT> sink{eps, &list_n, list_key, o.rec_w + seg_base + flushed, room, tsum, 0xffffffffu, 0.0,
                                                               CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
     if constexpr (ROWOUT) { sink.frow = o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1); sink.kbm = kbm; }
-    if constexpr (FLUSH) sink.pause_at = P - (kBlock / 64) * kMaxKeptPerTile - 64;  // (every wave may be in the middle of a tile)
+    constexpr int kUU = flush_tile_depth(LEN, SAMPLED, FLUSH);
+    if constexpr (FLUSH) sink.pause_at = P - (kBlock / 64) * (kMaxKeptPerTile * kUU / PYNQS_U) - 64;  // (every wave may be in the middle of a tile)
     const bool exhausted =
-        visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED)>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
+        visit_tiles<LEN, T, decltype(sink), true, list_quarter(SAMPLED), kUU>(p, pl, L, nocc, plan, wk, nchunks, chunk, chunk_len, 0u, &next_tile, sink);
     sink.flush();
     if (FLUSH && exhausted && lane == 0) s_done = 1u;  // (a wave that found no tile left: every tile has been taken, and finished by the barrier)
   }
@@ -477,7 +491,7 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   // the values, from their order of arrival into the sorted order: every thread fetches its entries' values, then (barrier) stores them
   const int64_t out_base = seg_base + flushed;
   {
-    constexpr int kMaxPer = 8;  // n <= 2048 = 8 x 256
+    constexpr int kMaxPer = (int)(flush_list_slots(LEN, SAMPLED, FLUSH) / kBlock);  // n <= 2048 = 8 x 256 (three-word deterministic flushing form: 4096)
     T mine_w[kMaxPer];
 #pragma unroll
     for (int r = 0; r < kMaxPer; ++r) {

@@ -41,14 +41,16 @@ def main():
     ap.add_argument("--pmc-name", default=None, help="profiles/pmc_<this>.json (default: the workload's name)")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--keep-raw", action="store_true", help="keep rocprofv3's CSVs under gpurun_out/pmc_<tag>/ (tens of MB per workload; gpurun copies at most 64 MiB back)")
+    ap.add_argument("--passes", default=None, help="other counter passes instead of the default five, ';' between passes (e.g. 'SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE;SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS'): everything lands in profiles/<tag>.txt")
     a, extra = ap.parse_known_args()
+    passes = [c.strip() for c in a.passes.split(";") if c.strip()] if a.passes else PASSES
     tag = a.tag or f"r04_{a.workload}"
     out = os.path.join(ROOT, "gpurun_out", "pmc_" + tag)
     os.makedirs(out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--workload", a.workload] + (["--walkers", str(a.walkers)] if a.walkers else []) + extra
     runs = [("trace", ["--kernel-trace", "--stats"], ["--steps", str(a.steps), "--warmup", "5"])] + \
-           [("pmc%d" % i, ["--kernel-trace", "--pmc"] + c.split(), ["--steps", "3", "--warmup", "1"]) for i, c in enumerate(PASSES)]
+           [("pmc%d" % i, ["--kernel-trace", "--pmc"] + c.split(), ["--steps", "3", "--warmup", "1"]) for i, c in enumerate(passes)]
     for name, flags, steps in runs:
         d = os.path.join(out, name)
         cmd = ["rocprofv3"] + flags + ["--output-format", "csv", "-d", d, "--"] + bench + steps
