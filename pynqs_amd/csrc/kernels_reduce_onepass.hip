@@ -668,8 +668,11 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   // the list (PYNQS_OP_SPLIT=0 ignores the buffer)
   static const int split_env = getenv("PYNQS_OP_SPLIT") ? atoi(getenv("PYNQS_OP_SPLIT")) : -1;
   if (sampled && have_row_f32 && split_env != 0 && list_env != 0 && seg_cap <= 1024 && reduce_draw_supported(p, eps_sample)) {
-    const size_t lds_a = onepass_list_lds(p, esz, max_tiles, true, f.P, (uint32_t)eps_sample, false, false, true);
+    // (no sort in this form: the list needs as many slots as a segment has records, not a power of two)
+    const uint32_t slots = ((uint32_t)seg_cap + 1u) & ~1u;
+    const size_t lds_a = onepass_list_lds(p, esz, max_tiles, true, slots, (uint32_t)eps_sample, false, false, true);
     if (lds_a + 256 <= 160 * 1024) {
+      f.P = slots;
       f.use_list = true; f.use_split = true; f.use_cache = f.use_gtile = f.use_flush = false; f.lds = lds_a;
       return f;
     }

@@ -8,7 +8,9 @@ namespace pynqs {
 
 template <int LEN, typename T>
 // (at least six waves per SIMD, 80 VGPRs: the four records a thread resolves side by side want registers; measured 8 / 7 / 6 / 5 waves:
-// 610 / 583 / 572 / 588 us per 8192 Fe2S2 walkers)
+// 610 / 583 / 572 / 588 us per 8192 Fe2S2 walkers while 23 KB of LDS allowed six workgroups per CU whatever the registers; with 19.9 KB
+// (eight fit) 8 / 7 / 6: 667 / 613 / 598 us in one run -- more workgroups in flight are SLOWER: 7 x 32 rows of 31.5 KB per XCD fall out of
+// its 4 MiB L2 before the draws read them back)
 #ifndef PYNQS_ROWOUT_WAVES
 #define PYNQS_ROWOUT_WAVES 6
 #endif

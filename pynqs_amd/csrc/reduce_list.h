@@ -298,13 +298,18 @@ __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz
   size_t b = list_base_lds(p, esz, sampled, cached, rowout);
   if (sampled) {
     if (!gtile) {
-      b += (size_t)max_tiles * 8;
-      b += ((size_t)max_tiles * 4 + 15) & ~(size_t)15;
+      if (rowout) b += ((size_t)max_tiles * 8 + 15) & ~(size_t)15;  // (no draw counts per tile)
+      else b += (size_t)max_tiles * 8 + (((size_t)max_tiles * 4 + 15) & ~(size_t)15);
     }
     if (!cached && !rowout) b += (kBlock / 64) * kDrawLdsPerWave;
   }
-  if (rowout) {  // kept list | bitmap of the kept columns | the drawn records' slots; the draws' other arrays lie over the staging scratch (reduce_draw.h)
-    return b + (((size_t)P * 8 + 15) & ~(size_t)15) + (size_t)kBlock * 4 + (((size_t)nsample * 4 + 15) & ~(size_t)15);
+  if (rowout) {
+    // enumeration: kept list [P] u64 | bitmap of the kept columns [kBlock] u32; afterwards: the kept columns in slot order [P] u32 | the drawn
+    // records' slots [nsample] u32 (over the second half of the list and the bitmap, both done with by then); the draws' other arrays lie
+    // over the staging scratch (reduce_draw.h)
+    const size_t during = (((size_t)P * 8 + 15) & ~(size_t)15) + (size_t)kBlock * 4;
+    const size_t after = (((size_t)P * 4 + 15) & ~(size_t)15) + (((size_t)nsample * 4 + 15) & ~(size_t)15);
+    return b + (during > after ? during : after);
   }
   const size_t list = (size_t)P * 8, pend = (size_t)nsample * 4 * (gtile ? 2 : 1);  // (gtile: + the list of the drawn tiles)
   return b + ((list > pend ? list : pend) + 15 & ~(size_t)15);
@@ -347,7 +352,8 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   unsigned char *tile_mem = GTILE ? o.tile_scratch + (size_t)walker * o.tile_stride : extra;
   double *tsum = reinterpret_cast<double *>(tile_mem);
   uint32_t *dinfo = reinterpret_cast<uint32_t *>(tile_mem + (SAMPLED ? (size_t)max_tiles * 8 : 0));
-  unsigned char *after = (SAMPLED && !GTILE) ? reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15) : extra;
+  unsigned char *after = (SAMPLED && !GTILE) ? (ROWOUT ? extra + (((size_t)max_tiles * 8 + 15) & ~(size_t)15)
+                                                       : reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15)) : extra;
   unsigned char *draw0 = CACHED ? smem + list_scratch_offset(p) : after;  // (CACHED: over the staging scratch, see list_base_lds)
   static_assert(!ROWOUT || (SAMPLED && !CACHED && !FLUSH && !GTILE), "row to global memory as float32, the draws of reduce_draw.h");
   if (SAMPLED && !CACHED && !ROWOUT) after += (kBlock / 64) * kDrawLdsPerWave;
@@ -357,9 +363,13 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   unsigned long long *list_key = reinterpret_cast<unsigned long long *>(after);
   uint32_t *pend = reinterpret_cast<uint32_t *>(after);           // phase C re-uses the list's memory
   uint32_t *kbm = reinterpret_cast<uint32_t *>(after + (((size_t)P * 8 + 15) & ~(size_t)15));  // ROWOUT: [kBlock] words (rows of up to 8192 columns)
-  uint32_t *drec = kbm + kBlock;                                                                // ROWOUT: the drawn records' slots [nsample]
+  uint32_t *drec = reinterpret_cast<uint32_t *>(after + (((size_t)P * 4 + 15) & ~(size_t)15));  // ROWOUT: the drawn records' slots [nsample], behind kcol[P]:
+                                                                                                // over the list's second half and kbm, dead by then
   if constexpr (SAMPLED) {
-    for (uint32_t i = tid; i < max_tiles; i += kBlock) { tsum[i] = 0.0; dinfo[i] = 0u; }
+    for (uint32_t i = tid; i < max_tiles; i += kBlock) {
+      tsum[i] = 0.0;
+      if constexpr (!ROWOUT) dinfo[i] = 0u;
+    }
     if constexpr (!ROWOUT) {
       for (uint32_t i = tid; i < nsample; i += kBlock) o.srec_col[(int64_t)walker * nsample + i] = -1;
     } else {  // (the zeros behind the row's last column; the bitmap of the kept columns)
