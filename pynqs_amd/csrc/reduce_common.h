@@ -197,8 +197,8 @@ __device__ __forceinline__ bool assign_row(const OnepassOut<T> &o, uint32_t s, i
     __hip_atomic_store(reinterpret_cast<int32_t *>(o.dedup + (size_t)s * dedup_slot_words(LEN)) + dedup_row_offset(LEN), r, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-  for (int i = 0; i < LEN; ++i) o.uniq_onv[(size_t)r * LEN + i] = ket[i];
-  if (o.uniq_parent) o.uniq_parent[r] = o.parent;
+  for (int i = 0; i < LEN; ++i) __builtin_nontemporal_store(ket[i], o.uniq_onv + (size_t)r * LEN + i);  // (streaming: read by the next kernel only)
+  if (o.uniq_parent) __builtin_nontemporal_store(o.parent, o.uniq_parent + r);
   return true;
 }
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ void probe_k_oneword(const OnepassOut<T> &o, const ui
     if constexpr (K == 4) {
       // key and row of the four slots: four 16-byte loads at agent scope (what a relaxed atomic load compiles to, `sc1`, twice as wide: a
       // slot's words are each written atomically and only ever go from empty to their final value, so a torn view is a valid earlier one),
-      // in flight together; a lane without an open record reads the table's first slot
+      // in flight together; a lane without an open record reads the table's first slot.  (`nt` on these loads: 577 -> 732 us per launch.)
       typedef uint32_t u4 __attribute__((ext_vector_type(4)));
       u4 x0, x1, x2, x3;
       const uint64_t *a0 = o.dedup + (open[0] ? (size_t)s[0] * 2 : 0), *a1 = o.dedup + (open[1] ? (size_t)s[1] * 2 : 0),
@@ -167,7 +167,7 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, uint32_t *rec, 
     if (sgm < nseg) {
 #pragma unroll
       for (int q4 = 0; q4 < SEG / 4; ++q4) {
-        const f4 x = *reinterpret_cast<const f4 *>(w + (size_t)sgm * SEG + 4 * q4);
+        const f4 x = *reinterpret_cast<const f4 *>(w + (size_t)sgm * SEG + 4 * q4);  // (nontemporal loads here: 598 -> 718 us)
         a += (double)fabsf(x[0]); a += (double)fabsf(x[1]); a += (double)fabsf(x[2]); a += (double)fabsf(x[3]);
       }
     }
@@ -286,7 +286,8 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, uint32_t *rec, 
   // ---- ALL records of the walker, kept (slot order) and drawn (ascending columns, like the reference's unique), four per thread side by
   //      side: columns, weights, kets, probes, ONE allocation of rows for the new determinants, links ----
   constexpr int32_t kNoRecord = -0x7fffffff;
-  for (uint32_t i = nd + tid; i < nsample; i += NT) o.srec_col[sbase + i] = -1;  // (unused draw slots)
+  // (record stores are streaming stores: the next kernels read them, nothing in this one does, and the XCD's L2 is wanted for the plan and the rows)
+  for (uint32_t i = nd + tid; i < nsample; i += NT) __builtin_nontemporal_store((int32_t)-1, o.srec_col + sbase + i);  // (unused draw slots)
   const uint32_t nrec = nkept + nd;
   for (uint32_t i0 = 0; i0 < nrec; i0 += K * NT) {
     bool act[K], won[K];
@@ -311,9 +312,9 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, uint32_t *rec, 
         col = e & 0x7fffu;
         const int64_t at = sbase + (i - nkept);
         dst[k] = -1 - at;
-        o.srec_col[at] = (int32_t)col;
+        __builtin_nontemporal_store((int32_t)col, o.srec_col + at);
         const double val = scale * (double)(e >> 16);
-        o.srec_w[at] = (T)(((e >> 15) & 1u) ? -val : val);
+        __builtin_nontemporal_store((T)(((e >> 15) & 1u) ? -val : val), o.srec_w + at);
       }
       act[k] = true;
       if (col) {
@@ -324,7 +325,7 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, uint32_t *rec, 
       if (onv) {
         const int64_t g = dst[k] >= 0 ? dst[k] : -1 - dst[k];
 #pragma unroll
-        for (int ww = 0; ww < LEN; ++ww) onv[g * LEN + ww] = ket[k][ww];
+        for (int ww = 0; ww < LEN; ++ww) __builtin_nontemporal_store(ket[k][ww], onv + g * LEN + ww);
       }
     }
     bool fast = false;
@@ -347,7 +348,7 @@ __device__ __forceinline__ void rowout_draws(unsigned char *lds, uint32_t *rec, 
       if (lk[k] >= 0 && rows[k] < 0 && rowhint[k] >= 0 && (uint32_t)rowhint[k] < o.ucap) link = rowhint[k] | kDirectLink;
       else if (o.debug & 4096u) link = lk[k];  // (timing ablation: no second look at a slot whose row was not out yet)
       else link = final_link<LEN, T>(o, lk[k], rows[k]);
-      if (dst[k] >= 0) o.rec_link[dst[k]] = link; else o.srec_link[-1 - dst[k]] = link;
+      __builtin_nontemporal_store(link, dst[k] >= 0 ? o.rec_link + dst[k] : o.srec_link + (-1 - dst[k]));
     }
   }
 }

@@ -82,7 +82,8 @@ struct ListKeepSink {
   __device__ __forceinline__ void add(uint32_t col, T h) {
     const T a = fabs(h);
     if constexpr (CACHED) hrow[col] = h;
-    if constexpr (ROWOUT) frow[col] = a >= eps ? 0.0f : (float)h;
+    // (streaming stores: the row is read back once, 50 us later, and must not push the integral plan out of the XCD's L2 meanwhile: 598 -> 593 us)
+    if constexpr (ROWOUT) __builtin_nontemporal_store(a >= eps ? 0.0f : (float)h, frow + col);
     if (a >= eps) {
       const uint32_t k = atomicAdd(list_n, 1u);
       if (k < cap) {
@@ -110,7 +111,7 @@ struct ListKeepSink {
     if constexpr (ROWOUT) {
       if ((reinterpret_cast<uintptr_t>(frow + col) & 7u) == 0) {  // (neighbouring elements in one 8-byte store)
         typedef float f2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<f2 *>(frow + col) = f2{fabs(h0) >= eps ? 0.0f : (float)h0, fabs(h1) >= eps ? 0.0f : (float)h1};
+        __builtin_nontemporal_store(f2{fabs(h0) >= eps ? 0.0f : (float)h0, fabs(h1) >= eps ? 0.0f : (float)h1}, reinterpret_cast<f2 *>(frow + col));
         add_nocache(col, h0); add_nocache(col + 1, h1);
         return;
       }
@@ -454,8 +455,8 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
 #pragma unroll
     for (int r = 0; r < kMaxPer; ++r) {
       if (mine_r[r] < cap) {
-        o.rec_w[seg_base + mine_r[r]] = mine_w[r];
-        o.rec_col[seg_base + mine_r[r]] = (int32_t)mine_c[r];
+        __builtin_nontemporal_store(mine_w[r], o.rec_w + seg_base + mine_r[r]);
+        __builtin_nontemporal_store((int32_t)mine_c[r], o.rec_col + seg_base + mine_r[r]);
         kcol[mine_r[r]] = mine_c[r];
       }
     }
