@@ -395,7 +395,10 @@ int64_t pynqs_reduce_onepass_tile_scratch_bytes(int64_t nbatch, int sorb, int ne
 int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample,
                                        int with_row_cache, int without_table, int64_t *cap_doubles);
 /* 1 when a call with these arguments takes the round-4 semi-stochastic form if io->row_f32 is given (rows of up to 8192 columns, at most
- * 16383 draws, kept records within the list: Fe2S2), 0 when it would not (leave row_f32 NULL then), -1 on bad arguments;
+ * 16383 draws, kept records within the list: Fe2S2); 2 when it takes the flushing form (rows of any length, kept records beyond the list),
+ * whose draws then read the drawn tiles back from io->row_f32 instead of enumerating them a second time (4 bytes per column and walker:
+ * the caller decides whether that is affordable; io->tile_scratch is still wanted on long rows); 0 when the buffer would not be used
+ * (leave row_f32 NULL then), -1 on bad arguments;
  * ..._row_f32_elements: floats io->row_f32 must hold for nbatch walkers (-1 on bad arguments). */
 int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample, int64_t cap_doubles);
 int64_t pynqs_reduce_onepass_row_f32_elements(int64_t nbatch, int sorb, int nele, int noA, int noB);

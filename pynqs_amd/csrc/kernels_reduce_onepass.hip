@@ -644,6 +644,7 @@ struct OnepassForm {
   bool use_list, use_cache, use_flush, use_gtile;
   size_t lds;
   bool use_split = false;  // LIST kernel with the row's float32 copy in global memory and the draws of reduce_draw.h (kernels_reduce_rowout.hip)
+  bool use_row32 = false;  // flushing semi-stochastic form whose draws read the drawn tiles back from the row's float32 copy (same file)
 };
 // (list slots of the flushing form: flush_list_slots(), reduce_list.h)
 static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tiles, uint32_t fixed, uint64_t cap_doubles, int eps_sample,
@@ -693,6 +694,10 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
                 (long_row || flush_env == 1 || no_table || cap_doubles * 10 <= (uint64_t)chunk_len);
   if (f.use_flush) { f.use_gtile = gtile_f; f.use_cache = false; }
   if (f.use_flush) { f.P = flush_P; f.lds = lds_flush; }
+  // (PYNQS_OP_ROW32=0: the drawn tiles are enumerated a second time, as before the end of round 4)
+  static const int row32_env = getenv("PYNQS_OP_ROW32") ? atoi(getenv("PYNQS_OP_ROW32")) : -1;
+  f.use_row32 = f.use_flush && sampled && have_row_f32 && row32_env != 0 && row32_fits(esz, flush_P, (uint32_t)eps_sample, gtile_f);
+  if (f.use_row32) f.lds = onepass_list_lds(p, esz, max_tiles, true, flush_P, (uint32_t)eps_sample, false, gtile_f, false, true);
   return f;
 }
 
@@ -748,8 +753,12 @@ extern "C" int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int 
   if (eps_sample == 0) return 0;
   uint32_t nchunks, chunk_len, max_tiles, fixed;
   onepass_geometry(nbatch, p, true, &nchunks, &chunk_len, &max_tiles, &fixed);
-  const OnepassForm f = onepass_form(p, dtype == PYNQS_F64 ? 8 : 4, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, false, true);
-  return f.use_split ? 1 : 0;
+  const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
+  const OnepassForm f = onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, false, true);
+  if (f.use_split) return 1;
+  // the flushing form with draws (with or without io->tile_scratch: the caller decides that by the row's length)
+  const OnepassForm g = onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, true, true);
+  return (f.use_row32 || g.use_row32) ? 2 : 0;
 }
 
 extern "C" int64_t pynqs_reduce_onepass_row_f32_elements(int64_t nbatch, int sorb, int nele, int noA, int noB) {
@@ -798,7 +807,7 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
                                         io->dedup_table == nullptr, have_tiles, io->row_f32 != nullptr);
   const uint32_t P = form.P;
   const bool use_list = form.use_list || form.use_flush, use_cache = form.use_cache, use_flush = form.use_flush, use_gtile = form.use_gtile;
-  const bool use_split = form.use_split;
+  const bool use_split = form.use_split, use_row32 = form.use_row32;
   const size_t lds = form.lds;
   if (lds + onepass_static_lds(len) > 160 * 1024) return set_error(PYNQS_EINVAL, "row too long for the fused form (LDS): use the multi-pass entry points");
   if (!io->dedup_table && !use_list)
@@ -806,10 +815,11 @@ extern "C" int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sor
   static const bool verbose = getenv("PYNQS_OP_VERBOSE") != nullptr;
   if (verbose)
     fprintf(stderr, "pynqs_reduce_onepass: %s form%s, LDS %zu bytes per workgroup (walker tables %zu, max_tiles %u, list P %u), %u chunk(s) per walker\n",
-            use_split ? "LIST + float32 row copy + sorted draws" : use_flush ? "flushing LIST" : use_list ? (use_gtile ? "LIST (tile sums in global memory)" : "LIST") : "look-back", use_cache ? " with row cache" : "", lds, (size_t)lds_fixed_bytes(p), max_tiles, P, nchunks);
+            use_split ? "LIST + float32 row copy + sorted draws" : use_row32 ? (use_gtile ? "flushing LIST + float32 row copy (tile sums in global memory)" : "flushing LIST + float32 row copy") : use_flush ? "flushing LIST" : use_list ? (use_gtile ? "LIST (tile sums in global memory)" : "LIST") : "look-back", use_cache ? " with row cache" : "", lds, (size_t)lds_fixed_bytes(p), max_tiles, P, nchunks);
   // eloc.py:257-264: with draws and eps <= 0 nothing is kept (every column can be drawn); without draws |H| >= eps as it stands
   const double eps_eff = (sampled && !(eps > 0.0)) ? __builtin_inf() : eps;
   if (use_split) return launch_reduce_rowout(bra, nbatch, p, pl, chunk_len, max_tiles, plan, dtype, eps_eff, eps_sample, seed, P, lds, io, fixed, st);
+  if (use_row32) return launch_reduce_flush_row32(bra, nbatch, p, pl, chunk_len, max_tiles, plan, dtype, eps_eff, eps_sample, seed, P, lds, io, fixed, use_gtile, st);
 #define PYNQS_OP_LAUNCH(TT, SM)                                                                                                      \
   do {                                                                                                                               \
     auto kfn = use_flush ? (use_gtile ? reduce_onepass_list_flush_kernel<LEN, TT, SM, SM> : reduce_onepass_list_flush_kernel<LEN, TT, SM, false>) \

@@ -20,6 +20,35 @@ void reduce_onepass_list_rowout_kernel(const uint64_t *__restrict__ bra, SDParam
   reduce_onepass_list_body<LEN, T, true, false, false, false, true>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
 }
 
+// The flushing semi-stochastic form (rows of any length; the kept list is emptied whenever it is nearly full) with the row's float32 copy:
+// the draws inside the drawn tiles read their columns back instead of enumerating the tile again (reduce_list.h, ROW32).
+template <int LEN, typename T, bool GTILE>
+__global__ __launch_bounds__(kBlock) void reduce_onepass_list_flush_row32_kernel(const uint64_t *__restrict__ bra, SDParams p, PlanLayout pl, uint32_t nchunks,
+                                                                                uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
+                                                                                uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
+  reduce_onepass_list_body<LEN, T, true, false, true, GTILE, false, true>(bra, p, pl, nchunks, chunk_len, max_tiles, plan, eps, nsample, seed, P, o);
+}
+
+int launch_reduce_flush_row32(const uint64_t *bra, int64_t nbatch, const SDParams &p, const PlanLayout &pl, uint32_t chunk_len, uint32_t max_tiles,
+                              const void *plan, int dtype, double eps_eff, int eps_sample, uint64_t seed, uint32_t P, size_t lds,
+                              const pynqs_reduce_io *io, uint32_t fixed, bool gtile, hipStream_t st) {
+  if (!io->row_f32) return set_error(PYNQS_EINVAL, "io->row_f32 missing");
+  const int len = (p.sorb - 1) / 64 + 1;
+#define PYNQS_R32_LAUNCH(TT)                                                                                                             \
+  do {                                                                                                                                   \
+    auto kfn = gtile ? reduce_onepass_list_flush_row32_kernel<LEN, TT, true> : reduce_onepass_list_flush_row32_kernel<LEN, TT, false>;   \
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return check_launch("hipFuncSetAttribute");                                                                                       \
+    hipLaunchKernelGGL(kfn, dim3((uint32_t)nbatch), dim3(kBlock), lds, st, bra, p, pl, 1u, chunk_len, max_tiles, (const TT *)plan, (TT)eps_eff, \
+                       (uint32_t)eps_sample, seed, P, make_out<TT>(io, len, fixed, gtile ? max_tiles : 0u));                            \
+  } while (0)
+  DISPATCH_LEN(len, {
+    if (dtype == PYNQS_F64) PYNQS_R32_LAUNCH(double); else PYNQS_R32_LAUNCH(float);
+  });
+#undef PYNQS_R32_LAUNCH
+  return check_launch("reduce_onepass (semi-stochastic, flushing, float32 row copy)");
+}
+
 bool reduce_draw_supported(const SDParams &p, int eps_sample) {
   return eps_sample > 0 && (uint32_t)eps_sample <= kDrawMaxDraws && p.nsd + 1 <= kDrawMaxCols;
 }

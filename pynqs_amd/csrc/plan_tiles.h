@@ -87,12 +87,12 @@ __host__ __device__ inline uint32_t max_tiles_per_chunk(const SDParams &p, uint3
   return 1 + (tS_all + nchunks - 1) / nchunks + chunk_len / (128u * PYNQS_U) + 4;
 }
 
+constexpr int kSinglesPerFastTile = 64;
+
 // EXACT = true : <x|H|x> and the singles are summed in the reference's order (bit-identical values; needs the LDS
 //                staging scratch of lds_bytes(p, sizeof(T)), or 4 * QUARTER elements when QUARTER is given).
 // EXACT = false: order-free sums (plan_dev.h: fast_diag / fast_single), no scratch (lds_bytes(p, 0)), 64 singles per
 //                tile: for sinks that only accumulate a rounded sum over all columns (fused local energies).
-constexpr int kSinglesPerFastTile = 64;
-
 // optional member of a sink: bool skip_tile(uint32_t tile) (wave-uniform), asked after tile_begin -- true: none of
 // this tile's columns is wanted, do not even enumerate them (the draw pass of the semi-stochastic REDUCE: a tile that
 // received no draws)
@@ -119,6 +119,62 @@ struct sink_can_remap<S, std::void_t<decltype(std::declval<S &>().remap(0u))>> :
 
 // UU: pair slots per lane and tile.  Everything that sizes buffers by the tile (the semi-stochastic forms' draw areas, the look-back buffers,
 // max_tiles_per_chunk) assumes PYNQS_U; a sink that keeps nothing per tile may ask for deeper tiles = more gathers in flight per lane.
+// The tiles of one workgroup (one chunk of a walker's row), as visit_tiles numbers them: tile 0 (column 0 and the unpaired doubles), tS tiles
+// of singles, then tA / tB / tO tiles of same-spin alpha, same-spin beta and opposite-spin doubles.  columns(): the columns a tile covers -- a
+// contiguous range for every tile but tile 0 -- for code that comes back to a tile later (the draws of the semi-stochastic REDUCE from the
+// row's float32 copy).
+template <int LEN, bool EXACT = true, int UU = PYNQS_U>
+struct TileGeom {
+  static constexpr bool kPaired = LEN == 1;
+  static constexpr uint32_t kTile = 64u * UU;                       // pair slots per tile
+  static constexpr uint32_t kSlots = kPaired ? kTile : 2 * kTile;   // slots per tile: pair slots, or single ranks
+  static constexpr uint32_t kSPT = EXACT ? kSinglesPerTile : kSinglesPerFastTile;
+  ClassRange gA, gB, gO;
+  uint32_t tS, tA, tB, tO, ntiles, lo, d1, chunk, nchunks;
+  __device__ __forceinline__ TileGeom(const SDParams &p, uint32_t nchunks_, uint32_t chunk_, uint32_t chunk_len, uint32_t odd_base) {
+    const uint32_t ncomb = p.nsd + 1;
+    lo = chunk_ * chunk_len;
+    const uint32_t hi = min(lo + chunk_len, ncomb);
+    const uint32_t rlo = lo == 0 ? 0 : lo - 1, rhi = hi - 1;  // excitation ranks [rlo, rhi): column = rank + 1
+    gA = class_range<kPaired>(p.d1, p.d2, rlo, rhi, odd_base);
+    gB = class_range<kPaired>(p.d2, p.d3, rlo, rhi, odd_base);
+    gO = class_range<kPaired>(p.d3, p.nsd, rlo, rhi, odd_base);
+    tA = (gA.npairs + kSlots - 1) / kSlots; tB = (gB.npairs + kSlots - 1) / kSlots; tO = (gO.npairs + kSlots - 1) / kSlots;
+    // The singles tiles of the walker are dealt round-robin to its workgroups (they cost far more per column
+    // than doubles; left to the first chunk they would make it the straggler when rows are cut into many chunks).
+    const uint32_t tS_all = (p.d1 + kSPT - 1) / kSPT;
+    tS = tS_all > chunk_ ? (tS_all - chunk_ + nchunks_ - 1) / nchunks_ : 0;
+    ntiles = 1 + tS + tA + tB + tO;
+    d1 = p.d1; chunk = chunk_; nchunks = nchunks_;
+  }
+  // tile >= 1: first column and number of columns of the tile
+  __device__ __forceinline__ void columns(uint32_t tile, uint32_t &c0, uint32_t &n) const {
+    if (tile <= tS) {
+      const uint32_t r0 = (chunk + (tile - 1) * nchunks) * kSPT;
+      c0 = r0 + 1; n = min(r0 + kSPT, d1) - r0;
+      return;
+    }
+    tile -= 1 + tS;
+    const int k = tile < tA ? 0 : (tile < tA + tB ? 1 : 2);
+    const ClassRange &g = k == 0 ? gA : (k == 1 ? gB : gO);
+    const uint32_t first = (tile - (k == 0 ? 0u : (k == 1 ? tA : tA + tB))) * kSlots;
+    const uint32_t slots = min(kSlots, g.npairs - first);
+    if (kPaired) { c0 = g.r_e + 2 * first + 1; n = 2 * slots; }
+    else { c0 = g.r_e + first + 1; n = slots; }
+  }
+  // tile 0: its j-th column (j < 7), or 0xffffffff: column 0 when the chunk starts the row, then the unpaired heads / tails of the three classes
+  __device__ __forceinline__ uint32_t odd_column(int j) const {
+    if (j == 0) return lo == 0 ? 0u : 0xffffffffu;
+    if (!kPaired || j > 6) return 0xffffffffu;
+    const int k = (j - 1) >> 1;
+    const ClassRange &g = k == 0 ? gA : (k == 1 ? gB : gO);
+    const uint32_t tail = g.r_e + 2 * g.npairs;
+    const bool head = ((j - 1) & 1) == 0;
+    if (head ? (g.r_e > g.a0 && g.a0 < g.a1) : (tail < g.a1)) return (head ? g.a0 : tail) + 1;
+    return 0xffffffffu;
+  }
+};
+
 template <int LEN, typename T, typename Sink, bool EXACT = true, int QUARTER = kDiagTile / 4, int UU = PYNQS_U>
 __device__ __forceinline__ bool visit_tiles(const SDParams &p, const PlanLayout &pl, const LdsLayout &L, int nocc,
                                             const T *__restrict__ plan, const Walker<LEN> &wk, uint32_t nchunks, uint32_t chunk,
@@ -134,16 +190,11 @@ __device__ __forceinline__ bool visit_tiles(const SDParams &p, const PlanLayout 
 
   constexpr bool kPaired = LEN == 1;
   constexpr uint32_t kSlots = kPaired ? kTile : 2 * kTile;  // slots per tile: pair slots, or single ranks
-  const ClassRange gA = class_range<kPaired>(p.d1, p.d2, rlo, rhi, odd_base);
-  const ClassRange gB = class_range<kPaired>(p.d2, p.d3, rlo, rhi, odd_base);
-  const ClassRange gO = class_range<kPaired>(p.d3, p.nsd, rlo, rhi, odd_base);
-  const uint32_t tA = (gA.npairs + kSlots - 1) / kSlots, tB = (gB.npairs + kSlots - 1) / kSlots, tO = (gO.npairs + kSlots - 1) / kSlots;
-  // The singles tiles of the walker are dealt round-robin to its workgroups (they cost far more per column
-  // than doubles; left to the first chunk they would make it the straggler when rows are cut into many chunks).
+  const TileGeom<LEN, EXACT, UU> geom(p, nchunks, chunk, chunk_len, odd_base);
+  const ClassRange gA = geom.gA, gB = geom.gB, gO = geom.gO;
+  const uint32_t tA = geom.tA, tB = geom.tB, tS = geom.tS;
   constexpr uint32_t kSPT = EXACT ? kSinglesPerTile : kSinglesPerFastTile;
-  const uint32_t tS_all = (p.d1 + kSPT - 1) / kSPT;
-  const uint32_t tS = tS_all > chunk ? (tS_all - chunk + nchunks - 1) / nchunks : 0;
-  const uint32_t ntiles = 1 + tS + tA + tB + tO;
+  const uint32_t ntiles = geom.ntiles;
   const T *__restrict__ Vss = plan + pl.offVss;
   const T *__restrict__ Vab = plan + pl.offVab;
 

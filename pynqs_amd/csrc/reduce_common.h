@@ -422,5 +422,9 @@ bool reduce_draw_supported(const SDParams &p, int eps_sample);
 int launch_reduce_rowout(const uint64_t *bra, int64_t nbatch, const SDParams &p, const PlanLayout &pl, uint32_t chunk_len, uint32_t max_tiles,
                          const void *plan, int dtype, double eps_eff, int eps_sample, uint64_t seed, uint32_t P, size_t lds,
                          const pynqs_reduce_io *io, uint32_t fixed, hipStream_t st);
+// the flushing semi-stochastic form with the row's float32 copy (kernels_reduce_rowout.hip): as above, for rows of any length
+int launch_reduce_flush_row32(const uint64_t *bra, int64_t nbatch, const SDParams &p, const PlanLayout &pl, uint32_t chunk_len, uint32_t max_tiles,
+                              const void *plan, int dtype, double eps_eff, int eps_sample, uint64_t seed, uint32_t P, size_t lds,
+                              const pynqs_reduce_io *io, uint32_t fixed, bool gtile, hipStream_t st);
 
 }  // namespace pynqs

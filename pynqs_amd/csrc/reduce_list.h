@@ -60,7 +60,10 @@ constexpr size_t kCachedDrawLdsPerWave = (size_t)kOneTileCols * (8 + 2);
 // ROWOUT (round 4, the two-kernel semi-stochastic form): the enumeration leaves every sub-eps matrix element of the row as a float32 in
 // global memory (io->row_f32; kept columns: 0, they are never drawn) -- a quarter of round 3's row-cache traffic, written once and read
 // once by the draw kernel (kernels_reduce_draw.hip) -- and sums the exact |H| per tile in float64 as the re-enumerating form does.
-template <int LEN, typename T, bool SAMPLED, bool CACHED = false, bool FLUSH = false, bool ROWOUT = false>
+// ROW32 (end of round 4): the flushing semi-stochastic form on long rows leaves the float32 copy of the row too (no bitmap: the kept records
+// go through the list and its flushes as before) -- the draws inside the drawn tiles then read their <= 256 columns back instead of
+// enumerating the tile a second time.
+template <int LEN, typename T, bool SAMPLED, bool CACHED = false, bool FLUSH = false, bool ROWOUT = false, bool ROW32 = false>
 struct ListKeepSink {
   T eps;
   uint32_t *list_n;
@@ -83,7 +86,7 @@ struct ListKeepSink {
     const T a = fabs(h);
     if constexpr (CACHED) hrow[col] = h;
     // (streaming stores: the row is read back once, 50 us later, and must not push the integral plan out of the XCD's L2 meanwhile: 598 -> 593 us)
-    if constexpr (ROWOUT) __builtin_nontemporal_store(a >= eps ? 0.0f : (float)h, frow + col);
+    if constexpr (ROWOUT || ROW32) __builtin_nontemporal_store(a >= eps ? 0.0f : (float)h, frow + col);
     if (a >= eps) {
       const uint32_t k = atomicAdd(list_n, 1u);
       if (k < cap) {
@@ -108,7 +111,7 @@ struct ListKeepSink {
         return;
       }
     }
-    if constexpr (ROWOUT) {
+    if constexpr (ROWOUT || ROW32) {
       if ((reinterpret_cast<uintptr_t>(frow + col) & 7u) == 0) {  // (neighbouring elements in one 8-byte store)
         typedef float f2 __attribute__((ext_vector_type(2)));
         __builtin_nontemporal_store(f2{fabs(h0) >= eps ? 0.0f : (float)h0, fabs(h1) >= eps ? 0.0f : (float)h1}, reinterpret_cast<f2 *>(frow + col));
@@ -122,7 +125,7 @@ struct ListKeepSink {
     const T a = fabs(h);
     if (a >= eps) {
       const uint32_t k = atomicAdd(list_n, 1u);
-      if (k < cap) { list_key[k] = ((unsigned long long)col << 32) | k; rec_w[k] = h; }
+      if (k < cap) { list_key[k] = FLUSH ? (((unsigned long long)col << 32) | k | tag) : (((unsigned long long)col << 32) | k); rec_w[k] = h; }
       if constexpr (ROWOUT) atomicOr(&kbm[col >> 5], 1u << (col & 31u));
     } else if constexpr (SAMPLED && !CACHED) {
       sub += (double)a;
@@ -294,15 +297,32 @@ __host__ __device__ inline size_t list_base_lds(const SDParams &p, size_t esz, b
 
 // gtile: the tile sums and the tiles' draw counts live in global memory (io->tile_scratch) instead of the LDS -- long rows: 4768 tiles at
 // sorb 120 are 57 KB, which with the draw areas and the list leaves ONE workgroup per CU
+// row32 (the flushing form with the row's float32 copy): no draw areas of their own -- the waves' 2.5 KB (running sums and hit counts of one
+// tile) lie over the staging scratch and, for the waves that do not fit there, behind the draw slots' columns in the list's memory, both
+// done with when the draws begin (row32_draw_area; row32_fits: whether they do)
+__host__ __device__ inline size_t row32_scratch_bytes(size_t esz) { return esz * (size_t)(list_quarter(true) * (kBlock / 64)); }
+__host__ __device__ inline size_t row32_pend_bytes(uint32_t nsample, bool gtile) { return (((size_t)nsample * 4 * (gtile ? 2 : 1)) + 15) & ~(size_t)15; }
+__host__ __device__ inline bool row32_fits(size_t esz, uint32_t P, uint32_t nsample, bool gtile) {
+  const size_t in_scratch = row32_scratch_bytes(esz) / kCachedDrawLdsPerWave;
+  const size_t rest = in_scratch >= (size_t)(kBlock / 64) ? 0 : (size_t)(kBlock / 64) - in_scratch;
+  return row32_pend_bytes(nsample, gtile) + rest * kCachedDrawLdsPerWave <= (size_t)P * 8;
+}
+// offset of wave `wave`'s area from the start of the staging scratch (in_list = false) or of the list (in_list = true)
+__host__ __device__ inline size_t row32_draw_area(size_t esz, uint32_t nsample, bool gtile, int wave, bool &in_list) {
+  const size_t in_scratch = row32_scratch_bytes(esz) / kCachedDrawLdsPerWave;
+  in_list = (size_t)wave >= in_scratch;
+  return in_list ? row32_pend_bytes(nsample, gtile) + ((size_t)wave - in_scratch) * kCachedDrawLdsPerWave : (size_t)wave * kCachedDrawLdsPerWave;
+}
+
 __host__ __device__ inline size_t onepass_list_lds(const SDParams &p, size_t esz, uint32_t max_tiles, bool sampled, uint32_t P, uint32_t nsample,
-                                                   bool cached, bool gtile = false, bool rowout = false) {
+                                                   bool cached, bool gtile = false, bool rowout = false, bool row32 = false) {
   size_t b = list_base_lds(p, esz, sampled, cached, rowout);
   if (sampled) {
     if (!gtile) {
       if (rowout) b += ((size_t)max_tiles * 8 + 15) & ~(size_t)15;  // (no draw counts per tile)
       else b += (size_t)max_tiles * 8 + (((size_t)max_tiles * 4 + 15) & ~(size_t)15);
     }
-    if (!cached && !rowout) b += (kBlock / 64) * kDrawLdsPerWave;
+    if (!cached && !rowout && !row32) b += (kBlock / 64) * kDrawLdsPerWave;
   }
   if (rowout) {
     // enumeration: kept list [P] u64 | bitmap of the kept columns [kBlock] u32; afterwards: the kept columns in slot order [P] u32 | the drawn
@@ -329,7 +349,7 @@ __host__ __device__ constexpr uint32_t flush_list_slots(int len, bool sampled, b
 }
 static_assert((kBlock / 64) * 128 * PYNQS_U_LONG + 64 < 4096 && (kBlock / 64) * 128 * PYNQS_U + 64 < 2048, "the pause threshold of the flushing form");
 
-template <int LEN, typename T, bool SAMPLED, bool CACHED, bool FLUSH = false, bool GTILE = false, bool ROWOUT = false>
+template <int LEN, typename T, bool SAMPLED, bool CACHED, bool FLUSH = false, bool GTILE = false, bool ROWOUT = false, bool ROW32 = false>
 __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restrict__ bra, const SDParams &p, const PlanLayout &pl, uint32_t nchunks,
                                                          uint32_t chunk_len, uint32_t max_tiles, const T *__restrict__ plan, T eps,
                                                          uint32_t nsample, uint64_t seed, uint32_t P, OnepassOut<T> o) {
@@ -357,7 +377,8 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
                                                        : reinterpret_cast<unsigned char *>(dinfo) + (((size_t)max_tiles * 4 + 15) & ~(size_t)15)) : extra;
   unsigned char *draw0 = CACHED ? smem + list_scratch_offset(p) : after;  // (CACHED: over the staging scratch, see list_base_lds)
   static_assert(!ROWOUT || (SAMPLED && !CACHED && !FLUSH && !GTILE), "row to global memory as float32, the draws of reduce_draw.h");
-  if (SAMPLED && !CACHED && !ROWOUT) after += (kBlock / 64) * kDrawLdsPerWave;
+  static_assert(!ROW32 || (SAMPLED && !CACHED && FLUSH && !ROWOUT), "float32 copy of a long row: the flushing semi-stochastic form");
+  if (SAMPLED && !CACHED && !ROWOUT && !ROW32) after += (kBlock / 64) * kDrawLdsPerWave;
   // the kept list: ONE 64-bit key per entry (column << 32 | order of arrival); the values wait in the segment's rec_w, in order of arrival,
   // and are permuted after the sort (12 -> 8 bytes of LDS per entry: with the draw slots' 4000 bytes sharing the memory that is what
   // decides between 7 and 8 workgroups per CU)
@@ -393,9 +414,10 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
   for (;;) {
   const uint32_t room = FLUSH ? (cap > flushed ? min(cap - flushed, P) : 0u) : cap;
   {
-    ListKeepSink<LEN, T, SAMPLED, CACHED, FLUSH, ROWOUT> sink{eps, &list_n, list_key, o.rec_w + seg_base + flushed, room, tsum, 0xffffffffu, 0.0,
-                                                              CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
+    ListKeepSink<LEN, T, SAMPLED, CACHED, FLUSH, ROWOUT, ROW32> sink{eps, &list_n, list_key, o.rec_w + seg_base + flushed, room, tsum, 0xffffffffu, 0.0,
+                                                                     CACHED ? o.row_cache + (size_t)walker * (p.nsd + 1) : nullptr};
     if constexpr (ROWOUT) { sink.frow = o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1); sink.kbm = kbm; }
+    if constexpr (ROW32) sink.frow = o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1);
     constexpr int kUU = flush_tile_depth(LEN, SAMPLED, FLUSH);
     if constexpr (FLUSH) sink.pause_at = P - (kBlock / 64) * (kMaxKeptPerTile * kUU / PYNQS_U) - 64;  // (every wave may be in the middle of a tile)
     const bool exhausted =
@@ -661,6 +683,11 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
     PYNQS_STAMP(7);
     // ---- phase C: the draws inside the tiles ----
     unsigned char *mine = draw0 + (size_t)wave * (CACHED ? kCachedDrawLdsPerWave : kDrawLdsPerWave);
+    if constexpr (ROW32) {  // (over the staging scratch / behind the draw slots' columns in the list's memory: see row32_draw_area)
+      bool in_list;
+      const size_t off = row32_draw_area(sizeof(T), nsample, GTILE, wave, in_list);
+      mine = (in_list ? after : smem + list_scratch_offset(p)) + off;
+    }
     DrawLds S;
     S.prefix = reinterpret_cast<double *>(mine);
     S.run = reinterpret_cast<volatile double *>(mine + (size_t)kOneTileCols * 8);
@@ -741,6 +768,84 @@ __device__ __forceinline__ void reduce_onepass_list_body(const uint64_t *__restr
             const double v = scale * (double)hc[j];
             o.srec_w[sbase + at] = (T)(((neg >> j) & 1u) ? -v : v);
             pend[at] = col;
+            ++at;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if constexpr (ROW32) {
+      // the draws inside the drawn tiles from the float32 copy of the row (written by this workgroup; the barriers above make it visible):
+      // no second enumeration.  A wave pulls a drawn tile, loads its <= 256 columns (4 per lane; tile 0: its <= 7 scattered columns), forms
+      // the running sums of the float32 widths with one wave scan and draws / counts / emits as the row-cache form does.  P(column | tile) =
+      // w32 / sum of the tile's w32 (|H| rounded to float32, relative 6e-8); P(tile) and S stay the exact float64 sums of the enumeration.
+      const TileGeom<LEN, true, PYNQS_U> geom(p, nchunks, chunk, chunk_len, 0u);
+      const float *__restrict__ frow = o.row_f32 + (size_t)walker * draw_row_stride(p.nsd + 1);
+      const double scale = Srow / (double)nsample;
+      const int64_t sbase = (int64_t)walker * nsample;
+      uint32_t *hits2 = reinterpret_cast<uint32_t *>(mine + (size_t)kOneTileCols * 8);   // [cols / 2]: two 16-bit counts per word
+      for (;;) {
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(&next_tile, 1u);
+        q = __builtin_amdgcn_readfirstlane(q);
+        uint32_t t;
+        if constexpr (GTILE) { if (q >= ndrawn) break; t = tlist[q]; }
+        else { if (q >= geom.ntiles) break; t = q; }
+        const uint32_t info = dinfo[t], draws = info & 0xffffu;
+        if (draws == 0 || (o.debug & 64u)) continue;
+        uint32_t c0 = 0, ncols = 0;
+        if (t) geom.columns(t, c0, ncols);
+        float x4[4];
+        uint32_t cl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t e = (uint32_t)lane * 4 + j;
+          cl[j] = t ? (e < ncols ? c0 + e : 0xffffffffu) : geom.odd_column((int)e < 7 ? (int)e : 7);
+          x4[j] = cl[j] != 0xffffffffu ? frow[cl[j]] : 0.0f;
+        }
+        const double w4[4] = {(double)fabsf(x4[0]), (double)fabsf(x4[1]), (double)fabsf(x4[2]), (double)fabsf(x4[3])};
+        const double ls = (w4[0] + w4[1]) + (w4[2] + w4[3]);
+        const double incl = op_scan(ls, lane);
+        const double total = __shfl(incl, 63);
+        double run = incl - ls;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          run += w4[j];
+          S.prefix[lane * 4 + j] = run;
+        }
+        hits2[lane * 2] = 0u; hits2[lane * 2 + 1] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (!(total > 0.0)) continue;
+        for (uint32_t k = lane; k < draws; k += 64) {
+          const uint64_t r = op_mix64(key ^ op_mix64(((uint64_t)t << 32) | k));
+          const double target = (double)(r >> 11) * 0x1.0p-53 * total;
+          uint32_t lo = 0, hi = kOneTileCols;
+          while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (S.prefix[mid] > target) hi = mid; else lo = mid + 1;
+          }
+          if (lo >= (uint32_t)kOneTileCols) lo = kOneTileCols - 1;
+          while (lo > 0 && !(S.prefix[lo] > S.prefix[lo - 1])) --lo;   // (never a column of zero width: a kept one, or padding)
+          atomicAdd(&hits2[lo >> 1], 1u << (16u * (lo & 1u)));  // (a column is drawn < 2^16 times: nsample < 2^16)
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t h01 = hits2[lane * 2], h23 = hits2[lane * 2 + 1];
+        const uint32_t hc[4] = {h01 & 0xffffu, h01 >> 16, h23 & 0xffffu, h23 >> 16};
+        const uint32_t cnt4 = (hc[0] ? 1u : 0u) + (hc[1] ? 1u : 0u) + (hc[2] ? 1u : 0u) + (hc[3] ? 1u : 0u);
+        uint32_t before = cnt4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t ov = __shfl_up(before, d);
+          if (lane >= d) before += ov;
+        }
+        uint32_t at = (info >> 16) + before - cnt4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (hc[j]) {
+            o.srec_col[sbase + at] = (int32_t)cl[j];
+            const double v = scale * (double)hc[j];
+            o.srec_w[sbase + at] = (T)(x4[j] < 0.0f ? -v : v);
+            pend[at] = cl[j];
             ++at;
           }
         }

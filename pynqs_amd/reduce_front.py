@@ -25,6 +25,7 @@ OVERFLOW_DOUBLES, OVERFLOW_TABLE, OVERFLOW_UNIQUE = 1, 2, 4
 ROW_CACHE = True                  # semi-stochastic kernel: cache the row in global memory for the draws (see ReduceFrontEnd)
 ROW_CACHE_MAX_BYTES = 8 << 30
 ROW_F32 = __import__("os").environ.get("PYNQS_ROW_F32", "1") != "0"  # semi-stochastic calls on short rows: the two-kernel form (see ReduceFrontEnd)
+ROW_F32_MAX_BYTES = int(__import__("os").environ.get("PYNQS_ROW_F32_MAX_BYTES", str(16 << 30)))  # long rows: the float32 copy is 4 bytes per column and walker
 TILE_SCRATCH_MIN_ROW = int(__import__("os").environ.get("PYNQS_TILE_SCRATCH_MIN_ROW", "65536"))  # columns per row from which the tile sums leave the LDS
 
 
@@ -126,15 +127,21 @@ class ReduceFrontEnd:
         self.row_cache = None
         # the two-kernel semi-stochastic form (round 4; rows of up to 32768 columns): the enumerating kernel leaves the row's sub-eps elements as
         # float32 here, the draw kernel reads them once into registers; neither the float64 row cache nor the tile scratch is needed then
-        self.row_f32 = None
-        if self.eps_sample > 0 and ROW_F32 and N.lib().pynqs_reduce_onepass_wants_row_f32(
-                self.n, sorb, nele, noa, nob, N.PYNQS_F64 if esz == 8 else N.PYNQS_F32, self.eps_sample, self.cap_doubles) == 1:
-            self.row_f32 = torch.empty(max(int(N.lib().pynqs_reduce_onepass_row_f32_elements(self.n, sorb, nele, noa, nob)), 1), dtype=torch.float32, device=dev)
+        # (2: the flushing form -- rows of any length, kept columns beyond the LDS list -- whose draws read the drawn tiles back from the same
+        # float32 copy instead of enumerating them again; on long rows it still keeps its tile sums in the tile scratch)
+        self.row_f32, self.row_f32_form = None, 0
+        if self.eps_sample > 0 and ROW_F32:
+            self.row_f32_form = int(N.lib().pynqs_reduce_onepass_wants_row_f32(
+                self.n, sorb, nele, noa, nob, N.PYNQS_F64 if esz == 8 else N.PYNQS_F32, self.eps_sample, self.cap_doubles))
+            if self.row_f32_form in (1, 2):
+                nel = int(N.lib().pynqs_reduce_onepass_row_f32_elements(self.n, sorb, nele, noa, nob))
+                if self.row_f32_form == 1 or 4 * nel <= ROW_F32_MAX_BYTES:
+                    self.row_f32 = torch.empty(max(nel, 1), dtype=torch.float32, device=dev)
         if self.row_f32 is None and wants_row_cache(self.n, ncomb, self.eps_sample, self.nchunks, esz):
             self.row_cache = torch.empty(max(self.n * ncomb, 1), dtype=h_dtype, device=dev)
         # long rows with draws and no row cache: the tile sums / draw counts of the kernel in global memory instead of the LDS
         self.tile_scratch = None
-        if self.eps_sample > 0 and self.row_cache is None and self.row_f32 is None and ncomb > TILE_SCRATCH_MIN_ROW:
+        if self.eps_sample > 0 and self.row_cache is None and (self.row_f32 is None or self.row_f32_form == 2) and ncomb > TILE_SCRATCH_MIN_ROW:
             nb = int(N.lib().pynqs_reduce_onepass_tile_scratch_bytes(self.n, sorb, nele, noa, nob, self.eps_sample))
             if nb > 0:
                 self.tile_scratch = torch.empty(nb, dtype=torch.uint8, device=dev)

@@ -193,7 +193,9 @@ def test_semi_stochastic_flushing_form(sorb, no, n, eps, ns):
     long_row = E.get_Num_SinglesDoubles(sorb, no, no) + 1 > E.FRONT_LONG_ROW   # (sorb 56: a short row, sparse enough for the flushing form)
     assert RF.list_capacity(n, sorb, 2 * no, no, no, ns) == ((1 << 30) - 1 if long_row else 30976 // 10)
     fe, nu = E.reduce_front(x, h1, h2, sorb, 2 * no, no, no, eps, ns, seed=17, want_pm1=False)
-    assert fe.cap_doubles + fe.fixed > 2048 and (fe.tile_scratch is not None) == long_row   # (ns = 1000 at sorb 56: a row cache is allocated and not used)
+    assert fe.cap_doubles + fe.fixed > 2048 and (fe.tile_scratch is not None) == long_row
+    # (end of round 4: the draws read the drawn tiles back from the row's float32 copy instead of enumerating them again)
+    assert fe.row_f32 is not None and fe.row_f32_form == 2 and fe.row_cache is None
     assert fe.cap_doubles <= RF.list_capacity(n, sorb, 2 * no, no, no, ns)
     w, col, h, link, onv, drawn = fe.records()
     row, col2, onv2, h2_, counts = E.reduce_compact(x, h1, h2, sorb, 2 * no, no, no, eps, sort=True)
