@@ -208,7 +208,7 @@ def get_nbatch(sorb: int, n_sample: int, n_sd: int, Max_memory: float = 32, alph
       "sample_space", "simple_rbm"  outputs only (E_loc, psi(x), partner sum): everything in one call, up to a 2^22-walker cap;
       "reduce"                      records (fixed + kept + eps_sample slots of 20 + 8 len bytes) plus, per distinct x', the +-1 row,
                                     the determinant and two de-duplication slots (every record counted as distinct: an upper bound);
-                                    kept_estimate defaults to n_sd / 64.
+                                    with draws 4 bytes per column for the row's float32 copy; kept_estimate defaults to n_sd / 64.
     The ansatz' own activation memory is bounded separately by fp_batch, as in the reference."""
     if device is None:
         device = torch.device("cpu")
@@ -237,6 +237,8 @@ def get_nbatch(sorb: int, n_sample: int, n_sd: int, Max_memory: float = 32, alph
         kept = int(kept_estimate) if kept_estimate is not None else max(64, n_sd // 64)
         nrec = kept + int(eps_sample) + 64
         per = nrec * (20 + 8 * bra_len) + nrec * (8 * sorb + 8 * bra_len + 2 * 8 * (2 if bra_len == 1 else 4))
+        if eps_sample > 0:
+            per += 4 * (n_sd + 17)   # the row's float32 copy of the semi-stochastic forms (ReduceFrontEnd.row_f32)
         return max(1, min(n_sample, int(budget * alpha * (1 << 30) / per)))
     raise ValueError(f"fused = {fused!r}")
 
