@@ -1494,6 +1494,31 @@ def main():
                 del h1c, h2c, xc, res6, e6
                 E6._FRONTS.clear()
                 torch.cuda.empty_cache()
+            # BASELINE configs[2]'s size with the METHOD the Fe2S2 example runs (semi-stochastic REDUCE, 1000 draws): 8192 walkers at sorb 120 through
+            # total_energy (fused-aware chunks, look-ahead stream; the draws read the drawn tiles back from the row's float32 copy)
+            h1c, h2c = (t.to(dev) for t in synth_integrals(120))
+            xc = synth_walkers(8192, 120, 30, 30, 4321).to(dev)
+            g6 = torch.Generator().manual_seed(1)
+            m6 = RealRBM6(0.02 * (torch.rand(120, 120, generator=g6) - 0.5), 0.02 * (torch.rand(120, generator=g6) - 0.5), 0.05 * (torch.rand(120, generator=g6) - 0.5)).to(dev)
+            ab120 = lambda xx, func: pf6.ansatz_batch(func, xx, 1 << 22, 120, dev, torch.float64)  # noqa: E731
+            fin6 = torch.cat([torch.isfinite(E6.local_energy(xc[b:b + 1024].contiguous(), h1c, h2c, m6, ab120, 120, 60, 30, 30, reduce_psi=True, eps=0.4995)[0]) for b in range(0, 8192, 1024)])
+            xs6 = xc[fin6].contiguous()   # (walkers whose diagonal falls below eps are NaN, as in the reference: total_energy refuses them)
+            E6._FRONTS.clear()
+            fn = lambda: E6.total_energy(xs6, 0, -1, h1c, h2c, m6, 120, 60, 30, 30, reduce_psi=True, eps=0.4995, eps_sample=1000)[0]  # noqa: E731
+            fn(); fn(); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                e6 = fn()
+            torch.cuda.synchronize(dev)
+            el6 = (time.perf_counter() - t0) / 3
+            nb6 = E6.auto_nbatch(xs6, h1c, 120, 60, 30, 30, m6, None, torch.double, True, 1000, False, False, False, False)
+            extra["syn120_reduce_sample1000_total_energy_8192_walkers"] = {
+                "value": xs6.size(0) / el6, "unit": "local energies/s", "walkers": int(xs6.size(0)), "ncomb": 1190251, "eps": 0.4995, "eps_sample": 1000,
+                "ms_per_step": el6 * 1e3, "walkers_per_local_energy_call": int(nb6), "finite": int(torch.isfinite(e6).sum()),
+                "parity": "tests/test_gpu_reduce_route.py::test_semi_stochastic_flushing_form, ::test_long_row_forms_against_the_oracle[120-30-16-0.4995-200-True]"}
+            del h1c, h2c, xc, xs6, e6
+            E6._FRONTS.clear()
+            torch.cuda.empty_cache()
             torch.set_default_dtype(old_default6)
         except Exception as e:  # pragma: no cover
             extra["reduce_local_energy_large"] = {"error": repr(e)}
