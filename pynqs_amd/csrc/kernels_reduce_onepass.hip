@@ -742,7 +742,8 @@ extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int 
   return PYNQS_OK;
 }
 
-extern "C" int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample, int64_t cap_doubles) {
+extern "C" int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample, int64_t cap_doubles,
+                                                  int with_tile_scratch) {
   SDParams p;
   PlanLayout pl;
   if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl) || nbatch < 0 || nbatch > 0x7fffffffll || eps_sample < 0 ||
@@ -756,9 +757,9 @@ extern "C" int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int 
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
   const OnepassForm f = onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, false, true);
   if (f.use_split) return 1;
-  // the flushing form with draws (with or without io->tile_scratch: the caller decides that by the row's length)
-  const OnepassForm g = onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, true, true);
-  return (f.use_row32 || g.use_row32) ? 2 : 0;
+  // the flushing form with draws: with io->tile_scratch its draw slots need twice the room (the list of the drawn tiles)
+  const OnepassForm g = with_tile_scratch ? onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, true, true) : f;
+  return g.use_row32 ? 2 : 0;
 }
 
 extern "C" int64_t pynqs_reduce_onepass_row_f32_elements(int64_t nbatch, int sorb, int nele, int noA, int noB) {

@@ -182,7 +182,8 @@ def test_semi_stochastic_long_rows_leave_the_front_end_when_the_list_overflows(m
     assert int(torch.isfinite(e1).sum()) > n // 2
 
 
-@pytest.mark.parametrize("sorb,no,n,eps,ns", [(80, 20, 48, 0.47, 300), (136, 4, 40, 0.45, 100), (56, 7, 64, 0.47, 100), (56, 7, 64, 0.47, 1000)])
+@pytest.mark.parametrize("sorb,no,n,eps,ns", [(80, 20, 48, 0.47, 300), (136, 4, 40, 0.45, 100), (56, 7, 64, 0.47, 100), (56, 7, 64, 0.47, 1000),
+                                              (80, 20, 24, 0.47, 3000)])   # (3000 draws: more than fit behind the draw slots, the re-enumerating form)
 def test_semi_stochastic_flushing_form(sorb, no, n, eps, ns):
     """Long rows with draws and more kept columns than the list holds: the kept list is flushed during the enumeration, the draws follow.
     Kept records = the multi-pass kernels', bit for bit; every drawn record is a sub-eps column with weight (c / N) sign(H) S, S = the
@@ -195,7 +196,7 @@ def test_semi_stochastic_flushing_form(sorb, no, n, eps, ns):
     fe, nu = E.reduce_front(x, h1, h2, sorb, 2 * no, no, no, eps, ns, seed=17, want_pm1=False)
     assert fe.cap_doubles + fe.fixed > 2048 and (fe.tile_scratch is not None) == long_row
     # (end of round 4: the draws read the drawn tiles back from the row's float32 copy instead of enumerating them again)
-    assert fe.row_f32 is not None and fe.row_f32_form == 2 and fe.row_cache is None
+    assert (fe.row_f32 is not None) == (fe.row_f32_form == 2) and fe.row_cache is None and (fe.row_f32_form == 2) == (ns <= 1000)
     assert fe.cap_doubles <= RF.list_capacity(n, sorb, 2 * no, no, no, ns)
     w, col, h, link, onv, drawn = fe.records()
     row, col2, onv2, h2_, counts = E.reduce_compact(x, h1, h2, sorb, 2 * no, no, no, eps, sort=True)
