@@ -401,7 +401,8 @@ int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int nele, int n
  * (leave row_f32 NULL then), -1 on bad arguments;
  * ..._row_f32_elements: floats io->row_f32 must hold for nbatch walkers (-1 on bad arguments). */
 int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample, int64_t cap_doubles,
-                                       int with_tile_scratch /* whether the call will also pass io->tile_scratch */);
+                                       int with_tile_scratch /* whether the call will also pass io->tile_scratch */,
+                                       int without_table /* whether io->dedup_table will be NULL */);
 int64_t pynqs_reduce_onepass_row_f32_elements(int64_t nbatch, int sorb, int nele, int noA, int noB);
 int pynqs_reduce_onepass(const uint64_t *bra, int64_t nbatch, int sorb, int nele, int noA, int noB, const void *plan,
                          int dtype, double eps, int eps_sample, uint64_t seed, const pynqs_reduce_io *io, void *stream);

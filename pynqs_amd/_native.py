@@ -88,7 +88,7 @@ SIGNATURES.update({
     "pynqs_reduce_onepass_geometry": (_int, [_i64, _int, _int, _int, _int, _int, C.POINTER(_i64)]),
     "pynqs_reduce_onepass_tile_scratch_bytes": (_i64, [_i64, _int, _int, _int, _int, _int]),
     "pynqs_reduce_onepass_list_capacity": (_int, [_i64, _int, _int, _int, _int, _int, _int, _int, _int, C.POINTER(_i64)]),
-    "pynqs_reduce_onepass_wants_row_f32": (_int, [_i64, _int, _int, _int, _int, _int, _int, _i64, _int]),
+    "pynqs_reduce_onepass_wants_row_f32": (_int, [_i64, _int, _int, _int, _int, _int, _int, _i64, _int, _int]),
     "pynqs_reduce_onepass_row_f32_elements": (_i64, [_i64, _int, _int, _int, _int]),
     "pynqs_reduce_onepass": (_int, [_vp, _i64, _int, _int, _int, _int, _vp, _int, _dbl, _int, C.c_uint64, C.POINTER(ReduceIO), _vp]),
     "pynqs_rbm_forward": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _int, _int, _vp, _vp]),

@@ -696,8 +696,15 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   if (f.use_flush) { f.P = flush_P; f.lds = lds_flush; }
   // (PYNQS_OP_ROW32=0: the drawn tiles are enumerated a second time, as before the end of round 4)
   static const int row32_env = getenv("PYNQS_OP_ROW32") ? atoi(getenv("PYNQS_OP_ROW32")) : -1;
-  f.use_row32 = f.use_flush && sampled && have_row_f32 && row32_env != 0 && row32_fits(esz, flush_P, (uint32_t)eps_sample, gtile_f);
-  if (f.use_row32) f.lds = onepass_list_lds(p, esz, max_tiles, true, flush_P, (uint32_t)eps_sample, false, gtile_f, false, true);
+  // The copy costs 4 bytes of stores per column; it pays where it puts more workgroups on a CU (no draw areas of their own: sorb 120 four
+  // instead of two, 6.30 -> 4.79 ms per 1024 walkers) or where a good part of the tiles is drawn (sorb 56 / 80, 1000 draws: 1.81 -> 1.34 /
+  // 3.41 -> 2.54 ms); at sorb 184 (26146 tiles, two workgroups per CU either way) 1000 draws re-enumerate 4 % of the row and the copy is
+  // the dearer of the two (13.1 -> 13.9 ms per 512 walkers): not used there.  PYNQS_OP_ROW32=1: wherever it fits.
+  if (f.use_flush && sampled && have_row_f32 && row32_env != 0 && row32_fits(esz, flush_P, (uint32_t)eps_sample, gtile_f)) {
+    const size_t lds_r = onepass_list_lds(p, esz, max_tiles, true, flush_P, (uint32_t)eps_sample, false, gtile_f, false, true);
+    const size_t wg_old = (size_t)160 * 1024 / (lds_flush + 512), wg_new = (size_t)160 * 1024 / (lds_r + 512);
+    if (row32_env == 1 || wg_new > wg_old || (uint64_t)eps_sample * 8 >= max_tiles) { f.use_row32 = true; f.lds = lds_r; }
+  }
   return f;
 }
 
@@ -743,7 +750,7 @@ extern "C" int pynqs_reduce_onepass_list_capacity(int64_t nbatch, int sorb, int 
 }
 
 extern "C" int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int nele, int noA, int noB, int dtype, int eps_sample, int64_t cap_doubles,
-                                                  int with_tile_scratch) {
+                                                  int with_tile_scratch, int without_table) {
   SDParams p;
   PlanLayout pl;
   if (!make_sd_params(sorb, nele, noA, noB, &p) || !make_plan_layout(sorb, &pl) || nbatch < 0 || nbatch > 0x7fffffffll || eps_sample < 0 ||
@@ -755,10 +762,10 @@ extern "C" int pynqs_reduce_onepass_wants_row_f32(int64_t nbatch, int sorb, int 
   uint32_t nchunks, chunk_len, max_tiles, fixed;
   onepass_geometry(nbatch, p, true, &nchunks, &chunk_len, &max_tiles, &fixed);
   const size_t esz = dtype == PYNQS_F64 ? 8 : 4;
-  const OnepassForm f = onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, false, true);
+  const OnepassForm f = onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, without_table != 0, false, true);
   if (f.use_split) return 1;
   // the flushing form with draws: with io->tile_scratch its draw slots need twice the room (the list of the drawn tiles)
-  const OnepassForm g = with_tile_scratch ? onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, false, true, true) : f;
+  const OnepassForm g = with_tile_scratch ? onepass_form(p, esz, max_tiles, fixed, (uint64_t)cap_doubles, eps_sample, false, chunk_len, without_table != 0, true, true) : f;
   return g.use_row32 ? 2 : 0;
 }
 

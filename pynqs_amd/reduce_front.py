@@ -133,7 +133,7 @@ class ReduceFrontEnd:
         if self.eps_sample > 0 and ROW_F32:
             self.row_f32_form = int(N.lib().pynqs_reduce_onepass_wants_row_f32(
                 self.n, sorb, nele, noa, nob, N.PYNQS_F64 if esz == 8 else N.PYNQS_F32, self.eps_sample, self.cap_doubles,
-                int(ncomb > TILE_SCRATCH_MIN_ROW)))
+                int(ncomb > TILE_SCRATCH_MIN_ROW), int(not self.dedup)))
             if self.row_f32_form in (1, 2):
                 nel = int(N.lib().pynqs_reduce_onepass_row_f32_elements(self.n, sorb, nele, noa, nob))
                 if self.row_f32_form == 1 or 4 * nel <= ROW_F32_MAX_BYTES:
