@@ -700,10 +700,15 @@ static OnepassForm onepass_form(const SDParams &p, size_t esz, uint32_t max_tile
   // instead of two, 6.30 -> 4.79 ms per 1024 walkers) or where a good part of the tiles is drawn (sorb 56 / 80, 1000 draws: 1.81 -> 1.34 /
   // 3.41 -> 2.54 ms); at sorb 184 (26146 tiles, two workgroups per CU either way) 1000 draws re-enumerate 4 % of the row and the copy is
   // the dearer of the two (13.1 -> 13.9 ms per 512 walkers): not used there.  PYNQS_OP_ROW32=1: wherever it fits.
-  if (f.use_flush && sampled && have_row_f32 && row32_env != 0 && row32_fits(esz, flush_P, (uint32_t)eps_sample, gtile_f)) {
+  // The LIST form that enumerates the drawn tiles again (kept records within the list, no row cache) gives way to the same kernel under
+  // the same rule: a list that never fills is never flushed.
+  const bool from_list = f.use_list && !f.use_cache && flush_env != 0;
+  if ((f.use_flush || from_list) && sampled && have_row_f32 && row32_env != 0 && row32_fits(esz, flush_P, (uint32_t)eps_sample, gtile_f)) {
     const size_t lds_r = onepass_list_lds(p, esz, max_tiles, true, flush_P, (uint32_t)eps_sample, false, gtile_f, false, true);
-    const size_t wg_old = (size_t)160 * 1024 / (lds_flush + 512), wg_new = (size_t)160 * 1024 / (lds_r + 512);
-    if (row32_env == 1 || wg_new > wg_old || (uint64_t)eps_sample * 8 >= max_tiles) { f.use_row32 = true; f.lds = lds_r; }
+    const size_t wg_old = (size_t)160 * 1024 / ((f.use_flush ? lds_flush : f.lds) + 512), wg_new = (size_t)160 * 1024 / (lds_r + 512);
+    if (lds_r + 256 <= 160 * 1024 && (row32_env == 1 || wg_new > wg_old || (uint64_t)eps_sample * 8 >= max_tiles)) {
+      f.use_row32 = true; f.use_flush = true; f.use_list = false; f.use_cache = false; f.use_gtile = gtile_f; f.P = flush_P; f.lds = lds_r;
+    }
   }
   return f;
 }
