@@ -68,7 +68,7 @@ while time.time() - t0 < budget:
     fe.run(x, plan, eps, seed, None)
     nu, flags, _ = fe.counters_host()
     assert flags == 0, (sorb, noA, noB, n, eps, ns, flags)
-    forms += fe.row_f32 is not None
+    forms += fe.row_f32_form == 1
     walker, col, w, link, onv, drawn = fe.records()
     wk, cl, ww, dr, ov = walker.cpu(), col.cpu().long(), w.cpu(), drawn.cpu(), onv.cpu()
     tag = f"sorb {sorb} {noA}a{noB}b n {n} eps {eps} N {ns} f32 {f32} dedup {dedup} seed {seed}"
@@ -92,8 +92,9 @@ while time.time() - t0 < budget:
     dw, dc, dh = wk[dr], cl[dr], ww[dr].double()
     assert not bool(keep[dw, dc].any()) and bool((ho[dw, dc] != 0).all()), "drawn columns: " + tag
     flat = dw * ho.shape[1] + dc
-    # (ascending columns: the round-4 kernel's order; the older forms -- taken when the kept records outgrow 1024 slots -- emit tile by tile)
-    if not (flat.unique().numel() == flat.numel() and (fe.row_f32 is None or bool((flat[1:] > flat[:-1]).all()))):
+    # (ascending columns: the round-4 kernel's order; the other forms -- taken when the kept records outgrow 1024 slots: the flushing form with
+    # or without the row's float32 copy, row_f32_form 2 / 0 -- emit tile by tile)
+    if not (flat.unique().numel() == flat.numel() and (fe.row_f32_form != 1 or bool((flat[1:] > flat[:-1]).all()))):
         badi = int((flat[1:] <= flat[:-1]).nonzero()[0])
         print("drawn order:", tag, "ncomb", ho.shape[1], "unique", flat.unique().numel(), "of", flat.numel(), "at", badi, "walkers", dw[badi - 2: badi + 4].tolist(),
               "cols", dc[badi - 2: badi + 4].tolist(), "w", dh[badi - 2: badi + 4].tolist())
@@ -114,4 +115,4 @@ while time.time() - t0 < budget:
     used = rec[0] >= 0
     assert torch.equal(rec[0], fe.srec_col) and torch.equal(rec[1][used], fe.srec_w[used]) and torch.equal(rec[2], fe.rec_col), "same seed, same records: " + tag
     cases += 1
-print(f"fuzz_draws ok: {cases} systems in {time.time() - t0:.0f} s ({forms} through the round-4 kernel)")
+print(f"fuzz_draws ok: {cases} systems in {time.time() - t0:.0f} s ({forms} through the round-4 kernel for short rows)")
