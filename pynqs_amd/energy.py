@@ -644,7 +644,7 @@ def reset_caches() -> None:
     """Drop every process-wide cache of this module: front-end workspaces, the table / no-table and front-end / multi-pass decisions,
     timed kernel choices.  (Results never depend on them; which FORM of a kernel a call takes does.)"""
     with _LOCK:
-        _FRONTS.clear(); _FRONT_NODEDUP.clear(); _FRONT_NODEDUP_CALLS.clear(); _FRONT_DENSE.clear(); _SS_CHOICE.clear()
+        _FRONTS.clear(); _FRONT_NODEDUP.clear(); _FRONT_NODEDUP_CALLS.clear(); _FRONT_DENSE.clear(); _SS_CHOICE.clear(); _AUTO_NBATCH.clear()
 
 
 def reduce_front(x: Tensor, h1e: Tensor, h2e: Tensor, sorb: int, nele: int, noa: int, nob: int, eps: float, eps_sample: int = 0,
@@ -998,6 +998,10 @@ def local_energy(
         return eloc.to(dtype), sloc.to(dtype), psi_x1[..., 0].to(dtype), ((t1 - t0) / 1e6, (t2 - t1) / 1e6, (t3 - t2) / 1e6)
 
 
+AUTO_NBATCH_KEEP = 64   # calls of one shape served from the last answer before the device memory is looked at again
+_AUTO_NBATCH: dict = {}
+
+
 def auto_nbatch(x, h1e, sorb, nele, noa, nob, ansatz, WF_LUT, dtype, reduce_psi, eps_sample, use_sample_space, use_multi_psi, use_spin_flip,
                 use_spin_raising, max_memory: float = 64.0, alpha: float = 0.25) -> int:
     """Walkers per local_energy call for the path local_energy will take on these arguments (same conditions as there)."""
@@ -1012,8 +1016,23 @@ def auto_nbatch(x, h1e, sorb, nele, noa, nob, ansatz, WF_LUT, dtype, reduce_psi,
         elif (not reduce_psi and not use_sample_space and FUSED_RBM and WF_LUT is None and not (use_multi_psi or use_spin_flip)
               and (_real_rbm_params(ansatz) is not None or _complex_rbm_params(ansatz) is not None)):
             fused = "simple_rbm"
-    return max(1, get_nbatch(sorb, max(n, 1), n_sd, max_memory, alpha, x.device, use_sample_space, dtype if dtype in (torch.double, torch.complex128) else torch.double,
-                             fused=fused, eps_sample=int(eps_sample)))
+    dt = dtype if dtype in (torch.double, torch.complex128) else torch.double
+    if fused is None:
+        return max(1, get_nbatch(sorb, max(n, 1), n_sd, max_memory, alpha, x.device, use_sample_space, dt, fused=None, eps_sample=int(eps_sample)))
+    # the fused paths ask once per total_energy call, i.e. once per VMC step: the answer (a function of the free device memory) is kept for
+    # AUTO_NBATCH_KEEP calls of the same shape -- the allocator statistics behind it cost 0.2 ms, 15 % of a configs[1]-sized step
+    key = (str(x.device), sorb, n, n_sd, fused, int(eps_sample), dt, float(max_memory), float(alpha))
+    with _LOCK:
+        hit = _AUTO_NBATCH.get(key)
+        if hit is not None and hit[1] < AUTO_NBATCH_KEEP:
+            hit[1] += 1
+            return hit[0]
+    nb = max(1, get_nbatch(sorb, max(n, 1), n_sd, max_memory, alpha, x.device, use_sample_space, dt, fused=fused, eps_sample=int(eps_sample)))
+    with _LOCK:
+        _AUTO_NBATCH[key] = [nb, 0]
+        while len(_AUTO_NBATCH) > 64:
+            _AUTO_NBATCH.pop(next(iter(_AUTO_NBATCH)))
+    return nb
 
 
 def total_energy(

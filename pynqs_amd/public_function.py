@@ -213,9 +213,14 @@ def get_nbatch(sorb: int, n_sample: int, n_sd: int, Max_memory: float = 32, alph
     if device is None:
         device = torch.device("cpu")
     budget = float(Max_memory)
-    if device.type != "cpu":
+    if device.type != "cpu" and fused is None:
         torch.cuda.empty_cache()
         budget = min(torch.cuda.mem_get_info(device)[0] / (1 << 30), budget)
+    elif device.type != "cpu":
+        # (the fused paths ask once per total_energy call: emptying the allocator's cache there costs 0.26 ms per call and sends the call's
+        # own buffers back to hipMalloc -- 17 % of a configs[1]-sized step; what the cache holds unused counts as free instead)
+        cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        budget = min((torch.cuda.mem_get_info(device)[0] + max(cached, 0)) / (1 << 30), budget)
     if fused is None:
         if not use_sample:
             per = n_sd * sorb * 8 / (1 << 30) * 2
