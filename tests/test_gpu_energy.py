@@ -494,3 +494,35 @@ def test_float32_inputs_take_the_fused_kernels(env, monkeypatch):
     assert e.dtype == torch.float32
     np.testing.assert_allclose(e.cpu().numpy(), d["eloc_simple"], rtol=2e-5, atol=2e-4)
     np.testing.assert_allclose(p0.cpu().numpy(), d["psi_simple"], rtol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eps_sample", [0, 150])
+def test_rbm_amplitudes_enqueued_before_the_counters_are_read(env, eps_sample, monkeypatch):
+    """local_energy (REDUCE) with an RBM of the reference's family: amplitude kernel and contraction enqueued behind the front end before
+    its counters are waited for (energy._rbm_ahead) -- the same numbers as the wait-then-launch order (1e-10 Ha), also on the first call of
+    a shape (whose buffers overflow and are regrown: the speculative result is dropped) and inside total_energy's look-ahead."""
+    energy = env["energy"]
+    kw = dict(reduce_psi=True, eps=1e-2, eps_sample=eps_sample)
+    out = {}
+    for spec in (False, True):
+        monkeypatch.setattr(energy, "SPECULATE_RBM", spec)
+        energy.reset_caches()
+        calls = {"n": 0}
+        ahead = energy._rbm_ahead
+        monkeypatch.setattr(energy, "_rbm_ahead", lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), ahead(*a, **k))[1])
+        res = []
+        for _ in range(3):   # (first call: sizing / overflow; later calls: the cached workspace)
+            torch.manual_seed(11)
+            res.append(_le(env, **kw)[0])
+        torch.manual_seed(11)
+        res.append(energy.total_energy(env["x"], 17, -1, env["h1e"], env["h2e"], env["rbm"], 40, 30, 15, 15, reduce_psi=True, eps=1e-2, eps_sample=eps_sample)[0])
+        monkeypatch.setattr(energy, "_rbm_ahead", ahead)
+        assert (calls["n"] > 0) == spec
+        out[spec] = res
+    # (not bit for bit: which walker becomes the PARENT of a distinct x' -- the first to insert it -- depends on the workgroups' timing, and
+    # psi(x') from another parent differs in the last bits; the draws' seeds come from torch's generator: the same sequence of calls draws
+    # the same seeds)
+    for a, b in zip(out[False], out[True]):
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) < 1e-10
+    assert float((out[True][0] - out[True][2]).abs().max()) < 1e-10
