@@ -662,9 +662,10 @@ class ReduceVmcStep(Workload):
         self.roofline_note = ("one launch: enumeration of all columns (exact matrix elements; the sub-eps ones also as float32 through global memory), kept columns "
                               "placed by the rank of their bit in an LDS bitmap, the N draws located one lane per draw in segments of 16 columns (binary search + 64 bytes read back), hit counts by the rank of "
                               "a column's bit in an LDS bitmap, hash-table de-duplication (four 16-byte coherent probes per thread side by side), records with direct row "
-                              "links, the distinct x' with their parent walkers.  The kernel is bound by its VECTOR INSTRUCTIONS: `achieved` = SQ_INSTS_VALU per launch / "
-                              "live kernel time against the 2-cycle issue peak (`frac_of_4cycle_issue`: against the rate one wave sustains); `algorithmic_frac` is SURVEY "
-                              "8(d)'s HBM form (the 2 MiB integral plan lives in the L2, so it says how far the kernel is from being memory-bound, not how good it is); "
+                              "links, the distinct x' with their parent walkers.  `achieved` / `frac`: SURVEY 8(d)'s form -- B_fused (integral gathers counted once each + walker "
+                              "+ result) x walkers / the kernel's live time against 8 TB/s; the 2 MiB integral plan lives in the L2, so it says how far the kernel is from "
+                              "being memory-bound, not how good it is.  What limits the kernel is VECTOR INSTRUCTION ISSUE (`limited_by`, `valu`: SQ_INSTS_VALU per launch / "
+                              "live kernel time against the 2-cycle issue peak; `frac_of_4cycle_issue`: against the rate one wave sustains); "
                               "`traffic` = (2 FETCH_SIZE + WRITE_SIZE) x 1024 of the same profile")
 
     def step(self):
@@ -1284,6 +1285,14 @@ def main():
                 out["l2_hit_rate"] = pmc["l2_hit_rate"]
             if pmc.get("rocprof_kernel_avg_ns"):
                 out["rocprof_kernel_ms"] = pmc["rocprof_kernel_avg_ns"] * 1e-6
+            if alg is not None:
+                # The contract's shape at the top level -- SURVEY 8(d): algorithmic bytes per launch / the kernel's live time against 8 TB/s --
+                # with the roof that actually limits the kernel (vector instruction issue) in `valu`
+                valu = {k: out[k] for k in ("achieved", "peak", "unit", "frac", "frac_of_4cycle_issue", "valu_instructions_per_launch", "source")}
+                ach_b = alg * w.n / t / 1e9
+                out.update({"bound": "hbm", "limited_by": "valu", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS, "valu": valu})
+                for k in ("frac_of_4cycle_issue", "valu_instructions_per_launch", "source"):
+                    out.pop(k, None)
         else:
             plan_bytes = w.plan.numel() * w.plan.element_size() if getattr(w, "plan", None) is not None else w.gather_bytes_per_walker * w.n
             mandatory = (w.out_bytes_per_walker + w.in_bytes_per_walker) * w.n + min(w.gather_bytes_per_walker * w.n, plan_bytes)
