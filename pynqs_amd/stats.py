@@ -58,7 +58,9 @@ def _moments(x: Tensor, prob: Tensor) -> Tensor:
         xc, pc = x.contiguous(), prob.contiguous()
         N.check(N.lib().pynqs_weighted_moments(xc.data_ptr(), int(x.is_complex()), pc.data_ptr(), x.numel(), ws.data_ptr(),
                                                torch.cuda.current_stream(dev).cuda_stream), "pynqs_weighted_moments")
-        return ws[:4].clone()
+        # (a view, no copy kernel: the kernel overwrites these four words on its next call, by which time dist_stats_moments -- the one caller --
+        # has reduced and consumed them in stream order)
+        return ws[:4]
     w = _wdot(x, prob)
     z = torch.zeros((), dtype=prob.dtype, device=x.device)
     return torch.stack([w.real if torch.is_complex(w) else w, w.imag if torch.is_complex(w) else z,
